@@ -1,0 +1,53 @@
+// capi_core.hip -- version, error text and device-memory helpers of the C ABI.
+#include "capi_common.hpp"
+
+using namespace csdr;
+
+extern "C" {
+
+int csdr_version(void) { return 100; }
+const char *csdr_last_error(void) { return last_error_ref().c_str(); }
+
+int csdr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void *csdr_dev_alloc(int device, unsigned long long bytes)
+{
+    if (!device_ok(device)) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        fail(CSDR_ENOMEM, "hipMalloc(%llu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+int csdr_dev_free(int device, void *p)
+{
+    if (!device_ok(device)) return CSDR_EHIP;
+    CSDR_HIP(hipFree(p));
+    return CSDR_OK;
+}
+int csdr_dev_upload(int device, void *dst, const void *src, unsigned long long bytes)
+{
+    if (!device_ok(device)) return CSDR_EHIP;
+    CSDR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return CSDR_OK;
+}
+int csdr_dev_download(int device, void *dst, const void *src, unsigned long long bytes)
+{
+    if (!device_ok(device)) return CSDR_EHIP;
+    CSDR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+int csdr_dev_sync(int device)
+{
+    if (!device_ok(device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    return CSDR_OK;
+}
+
+}  // extern "C"

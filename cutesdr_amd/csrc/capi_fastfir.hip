@@ -1,0 +1,279 @@
+// capi_fastfir.hip -- C ABI for CFastFIR (single-channel host form and batched device form).
+#include "capi_common.hpp"
+#include "fastfir_kernels.h"
+#include "host_math.hpp"
+#include <cstring>
+#include <vector>
+
+using namespace csdr;
+
+static int log2_of(int n)
+{
+    int l = 0;
+    while ((1 << l) < n) l++;
+    return ((1 << l) == n) ? l : -1;
+}
+
+struct csdr_fastfir_batch {
+    int device, channels, n, log2n;
+    bool per_channel;                 // false: one shared filter
+    float *d_h;                       // [filters][n] complex fp32 in pass-F3 register order
+    float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
+    int hist_cur;                     // which half holds the previous call's tail
+    float *d_tw1, *d_tw2;
+    double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
+    std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
+    std::vector<int> perm;            // device slot -> natural bin
+};
+
+static void build_perm(csdr_fastfir_batch *b)
+{
+    const int T = b->n / 32;
+    b->perm.resize(b->n);
+    // slot layout: float4 index j*T + t holds registers r = 2j, 2j+1 of thread t
+    for (int j = 0; j < 16; j++)
+        for (int t = 0; t < T; t++)
+            for (int e = 0; e < 2; e++)
+                b->perm[(j * T + t) * 2 + e] = fastfir_bin_of(b->log2n, t, 2 * j + e);
+}
+
+static int upload_response(csdr_fastfir_batch *b, int slot, const std::vector<cd> &H)
+{
+    std::vector<float> dev(2 * (size_t)b->n);
+    for (int i = 0; i < b->n; i++) {
+        const cd v = H[b->perm[i]];
+        dev[2 * i] = (float)v.real();
+        dev[2 * i + 1] = (float)v.imag();
+    }
+    CSDR_HIP(hipMemcpy(b->d_h + (size_t)slot * 2 * b->n, dev.data(), dev.size() * sizeof(float),
+                       hipMemcpyHostToDevice));
+    return CSDR_OK;
+}
+
+extern "C" {
+
+csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_size)
+{
+    const int l2 = log2_of(fft_size);
+    if (l2 < 11 || l2 > 14 || channels < 1) {
+        fail(CSDR_EINVAL, "fft_size must be 2048..16384 (power of two), channels >= 1");
+        return nullptr;
+    }
+    if (!device_ok(device)) return nullptr;
+    csdr_fastfir_batch *b = new csdr_fastfir_batch();
+    b->device = device; b->channels = channels; b->n = fft_size; b->log2n = l2;
+    b->per_channel = false; b->hist_cur = 0;
+    b->d_h = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
+    b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
+    build_perm(b);
+    const size_t hbytes = (size_t)fft_size * 8, histbytes = 2 * (size_t)channels * (fft_size / 2) * 8;
+    std::vector<float> tw1(2 * 1024), tw2(2 * 1024);
+    for (int i = 0; i < 1024; i++) {
+        const double a = kTwoPi * (double)i / (double)fft_size;
+        tw1[2 * i] = (float)std::cos(a); tw1[2 * i + 1] = (float)std::sin(a);
+    }
+    for (int k = 0; k < 32; k++)
+        for (int i = 0; i < 32; i++) {
+            const double a = kTwoPi * (double)(i * k) / 1024.0;
+            tw2[2 * (k * 32 + i)] = (float)std::cos(a); tw2[2 * (k * 32 + i) + 1] = (float)std::sin(a);
+        }
+    bool ok = hipMalloc((void **)&b->d_h, hbytes) == hipSuccess &&
+              hipMalloc((void **)&b->d_hist, histbytes) == hipSuccess &&
+              hipMalloc((void **)&b->d_tw1, 8192) == hipSuccess &&
+              hipMalloc((void **)&b->d_tw2, 8192) == hipSuccess &&
+              hipMemset(b->d_h, 0, hbytes) == hipSuccess &&
+              hipMemset(b->d_hist, 0, histbytes) == hipSuccess &&
+              hipMemcpy(b->d_tw1, tw1.data(), 8192, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(b->d_tw2, tw2.data(), 8192, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        fail(CSDR_ENOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        csdr_fastfir_batch_destroy(b);
+        return nullptr;
+    }
+    b->resp.assign(1, std::vector<cd>(fft_size, cd(0, 0)));
+    return b;
+}
+
+void csdr_fastfir_batch_destroy(csdr_fastfir_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->d_h) (void)hipFree(b->d_h);
+    if (b->d_hist) (void)hipFree(b->d_hist);
+    if (b->d_tw1) (void)hipFree(b->d_tw1);
+    if (b->d_tw2) (void)hipFree(b->d_tw2);
+    delete b;
+}
+
+int csdr_fastfir_batch_setup(csdr_fastfir_batch *b, int channel, double flo, double fhi,
+                             double offset, double fs)
+{
+    if (!b || channel < -1 || channel >= b->channels) return fail(CSDR_EINVAL, "bad handle/channel");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    if (channel < 0) {
+        // shared filter: same early-out as the reference (fastfir.cpp:182-186)
+        if (!b->per_channel && flo == b->flo && fhi == b->fhi && offset == b->off && fs == b->fs) return 0;
+        b->flo = flo; b->fhi = fhi; b->off = offset; b->fs = fs;
+    }
+    std::vector<cd> H;
+    if (!fastfir_design(b->n, flo, fhi, offset, fs, H))
+        return fail(CSDR_EINVAL, "filter parameter error (reference keeps the previous taps)");
+    if (channel >= 0 && !b->per_channel) {
+        // switch to one filter per channel, seeded with the shared one
+        float *nh = nullptr;
+        const size_t one = (size_t)b->n * 8;
+        CSDR_HIP(hipMalloc((void **)&nh, one * b->channels));
+        for (int c = 0; c < b->channels; c++)
+            CSDR_HIP(hipMemcpy((char *)nh + one * c, b->d_h, one, hipMemcpyDeviceToDevice));
+        CSDR_HIP(hipFree(b->d_h));
+        b->d_h = nh;
+        b->resp.resize(b->channels, b->resp[0]);
+        b->per_channel = true;
+    }
+    if (channel < 0 && b->per_channel) {
+        for (int c = 0; c < b->channels; c++) {
+            int rc = upload_response(b, c, H);
+            if (rc) return rc;
+            b->resp[c] = H;
+        }
+    } else {
+        const int slot = channel < 0 ? 0 : channel;
+        int rc = upload_response(b, slot, H);
+        if (rc) return rc;
+        b->resp[slot] = H;
+    }
+    return 1;
+}
+
+int csdr_fastfir_batch_reset(csdr_fastfir_batch *b)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipMemset(b->d_hist, 0, 2 * (size_t)b->channels * (b->n / 2) * 8));
+    return CSDR_OK;
+}
+
+int csdr_fastfir_batch_get_response(csdr_fastfir_batch *b, int channel, double *h_out)
+{
+    if (!b || !h_out || channel < 0 || channel >= b->channels) return fail(CSDR_EINVAL, "bad argument");
+    const std::vector<cd> &H = b->resp[b->per_channel ? channel : 0];
+    memcpy(h_out, H.data(), sizeof(cd) * H.size());
+    return CSDR_OK;
+}
+
+int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long long in_stride,
+                               int n_per_channel, float *d_out, long long out_stride,
+                               void *stream, int blocks_per_wg)
+{
+    if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad handle or null buffer");
+    const int L = b->n / 2;
+    if (n_per_channel <= 0 || n_per_channel % L != 0)
+        return fail(CSDR_EINVAL, "n_per_channel (%d) must be a positive multiple of the hop %d", n_per_channel, L);
+    if (in_stride < n_per_channel || out_stride < n_per_channel)
+        return fail(CSDR_EINVAL, "channel stride shorter than n_per_channel");
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15 || (in_stride & 1) || (out_stride & 1))
+        return fail(CSDR_EINVAL, "buffers must be 16-byte aligned and strides even");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    hipStream_t s = (hipStream_t)stream;
+    FastFirArgs a;
+    const size_t hist_half = (size_t)b->channels * L * 2;      // floats
+    a.in = (const v2f_h *)d_in; a.out = (v2f_h *)d_out;
+    a.hist = (const v2f_h *)(b->d_hist + b->hist_cur * hist_half);
+    a.hist_next = (v2f_h *)(b->d_hist + (b->hist_cur ^ 1) * hist_half);
+    a.h = (const v4f_h *)b->d_h; a.tw1 = (const v2f_h *)b->d_tw1; a.tw2 = (const v2f_h *)b->d_tw2;
+    a.in_stride = in_stride; a.out_stride = out_stride;
+    a.h_stride = b->per_channel ? b->n / 2 : 0;
+    a.channels = b->channels;
+    a.nblocks = n_per_channel / L;
+    if (blocks_per_wg <= 0) {
+        // enough workgroups to fill 256 CUs a few times over, runs as long as that allows
+        long want = 1024;
+        long runs = (want + b->channels - 1) / b->channels;
+        if (runs < 1) runs = 1;
+        if (runs > a.nblocks) runs = a.nblocks;
+        blocks_per_wg = (int)((a.nblocks + runs - 1) / runs);
+    }
+    if (blocks_per_wg > a.nblocks) blocks_per_wg = a.nblocks;
+    a.blocks_per_run = blocks_per_wg;
+    a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
+    CSDR_HIP(fastfir_launch(b->log2n, a, s));
+    b->hist_cur ^= 1;        // the kernel left this call's tail in the other half
+    return CSDR_OK;
+}
+
+/* ---------------- single-channel host form: CFastFIR drop-in ---------------- */
+}  // extern "C"
+
+struct csdr_fastfir {
+    csdr_fastfir_batch *b;
+    int n, pending;                  // pending < n/2 input samples not yet processed
+    std::vector<float> stage_in, stage_out;
+    float *d_in, *d_out;
+    size_t cap;                      // device staging capacity in samples
+};
+
+static int ensure_cap(csdr_fastfir *f, size_t samples)
+{
+    if (samples <= f->cap) return CSDR_OK;
+    if (f->d_in) (void)hipFree(f->d_in);
+    if (f->d_out) (void)hipFree(f->d_out);
+    f->d_in = f->d_out = nullptr; f->cap = 0;
+    CSDR_HIP(hipMalloc((void **)&f->d_in, samples * 8));
+    CSDR_HIP(hipMalloc((void **)&f->d_out, samples * 8));
+    f->cap = samples;
+    return CSDR_OK;
+}
+
+extern "C" {
+
+csdr_fastfir *csdr_fastfir_create(int device, int fft_size)
+{
+    csdr_fastfir_batch *b = csdr_fastfir_batch_create(device, 1, fft_size);
+    if (!b) return nullptr;
+    csdr_fastfir *f = new csdr_fastfir();
+    f->b = b; f->n = fft_size; f->pending = 0; f->d_in = f->d_out = nullptr; f->cap = 0;
+    return f;
+}
+
+void csdr_fastfir_destroy(csdr_fastfir *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->b->device);
+    if (f->d_in) (void)hipFree(f->d_in);
+    if (f->d_out) (void)hipFree(f->d_out);
+    csdr_fastfir_batch_destroy(f->b);
+    delete f;
+}
+
+int csdr_fastfir_setup(csdr_fastfir *f, double flo, double fhi, double offset, double fs)
+{
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    return csdr_fastfir_batch_setup(f->b, -1, flo, fhi, offset, fs);
+}
+
+int csdr_fastfir_process(csdr_fastfir *f, int n, const double *in_iq, double *out_iq)
+{
+    if (!f || n < 0 || (n > 0 && (!in_iq || !out_iq))) return fail(CSDR_EINVAL, "bad argument");
+    if (n == 0) return 0;
+    if (!device_ok(f->b->device)) return CSDR_EHIP;
+    const int L = f->n / 2;
+    // append to the pending (not yet hop-complete) samples, fp64 -> fp32 at the boundary
+    const size_t old = f->stage_in.size();
+    f->stage_in.resize(old + 2 * (size_t)n);
+    for (size_t i = 0; i < 2 * (size_t)n; i++) f->stage_in[old + i] = (float)in_iq[i];
+    const int avail = (int)(f->stage_in.size() / 2);
+    const int nproc = (avail / L) * L;
+    if (nproc == 0) return 0;
+    int rc = ensure_cap(f, (size_t)nproc);
+    if (rc) return rc;
+    CSDR_HIP(hipMemcpy(f->d_in, f->stage_in.data(), (size_t)nproc * 8, hipMemcpyHostToDevice));
+    rc = csdr_fastfir_batch_process(f->b, f->d_in, nproc, nproc, f->d_out, nproc, nullptr, 0);
+    if (rc) return rc;
+    f->stage_out.resize(2 * (size_t)nproc);
+    CSDR_HIP(hipMemcpy(f->stage_out.data(), f->d_out, (size_t)nproc * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < 2 * (size_t)nproc; i++) out_iq[i] = (double)f->stage_out[i];
+    f->stage_in.erase(f->stage_in.begin(), f->stage_in.begin() + 2 * (size_t)nproc);
+    return nproc;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// host_math.hpp -- fp64 host-side setup math (runs once per parameter change, never per sample).
+#pragma once
+#include <cmath>
+#include <complex>
+#include <vector>
+
+namespace csdr {
+
+typedef std::complex<double> cd;
+constexpr double kTwoPi = 2.0 * 3.14159265358979323846;   // K_2PI, dsp/datatypes.h:44
+constexpr double kPi = 3.14159265358979323846;
+
+// Unnormalised complex DFT, sign=+1 is the reference's FwdFFT convention (dsp/fft.cpp:416-420).
+inline void host_fft(std::vector<cd> &a, int sign)
+{
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len >> 1;
+        for (size_t k = 0; k < half; k++) {
+            const double ang = sign * kTwoPi * (double)k / (double)len;
+            const cd w(std::cos(ang), std::sin(ang));
+            for (size_t b = k; b < n; b += len) {
+                const cd u = a[b], v = a[b + half] * w;
+                a[b] = u + v;
+                a[b + half] = u - v;
+            }
+        }
+    }
+}
+
+// CFastFIR::SetupParameters (dsp/fastfir.cpp:178-259) with FFT size n, taps n/2+1:
+// Blackman-Nuttall windowed sinc (window :93-101), shifted to the pass-band centre, scaled by
+// 1/n, zero padded and forward transformed.  Returns false when the reference's sanity check
+// rejects the edges (it then keeps the old taps).
+inline bool fastfir_design(int n, double flo, double fhi, double offset, double fs, std::vector<cd> &H)
+{
+    const int p = n / 2 + 1;
+    flo += offset;
+    fhi += offset;
+    if (flo >= fhi || flo >= fs / 2.0 || flo <= -fs / 2.0 || fhi >= fs / 2.0 || fhi <= -fs / 2.0)
+        return false;
+    const double nfl = flo / fs, nfh = fhi / fs;
+    const double nfc = (nfh - nfl) / 2.0, nfs = kTwoPi * (nfh + nfl) / 2.0;
+    const double centre = 0.5 * (double)(p - 1);
+    H.assign(n, cd(0.0, 0.0));
+    for (int i = 0; i < p; i++) {
+        const double x = (double)i - centre;
+        double z;
+        if ((double)i == centre) {
+            z = 2.0 * nfc;
+        } else {
+            const double w = 0.3635819 - 0.4891775 * std::cos((kTwoPi * i) / (p - 1)) +
+                             0.1365995 * std::cos((2.0 * kTwoPi * i) / (p - 1)) -
+                             0.0106411 * std::cos((3.0 * kTwoPi * i) / (p - 1));
+            z = std::sin(kTwoPi * x * nfc) / (kPi * x) * w;
+        }
+        H[i] = cd(z * std::cos(nfs * x) / (double)n, z * std::sin(nfs * x) / (double)n);
+    }
+    host_fft(H, +1);
+    return true;
+}
+
+}  // namespace csdr
