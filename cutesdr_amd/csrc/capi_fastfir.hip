@@ -20,6 +20,7 @@ struct csdr_fastfir_batch {
     float *d_h;                       // [filters][n] complex fp32 in pass-F3 register order
     float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
     int hist_cur;                     // which half holds the previous call's tail
+    int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
@@ -62,7 +63,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
     if (!device_ok(device)) return nullptr;
     csdr_fastfir_batch *b = new csdr_fastfir_batch();
     b->device = device; b->channels = channels; b->n = fft_size; b->log2n = l2;
-    b->per_channel = false; b->hist_cur = 0;
+    b->per_channel = false; b->hist_cur = 0; b->dbg_stage = 0; b->dbg_out = nullptr;
     b->d_h = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
     build_perm(b);
@@ -196,8 +197,17 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     if (blocks_per_wg > a.nblocks) blocks_per_wg = a.nblocks;
     a.blocks_per_run = blocks_per_wg;
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
+    a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
     CSDR_HIP(fastfir_launch(b->log2n, a, s));
     b->hist_cur ^= 1;        // the kernel left this call's tail in the other half
+    return CSDR_OK;
+}
+
+/* test-only hook, not part of the public ABI: dump the LDS image after a pass */
+int csdr__dbg_fastfir_stage(csdr_fastfir_batch *b, int stage, float *d_dbg)
+{
+    if (!b) return CSDR_EINVAL;
+    b->dbg_stage = stage; b->dbg_out = d_dbg;
     return CSDR_OK;
 }
 

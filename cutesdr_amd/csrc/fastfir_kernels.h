@@ -22,6 +22,8 @@ struct FastFirArgs {
     int nblocks;          // hops of N/2 samples per channel in this call
     int blocks_per_run;   // consecutive blocks walked by one workgroup
     int runs;             // ceil(nblocks / blocks_per_run)
+    int dbg_stage;        // 0 in production; >0 selects the diagnostic twin kernel
+    v2f_h *dbg;           // [N] LDS image dump of the diagnostic twin
 };
 
 hipError_t fastfir_launch(int log2n, const FastFirArgs &a, hipStream_t stream);

@@ -33,7 +33,20 @@ struct FastFirCfg {
     static constexpr int LDS_BYTES = (LDS_DATA + 1024) * 8;         // + 32x32 twiddle table
 };
 
-template <int LOG2N>
+// DBG=true builds a diagnostic twin that copies the (unpadded) LDS image to a.dbg after pass
+// a.dbg_stage (1 = F1, 2 = F2, 3 = F3+H+I1, 4 = I2) of its first block and exits.
+template <int LOG2N, bool DBG>
+__device__ __forceinline__ void dbg_dump(const FastFirArgs &a, const v2f *lds, int stage)
+{
+    if constexpr (DBG) {
+        if (a.dbg_stage == stage) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < (1 << LOG2N); i += blockDim.x) a.dbg[i] = lds[lds_pad(i)];
+        }
+    }
+}
+
+template <int LOG2N, bool DBG = false>
 __global__ __launch_bounds__(FastFirCfg<LOG2N>::T)
 void fastfir_os_kernel(FastFirArgs a)
 {
@@ -134,6 +147,8 @@ void fastfir_os_kernel(FastFirArgs a)
             }
         });
         __syncthreads();
+        dbg_dump<LOG2N, DBG>(a, lds, 1);
+        if (DBG && a.dbg_stage == 1) return;
 
         // ---------------- F2: radix-32 DIF inside sub-transform sb, column sn -------------
         {
@@ -154,6 +169,8 @@ void fastfir_os_kernel(FastFirArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        dbg_dump<LOG2N, DBG>(a, lds, 2);
+        if (DBG && a.dbg_stage == 2) return;
 
         // ---------------- F3 + H + I1: rows 32t..32t+31, registers only -------------------
         {
@@ -181,6 +198,9 @@ void fastfir_os_kernel(FastFirArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        dbg_dump<LOG2N, DBG>(a, lds, 3);
+        if (DBG && a.dbg_stage == 3) return;
+
         // ---------------- I2: conj twiddle, radix-32 DIT inverse ---------------------------
         {
             const int base = lds_pad(1024 * sb) + sn;
@@ -194,6 +214,8 @@ void fastfir_os_kernel(FastFirArgs a)
             for (int n1 = 0; n1 < 32; n1++) lds[base + 34 * n1] = x[n1];
         }
         __syncthreads();
+        dbg_dump<LOG2N, DBG>(a, lds, 4);
+        if (DBG && a.dbg_stage == 4) return;
 
         // ---------------- I3: conj twiddle, radix-R0 DIT inverse, store valid half ---------
         static_for<0, R0>([&](auto Rr) {
@@ -259,13 +281,20 @@ static hipError_t launch_one(const FastFirArgs &a, hipStream_t stream)
     using Cfg = FastFirCfg<LOG2N>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os_kernel<LOG2N>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os_kernel<LOG2N, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(a.channels * a.runs), block(Cfg::T);
-    hipLaunchKernelGGL(fastfir_os_kernel<LOG2N>, grid, block, Cfg::LDS_BYTES, stream, a);
+    if (a.dbg_stage > 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os_kernel<LOG2N, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((fastfir_os_kernel<LOG2N, true>), dim3(1), block, Cfg::LDS_BYTES, stream, a);
+    } else {
+        hipLaunchKernelGGL((fastfir_os_kernel<LOG2N, false>), grid, block, Cfg::LDS_BYTES, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // cos(2*pi*k/32), k = 0..31
-__device__ static constexpr float kCos32[32] = {
+static constexpr float kCos32[32] = {
     1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
     0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
     0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
@@ -27,23 +27,23 @@ __device__ static constexpr float kCos32[32] = {
     0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
     0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
 
-__device__ __forceinline__ v2f cmul(v2f a, v2f w)
+__host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
     v2f wr = {-w.y, w.x};
     return a.xx * w + a.yy * wr;
 }
-__device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)      // a * conj(w)
+__host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)      // a * conj(w)
 {
-    v2f wr = {w.y, -w.x};
-    return a.xx * w + a.yy * wr;
+    v2f wc = {w.x, -w.y}, wr = {w.y, w.x};
+    return a.xx * wc + a.yy * wr;
 }
 // a * (+j) and a * (-j)
-__device__ __forceinline__ v2f mul_pj(v2f a) { return v2f{-a.y, a.x}; }
-__device__ __forceinline__ v2f mul_mj(v2f a) { return v2f{a.y, -a.x}; }
+__host__ __device__ __forceinline__ v2f mul_pj(v2f a) { return v2f{-a.y, a.x}; }
+__host__ __device__ __forceinline__ v2f mul_mj(v2f a) { return v2f{a.y, -a.x}; }
 
 // a * e^{SIGN * j * 2*pi*K/32}, K in [0,16): trivial rotations cost no multiplies
 template <int K, int SIGN>
-__device__ __forceinline__ v2f mul_w32(v2f a)
+__host__ __device__ __forceinline__ v2f mul_w32(v2f a)
 {
     if constexpr (K == 0) {
         return a;
@@ -74,7 +74,7 @@ template <int R> __host__ __device__ constexpr int bitrev(int v)
 
 // compile-time loop
 template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f)
+__host__ __device__ __forceinline__ void static_for(F &&f)
 {
     if constexpr (I < N) {
         f(std::integral_constant<int, I>{});
@@ -84,7 +84,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 // Decimation-in-frequency radix-R DFT over registers: natural order in, X[k] ends in x[bitrev(k)].
 template <int LEN, int R, int SIGN>
-__device__ __forceinline__ void dif_stage(v2f (&x)[R])
+__host__ __device__ __forceinline__ void dif_stage(v2f (&x)[R])
 {
     constexpr int H = LEN / 2;
     static_for<0, R / LEN>([&](auto B) {
@@ -98,14 +98,14 @@ __device__ __forceinline__ void dif_stage(v2f (&x)[R])
     if constexpr (LEN > 2) dif_stage<LEN / 2, R, SIGN>(x);
 }
 template <int R, int SIGN>
-__device__ __forceinline__ void dft_dif(v2f (&x)[R])
+__host__ __device__ __forceinline__ void dft_dif(v2f (&x)[R])
 {
     if constexpr (R > 1) dif_stage<R, R, SIGN>(x);
 }
 
 // Decimation-in-time radix-R DFT: input y[k] in x[bitrev(k)], natural order out.
 template <int LEN, int R, int SIGN>
-__device__ __forceinline__ void dit_stage(v2f (&x)[R])
+__host__ __device__ __forceinline__ void dit_stage(v2f (&x)[R])
 {
     constexpr int H = LEN / 2;
     static_for<0, R / LEN>([&](auto B) {
@@ -119,14 +119,14 @@ __device__ __forceinline__ void dit_stage(v2f (&x)[R])
     if constexpr (LEN < R) dit_stage<LEN * 2, R, SIGN>(x);
 }
 template <int R, int SIGN>
-__device__ __forceinline__ void dft_dit(v2f (&x)[R])
+__host__ __device__ __forceinline__ void dft_dit(v2f (&x)[R])
 {
     if constexpr (R > 1) dit_stage<2, R, SIGN>(x);
 }
 
 // w^k for k = 0..R-1 by a log-depth product tree (pw[0] unused = 1)
 template <int R>
-__device__ __forceinline__ void twiddle_powers(v2f w, v2f (&pw)[R])
+__host__ __device__ __forceinline__ void twiddle_powers(v2f w, v2f (&pw)[R])
 {
     pw[0] = v2f{1.0f, 0.0f};
     if constexpr (R > 1) pw[1] = w;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void twiddle_powers(v2f w, v2f (&pw)[R])
 
 // Hide a loop-invariant value from LICM (used where recomputing is cheaper than the registers
 // a hoisted copy would pin for the whole block loop).
-__device__ __forceinline__ v2f opaque(v2f v)
+__host__ __device__ __forceinline__ v2f opaque(v2f v)
 {
     asm volatile("" : "+v"(v));
     return v;
@@ -147,6 +147,6 @@ __device__ __forceinline__ v2f opaque(v2f v)
 
 // LDS index padding: 2 elements (16 B) every 32 elements keeps float4 alignment and makes the
 // stride-32 / stride-1024 access patterns of the three passes bank-conflict free.
-__device__ __forceinline__ int lds_pad(int pos) { return pos + ((pos >> 5) << 1); }
+__host__ __device__ __forceinline__ int lds_pad(int pos) { return pos + ((pos >> 5) << 1); }
 
 }  // namespace csdr
