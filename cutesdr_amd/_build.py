@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libcutesdr_mi.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"] + \
+    os.environ.get("CSDR_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

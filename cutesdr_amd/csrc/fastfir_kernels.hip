@@ -23,6 +23,45 @@
 
 namespace csdr {
 
+// ---- buffer (SRSRC) addressing: one wave-uniform descriptor per stream, a 32-bit per-lane byte
+//      offset and a scalar offset per access -- keeps 64-bit address pairs out of the VGPR file
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ v4f buf_load16(rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store16(rsrc_t r, int voff, int soff, v4f v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, 0);
+}
+
+// Wide stores (buffer_store_dwordx4 with an SGPR soffset, ds_write_b128) read their data VGPRs
+// over several cycles after issue.  hipcc (ROCm 7.2) pads the ">64-bit store data overwritten by
+// the next VALU" hazard only for the soffset-less form, and reuses one 128-bit tuple for
+// consecutive stores (v_mov into it right behind the previous store): on gfx950 that corrupted
+// the second dword in lanes 12-15 of every 16, intermittently (tools/debug_fastfir5.py).  So
+// every group of wide stores first materialises all its 128-bit operands in distinct registers
+// (store_operand), is fenced from the scheduler, and ends with two wait states.
+#define CSDR_STORE_GROUP_BEGIN() __builtin_amdgcn_sched_barrier(0)
+#define CSDR_STORE_GROUP_END()            \
+    do {                                  \
+        asm volatile("s_nop 1");          \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+__device__ __forceinline__ v4f store_operand(v2f lo, v2f hi)
+{
+    v4f v = {lo.x, lo.y, hi.x, hi.y};
+    asm volatile("" : "+v"(v));         // force the tuple to exist before the fenced store group
+    return v;
+}
+
 template <int LOG2N>
 struct FastFirCfg {
     static constexpr int N = 1 << LOG2N;
@@ -77,10 +116,22 @@ void fastfir_os_kernel(FastFirArgs a)
 
     for (int i = t; i < 1024; i += T) tw2[i] = a.tw2[i];
 
-    const v2f *in = a.in + (long)ch * a.in_stride;
-    const v2f *hist = a.hist + (long)ch * L;
-    v2f *out = a.out + (long)ch * a.out_stride;
-    const v4f *H = a.h + (long)ch * a.h_stride;
+    const rsrc_t r_in = make_rsrc(a.in + (long)ch * a.in_stride, (unsigned)a.nblocks * L * 8u);
+    const rsrc_t r_hist = make_rsrc(a.hist + (long)ch * L, L * 8u);
+    const rsrc_t r_out = make_rsrc(a.out + (long)ch * a.out_stride, (unsigned)a.nblocks * L * 8u);
+    const rsrc_t r_h = make_rsrc(a.h + (long)ch * a.h_stride, N * 8u);
+    const int voff = t * (G * 8);             // this thread's G adjacent columns, in bytes
+    // one hop-half of samples: rows n1 = 0..HALF-1 of 1024 samples, columns G*t .. G*t+G-1
+    auto load_half = [&](rsrc_t r, int soff, v2f (&dst)[16]) {
+#pragma unroll
+        for (int n1 = 0; n1 < HALF; n1++)
+#pragma unroll
+            for (int e = 0; e < G; e += 2) {
+                v4f v = buf_load16(r, voff + e * 8, soff + n1 * 8192);
+                dst[e * HALF + n1] = v2f{v.x, v.y};
+                dst[(e + 1) * HALF + n1] = v2f{v.z, v.w};
+            }
+    };
 
     // outer-pass base twiddles W_N^{n2}, n2 = G*t+e: constant over the block loop
     v2f w1[G];
@@ -89,33 +140,26 @@ void fastfir_os_kernel(FastFirArgs a)
 
     // x[e*R0 + n1] <-> sample 1024*n1 + G*t + e of the block
     v2f x[32];
-    v2f carry[16];       // the half that becomes the old half of the next block
+    v2f carry[16];       // new half of the previous block = old half of this one
+    v2f nxt[16];         // new half of this block, fetched while the previous block finished
 
     // old half of the first block: previous call's tail (b0 == 0) or the input itself
-    {
-        const v2f *src = (b0 == 0) ? hist : (in + (long)(b0 - 1) * L);
-#pragma unroll
-        for (int n1 = 0; n1 < HALF; n1++)
-#pragma unroll
-            for (int e = 0; e < G; e++) carry[e * HALF + n1] = src[1024 * n1 + G * t + e];
-    }
+    if (b0 == 0) load_half(r_hist, 0, carry);
+    else load_half(r_in, (b0 - 1) * (L * 8), carry);
+    load_half(r_in, b0 * (L * 8), nxt);
 
     const int sb = t >> 5, sn = t & 31;       // sub-transform and column of passes F2 / I2
 
     for (int b = b0; b < b1; b++) {
         // ---------------- F1: load, radix-R0 DIF, twiddle, scatter to LDS ----------------
-        {
-            const v2f *src = in + (long)b * L;
 #pragma unroll
-            for (int e = 0; e < G; e++)
+        for (int e = 0; e < G; e++)
 #pragma unroll
-                for (int n1 = 0; n1 < HALF; n1++) {
-                    x[e * R0 + n1] = carry[e * HALF + n1];
-                    v2f nv = src[1024 * n1 + G * t + e];
-                    x[e * R0 + HALF + n1] = nv;
-                    carry[e * HALF + n1] = nv;
-                }
-        }
+            for (int n1 = 0; n1 < HALF; n1++) {
+                x[e * R0 + n1] = carry[e * HALF + n1];
+                x[e * R0 + HALF + n1] = nxt[e * HALF + n1];
+                carry[e * HALF + n1] = nxt[e * HALF + n1];
+            }
 #pragma unroll
         for (int e = 0; e < G; e++) {
             v2f y[R0];
@@ -132,20 +176,23 @@ void fastfir_os_kernel(FastFirArgs a)
             for (int i = 0; i < R0; i++) x[e * R0 + i] = y[i];
         }
         __syncthreads();                       // previous block's I3 reads are done
-        static_for<0, R0>([&](auto Rr) {
-            constexpr int r = Rr.value, k0 = bitrev<R0>(r);
-            const int base = lds_pad(1024 * k0 + G * t);
-            if constexpr (G % 2 == 0) {
+        {
+            v4f wv[16];                        // (R0 rows) x (G/2 column pairs) = 16 float4
 #pragma unroll
-                for (int e = 0; e < G; e += 2) {
-                    v4f v = {x[e * R0 + r].x, x[e * R0 + r].y, x[(e + 1) * R0 + r].x, x[(e + 1) * R0 + r].y};
-                    *reinterpret_cast<v4f *>(&lds[base + e]) = v;
-                }
-            } else {
+            for (int r = 0; r < R0; r++)
 #pragma unroll
-                for (int e = 0; e < G; e++) lds[base + e] = x[e * R0 + r];
-            }
-        });
+                for (int e = 0; e < G; e += 2)
+                    wv[r * (G / 2) + e / 2] = store_operand(x[e * R0 + r], x[(e + 1) * R0 + r]);
+            CSDR_STORE_GROUP_BEGIN();
+            static_for<0, R0>([&](auto Rr) {
+                constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+                const int base = lds_pad(1024 * k0 + G * t);
+#pragma unroll
+                for (int e = 0; e < G; e += 2)
+                    *reinterpret_cast<v4f *>(&lds[base + e]) = wv[r * (G / 2) + e / 2];
+            });
+            CSDR_STORE_GROUP_END();
+        }
         __syncthreads();
         dbg_dump<LOG2N, DBG>(a, lds, 1);
         if (DBG && a.dbg_stage == 1) return;
@@ -160,10 +207,12 @@ void fastfir_os_kernel(FastFirArgs a)
                 constexpr int r = Rr.value, k1 = bitrev<32>(r);
                 x[r] = cmul(x[r], tw2[k1 * 32 + sn]);
             });
+            CSDR_STORE_GROUP_BEGIN();
             static_for<0, 32>([&](auto Rr) {
                 constexpr int r = Rr.value, k1 = bitrev<32>(r);
                 lds[base + 34 * k1] = x[r];
             });
+            CSDR_STORE_GROUP_END();
         }
         // F2 -> F3 stays inside the half-wave that owns sub-transform sb
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -174,6 +223,12 @@ void fastfir_os_kernel(FastFirArgs a)
 
         // ---------------- F3 + H + I1: rows 32t..32t+31, registers only -------------------
         {
+            // H[k] comes from L2; issue the loads before the LDS reads and the forward butterflies
+            // so that their latency is covered (pinned: the scheduler would sink them to the use)
+            v4f hv[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) hv[j] = buf_load16(r_h, t * 16, j * (T * 16));
+            __builtin_amdgcn_sched_barrier(0);
             const v4f *row = reinterpret_cast<const v4f *>(&lds[34 * t]);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -184,15 +239,18 @@ void fastfir_os_kernel(FastFirArgs a)
             dft_dif<32, +1>(x);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                v4f hv = H[j * T + t];
-                x[2 * j] = cmul(x[2 * j], v2f{hv.x, hv.y});
-                x[2 * j + 1] = cmul(x[2 * j + 1], v2f{hv.z, hv.w});
+                x[2 * j] = cmul(x[2 * j], v2f{hv[j].x, hv[j].y});
+                x[2 * j + 1] = cmul(x[2 * j + 1], v2f{hv[j].z, hv[j].w});
             }
             dft_dit<32, -1>(x);
             v4f *wrow = reinterpret_cast<v4f *>(&lds[34 * t]);
+            v4f wv[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                wrow[j] = v4f{x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y};
+            for (int j = 0; j < 16; j++) wv[j] = store_operand(x[2 * j], x[2 * j + 1]);
+            CSDR_STORE_GROUP_BEGIN();
+#pragma unroll
+            for (int j = 0; j < 16; j++) wrow[j] = wv[j];
+            CSDR_STORE_GROUP_END();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -210,31 +268,30 @@ void fastfir_os_kernel(FastFirArgs a)
                 if constexpr (k1 != 0) x[r] = cmul_conj(x[r], tw2[k1 * 32 + sn]);
             });
             dft_dit<32, -1>(x);
+            CSDR_STORE_GROUP_BEGIN();
 #pragma unroll
             for (int n1 = 0; n1 < 32; n1++) lds[base + 34 * n1] = x[n1];
+            CSDR_STORE_GROUP_END();
         }
         __syncthreads();
         dbg_dump<LOG2N, DBG>(a, lds, 4);
         if (DBG && a.dbg_stage == 4) return;
 
         // ---------------- I3: conj twiddle, radix-R0 DIT inverse, store valid half ---------
+        // next block's new samples: issued now, consumed at the top of the next iteration
+        if (b + 1 < b1) load_half(r_in, (b + 1) * (L * 8), nxt);
+        __builtin_amdgcn_sched_barrier(0);
         static_for<0, R0>([&](auto Rr) {
             constexpr int r = Rr.value, k0 = bitrev<R0>(r);
             const int base = lds_pad(1024 * k0 + G * t);
-            if constexpr (G % 2 == 0) {
 #pragma unroll
-                for (int e = 0; e < G; e += 2) {
-                    v4f v = *reinterpret_cast<const v4f *>(&lds[base + e]);
-                    x[e * R0 + r] = v2f{v.x, v.y};
-                    x[(e + 1) * R0 + r] = v2f{v.z, v.w};
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < G; e++) x[e * R0 + r] = lds[base + e];
+            for (int e = 0; e < G; e += 2) {
+                v4f v = *reinterpret_cast<const v4f *>(&lds[base + e]);
+                x[e * R0 + r] = v2f{v.x, v.y};
+                x[(e + 1) * R0 + r] = v2f{v.z, v.w};
             }
         });
         {
-            v2f *dst = out + (long)b * L;
             v2f y[G][R0];
 #pragma unroll
             for (int e = 0; e < G; e++) {
@@ -249,29 +306,39 @@ void fastfir_os_kernel(FastFirArgs a)
                 dft_dit<R0, -1>(y[e]);
             }
             // sample 1024*n1 + G*t + e, n1 >= R0/2  ->  output offset 1024*(n1-R0/2) + G*t + e
+            v4f sv[8];                         // (R0/2 rows) x (G/2 column pairs) = 8 float4
 #pragma unroll
-            for (int n1 = HALF; n1 < R0; n1++) {
-                v2f *p = dst + 1024 * (n1 - HALF) + G * t;
-                if constexpr (G % 2 == 0) {
+            for (int n1 = HALF; n1 < R0; n1++)
 #pragma unroll
-                    for (int e = 0; e < G; e += 2)
-                        *reinterpret_cast<v4f *>(p + e) = v4f{y[e][n1].x, y[e][n1].y, y[e + 1][n1].x, y[e + 1][n1].y};
-                } else {
+                for (int e = 0; e < G; e += 2)
+                    sv[(n1 - HALF) * (G / 2) + e / 2] = store_operand(y[e][n1], y[e + 1][n1]);
+            CSDR_STORE_GROUP_BEGIN();
 #pragma unroll
-                    for (int e = 0; e < G; e++) p[e] = y[e][n1];
-                }
-            }
+            for (int n1 = HALF; n1 < R0; n1++)
+#pragma unroll
+                for (int e = 0; e < G; e += 2)
+                    buf_store16(r_out, voff + e * 8, b * (L * 8) + (n1 - HALF) * 8192,
+                                sv[(n1 - HALF) * (G / 2) + e / 2]);
+            CSDR_STORE_GROUP_END();
         }
     }
 
     // the tail of this call's input is the overlap of the next call (fastfir.cpp:280-300);
     // written to the other half of the ping-pong history so no workgroup can still be reading it
     if (b1 == a.nblocks) {
-        v2f *hnext = a.hist_next + (long)ch * L;
+        const rsrc_t r_hn = make_rsrc(a.hist_next + (long)ch * L, L * 8u);
+        v4f sv[8];
 #pragma unroll
         for (int n1 = 0; n1 < HALF; n1++)
 #pragma unroll
-            for (int e = 0; e < G; e++) hnext[1024 * n1 + G * t + e] = carry[e * HALF + n1];
+            for (int e = 0; e < G; e += 2)
+                sv[n1 * (G / 2) + e / 2] = store_operand(carry[e * HALF + n1], carry[(e + 1) * HALF + n1]);
+        CSDR_STORE_GROUP_BEGIN();
+#pragma unroll
+        for (int n1 = 0; n1 < HALF; n1++)
+#pragma unroll
+            for (int e = 0; e < G; e += 2) buf_store16(r_hn, voff + e * 8, n1 * 8192, sv[n1 * (G / 2) + e / 2]);
+        CSDR_STORE_GROUP_END();
     }
 }
 

@@ -27,41 +27,129 @@ static constexpr float kCos32[32] = {
     0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
     0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
 
-__host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w)
+// ---- packed complex arithmetic ---------------------------------------------------------------
+// On the device the swizzles and sign flips of complex products ride on the VOP3P op_sel / neg
+// modifiers (one instruction each) instead of v_xor/v_mov pairs.  Every asm statement holds ONE
+// instruction, so hipcc's hazard recogniser still pads the 1-wait-state "packed fp32 result ->
+// next VALU" hazard around it (checked in the ISA).  The host build (unit tests of the butterfly
+// algebra) uses the plain C++ forms.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CSDR_NO_PK_ASM)
+#define CSDR_PK_ASM 1
+#else
+#define CSDR_PK_ASM 0
+#endif
+
+// product with a compile-time constant twiddle: hipcc keeps w and its rotation in SGPR pairs
+__host__ __device__ __forceinline__ v2f cmul_c(v2f a, v2f w)
 {
     v2f wr = {-w.y, w.x};
     return a.xx * w + a.yy * wr;
 }
-__host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)      // a * conj(w)
+
+// a * w, w a run-time value
+__host__ __device__ __forceinline__ v2f cmul(v2f a, v2f w)
 {
+#if CSDR_PK_ASM
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
+    return cmul_c(a, w);
+#endif
+}
+// a * conj(w)
+__host__ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w)
+{
+#if CSDR_PK_ASM
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
     v2f wc = {w.x, -w.y}, wr = {w.y, w.x};
     return a.xx * wc + a.yy * wr;
+#endif
 }
-// a * (+j) and a * (-j)
-__host__ __device__ __forceinline__ v2f mul_pj(v2f a) { return v2f{-a.y, a.x}; }
-__host__ __device__ __forceinline__ v2f mul_mj(v2f a) { return v2f{a.y, -a.x}; }
-
-// a * e^{SIGN * j * 2*pi*K/32}, K in [0,16): trivial rotations cost no multiplies
-template <int K, int SIGN>
-__host__ __device__ __forceinline__ v2f mul_w32(v2f a)
+// u + S*j*v  (S = +1 or -1)
+template <int S>
+__host__ __device__ __forceinline__ v2f add_jv(v2f u, v2f v)
 {
+#if CSDR_PK_ASM
+    v2f r;
+    if constexpr (S > 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(u), "v"(v));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(u), "v"(v));
+    return r;
+#else
+    return S > 0 ? v2f{u.x - v.y, u.y + v.x} : v2f{u.x + v.y, u.y - v.x};
+#endif
+}
+// S*j*(u - v)
+template <int S>
+__host__ __device__ __forceinline__ v2f sub_j(v2f u, v2f v)
+{
+#if CSDR_PK_ASM
+    v2f r;
+    if constexpr (S > 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(u), "v"(v));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(u), "v"(v));
+    return r;
+#else
+    return S > 0 ? v2f{-(u.y - v.y), u.x - v.x} : v2f{u.y - v.y, -(u.x - v.x)};
+#endif
+}
+
+constexpr float kSqrtHalf = 0.70710678118654752440f;
+
+// DIF butterfly: a' = u + v, b' = (u - v) * e^{SIGN j 2 pi K/32}, K in [0,16)
+template <int K, int SIGN>
+__host__ __device__ __forceinline__ void bfly_dif(v2f &xa, v2f &xb)
+{
+    const v2f u = xa, v = xb;
+    xa = u + v;
     if constexpr (K == 0) {
-        return a;
+        xb = u - v;
     } else if constexpr (K == 8) {
-        return SIGN > 0 ? mul_pj(a) : mul_mj(a);
+        xb = sub_j<SIGN>(u, v);
     } else if constexpr (K == 4) {
-        constexpr float h = 0.70710678118654752440f;
-        v2f r = SIGN > 0 ? mul_pj(a) : mul_mj(a);
-        return (a + r) * h;
+        const v2f d = u - v;
+        xb = add_jv<SIGN>(d, d) * kSqrtHalf;            // d (1 + S j)/sqrt2
     } else if constexpr (K == 12) {
-        constexpr float h = 0.70710678118654752440f;
-        v2f r = SIGN > 0 ? mul_pj(a) : mul_mj(a);
-        return (r - a) * h;
+        const v2f d = u - v;
+        xb = add_jv<-SIGN>(d, d) * (-kSqrtHalf);        // d (-1 + S j)/sqrt2
     } else {
         constexpr float c = kCos32[K];
         constexpr float s = (SIGN > 0 ? 1.0f : -1.0f) * kCos32[(K + 24) & 31];
-        v2f w = {c, s};
-        return cmul(a, w);
+        xb = cmul_c(u - v, v2f{c, s});
+    }
+}
+// DIT butterfly: v = b * e^{SIGN j 2 pi K/32}; a' = a + v, b' = a - v
+template <int K, int SIGN>
+__host__ __device__ __forceinline__ void bfly_dit(v2f &xa, v2f &xb)
+{
+    const v2f u = xa;
+    if constexpr (K == 0) {
+        const v2f v = xb;
+        xa = u + v; xb = u - v;
+    } else if constexpr (K == 8) {
+        const v2f v = xb;
+        xa = add_jv<SIGN>(u, v); xb = add_jv<-SIGN>(u, v);
+    } else if constexpr (K == 4) {
+        const v2f v = add_jv<SIGN>(xb, xb) * kSqrtHalf;
+        xa = u + v; xb = u - v;
+    } else if constexpr (K == 12) {
+        const v2f v = add_jv<-SIGN>(xb, xb) * (-kSqrtHalf);
+        xa = u + v; xb = u - v;
+    } else {
+        constexpr float c = kCos32[K];
+        constexpr float s = (SIGN > 0 ? 1.0f : -1.0f) * kCos32[(K + 24) & 31];
+        const v2f v = cmul_c(xb, v2f{c, s});
+        xa = u + v; xb = u - v;
     }
 }
 
@@ -90,9 +178,7 @@ __host__ __device__ __forceinline__ void dif_stage(v2f (&x)[R])
     static_for<0, R / LEN>([&](auto B) {
         static_for<0, H>([&](auto I) {
             constexpr int a = B.value * LEN + I.value, b = a + H;
-            v2f u = x[a], v = x[b];
-            x[a] = u + v;
-            x[b] = mul_w32<I.value *(32 / LEN), SIGN>(u - v);
+            bfly_dif<I.value *(32 / LEN), SIGN>(x[a], x[b]);
         });
     });
     if constexpr (LEN > 2) dif_stage<LEN / 2, R, SIGN>(x);
@@ -111,9 +197,7 @@ __host__ __device__ __forceinline__ void dit_stage(v2f (&x)[R])
     static_for<0, R / LEN>([&](auto B) {
         static_for<0, H>([&](auto I) {
             constexpr int a = B.value * LEN + I.value, b = a + H;
-            v2f u = x[a], v = mul_w32<I.value *(32 / LEN), SIGN>(x[b]);
-            x[a] = u + v;
-            x[b] = u - v;
+            bfly_dit<I.value *(32 / LEN), SIGN>(x[a], x[b]);
         });
     });
     if constexpr (LEN < R) dit_stage<LEN * 2, R, SIGN>(x);
