@@ -207,12 +207,12 @@ void fastfir_os_kernel(FastFirArgs a)
                 constexpr int r = Rr.value, k1 = bitrev<32>(r);
                 x[r] = cmul(x[r], tw2[k1 * 32 + sn]);
             });
-            CSDR_STORE_GROUP_BEGIN();
+            // 8-byte LDS stores: no tuple assembly, not subject to the wide-store hazard, so the
+            // scheduler may interleave them with the last butterfly stage
             static_for<0, 32>([&](auto Rr) {
                 constexpr int r = Rr.value, k1 = bitrev<32>(r);
                 lds[base + 34 * k1] = x[r];
             });
-            CSDR_STORE_GROUP_END();
         }
         // F2 -> F3 stays inside the half-wave that owns sub-transform sb
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -268,10 +268,8 @@ void fastfir_os_kernel(FastFirArgs a)
                 if constexpr (k1 != 0) x[r] = cmul_conj(x[r], tw2[k1 * 32 + sn]);
             });
             dft_dit<32, -1>(x);
-            CSDR_STORE_GROUP_BEGIN();
 #pragma unroll
             for (int n1 = 0; n1 < 32; n1++) lds[base + 34 * n1] = x[n1];
-            CSDR_STORE_GROUP_END();
         }
         __syncthreads();
         dbg_dump<LOG2N, DBG>(a, lds, 4);
