@@ -65,6 +65,23 @@ def _declare(L):
     f("csdr_fastfir_batch_reset", I, P)
     f("csdr_fastfir_batch_process", I, P, P, LL, I, P, LL, P, I)
     f("csdr_fastfir_batch_get_response", I, P, I, P)
+    f("csdr_downconvert_create", P, I)
+    f("csdr_downconvert_destroy", None, P)
+    f("csdr_downconvert_set_cw_offset", I, P, D)
+    f("csdr_downconvert_set_frequency", I, P, D)
+    f("csdr_downconvert_set_data_rate", D, P, D, D)
+    f("csdr_downconvert_process", I, P, I, P, P)
+    f("csdr_downconvert_get_stages", I, P, P, I)
+    f("csdr_downconvert_get_nco_freq", D, P)
+    f("csdr_downconvert_batch_create", P, I, I)
+    f("csdr_downconvert_batch_destroy", None, P)
+    f("csdr_downconvert_batch_set_cw_offset", I, P, I, D)
+    f("csdr_downconvert_batch_set_frequency", I, P, I, D)
+    f("csdr_downconvert_batch_set_data_rate", D, P, I, D, D)
+    f("csdr_downconvert_batch_get_stages", I, P, I, P, I)
+    f("csdr_downconvert_batch_get_nco_freq", D, P, I)
+    f("csdr_downconvert_batch_out_count", I, P, I, I)
+    f("csdr_downconvert_batch_process", I, P, P, LL, I, P, LL, P)
 
 
 def last_error():

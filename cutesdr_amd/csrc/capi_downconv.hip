@@ -1,0 +1,284 @@
+// capi_downconv.hip -- C ABI for CDownConvert (single-channel host form + batched device form).
+#include "capi_common.hpp"
+#include "downconv_kernels.h"
+#include "dc_host.hpp"
+#include <cstring>
+#include <vector>
+
+using namespace csdr;
+
+struct csdr_downconvert_batch {
+    int device, channels;
+    std::vector<DcHostChan> ch;            // host mirror of every channel's CDownConvert state
+    std::vector<DcPlan> plans;             // distinct (in_rate, max_bw) decimator chains in use
+    std::vector<int> plan_of;              // channel -> plan index
+    int hist_stride;                       // samples per channel in each history half
+    float *d_hist; int hist_cur;           // 2 x [channels][hist_stride] mixed samples
+    DcChan *d_chan; int *d_list; float *d_amp;
+};
+
+static int ensure_hist(csdr_downconvert_batch *b)
+{
+    int need = 2;
+    for (auto &p : b->plans) if (p.W > need) need = p.W;
+    if (need <= b->hist_stride && b->d_hist) return CSDR_OK;
+    // growing the history only happens together with a chain rebuild of the channels that need
+    // it; keep the other channels' histories by copying them over
+    float *nh = nullptr;
+    const size_t half_new = (size_t)b->channels * need * 2;
+    CSDR_HIP(hipMalloc((void **)&nh, half_new * 2 * sizeof(float)));
+    CSDR_HIP(hipMemset(nh, 0, half_new * 2 * sizeof(float)));
+    if (b->d_hist) {
+        // old history of channel c (length old stride, right aligned semantics: index 0 is the oldest
+        // of the last W samples of ITS plan, W <= old stride) stays valid at the front of the new row
+        const size_t half_old = (size_t)b->channels * b->hist_stride * 2;
+        CSDR_HIP(hipMemcpy2D(nh, (size_t)need * 8, b->d_hist + b->hist_cur * half_old,
+                             (size_t)b->hist_stride * 8, (size_t)b->hist_stride * 8, b->channels,
+                             hipMemcpyDeviceToDevice));
+        CSDR_HIP(hipFree(b->d_hist));
+    }
+    b->d_hist = nh; b->hist_stride = need; b->hist_cur = 0;
+    return CSDR_OK;
+}
+
+static int find_plan(csdr_downconvert_batch *b, double in_rate, double max_bw)
+{
+    for (size_t i = 0; i < b->plans.size(); i++)
+        if (b->plans[i].in_rate == in_rate && b->plans[i].max_bw == max_bw) return (int)i;
+    b->plans.push_back(dc_make_plan(in_rate, max_bw));
+    return (int)b->plans.size() - 1;
+}
+
+extern "C" {
+
+csdr_downconvert_batch *csdr_downconvert_batch_create(int device, int channels)
+{
+    if (channels < 1) { fail(CSDR_EINVAL, "channels >= 1"); return nullptr; }
+    if (!device_ok(device)) return nullptr;
+    csdr_downconvert_batch *b = new csdr_downconvert_batch();
+    b->device = device; b->channels = channels;
+    b->ch.assign(channels, DcHostChan());
+    b->plans.push_back(dc_make_plan(0, 0));          // plan 0: no stages (ctor state)
+    b->plan_of.assign(channels, 0);
+    b->hist_stride = 0; b->d_hist = nullptr; b->hist_cur = 0;
+    b->d_chan = nullptr; b->d_list = nullptr; b->d_amp = nullptr;
+    std::vector<float> amp(DC_AMP_N);
+    dc_amp_table(amp.data(), DC_AMP_N);
+    bool ok = hipMalloc((void **)&b->d_chan, sizeof(DcChan) * channels) == hipSuccess &&
+              hipMalloc((void **)&b->d_list, sizeof(int) * channels) == hipSuccess &&
+              hipMalloc((void **)&b->d_amp, sizeof(float) * DC_AMP_N) == hipSuccess &&
+              hipMemcpy(b->d_amp, amp.data(), sizeof(float) * DC_AMP_N, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok || ensure_hist(b) != CSDR_OK) {
+        fail(CSDR_ENOMEM, "device allocation failed");
+        csdr_downconvert_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+void csdr_downconvert_batch_destroy(csdr_downconvert_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->d_hist) (void)hipFree(b->d_hist);
+    if (b->d_chan) (void)hipFree(b->d_chan);
+    if (b->d_list) (void)hipFree(b->d_list);
+    if (b->d_amp) (void)hipFree(b->d_amp);
+    delete b;
+}
+
+#define DCB_CHECK(b, c) \
+    if (!(b) || (c) < -1 || (c) >= (b)->channels) return fail(CSDR_EINVAL, "bad handle/channel")
+#define DCB_FOR(b, c, i) for (int i = ((c) < 0 ? 0 : (c)); i < ((c) < 0 ? (b)->channels : (c) + 1); i++)
+
+int csdr_downconvert_batch_set_cw_offset(csdr_downconvert_batch *b, int channel, double offset)
+{
+    DCB_CHECK(b, channel);
+    DCB_FOR(b, channel, i) b->ch[i].cw_offset = offset;
+    return CSDR_OK;
+}
+
+int csdr_downconvert_batch_set_frequency(csdr_downconvert_batch *b, int channel, double freq)
+{
+    DCB_CHECK(b, channel);
+    DCB_FOR(b, channel, i) b->ch[i].set_frequency(freq);
+    return CSDR_OK;
+}
+
+double csdr_downconvert_batch_set_data_rate(csdr_downconvert_batch *b, int channel, double in_rate, double max_bw)
+{
+    if (!b || channel < -1 || channel >= b->channels) { fail(CSDR_EINVAL, "bad handle/channel"); return -1.0; }
+    if (!device_ok(b->device)) return -1.0;
+    double out = 0;
+    DCB_FOR(b, channel, i) {
+        DcHostChan &c = b->ch[i];
+        if (c.in_rate != in_rate || c.max_bw != max_bw) {       // downconvert.cpp:118-119
+            c.in_rate = in_rate; c.max_bw = max_bw;
+            const int pi = find_plan(b, in_rate, max_bw);
+            b->plan_of[i] = pi;
+            c.out_rate = b->plans[pi].out_rate;
+            if (ensure_hist(b) != CSDR_OK) return -1.0;
+            // a rebuilt chain starts from zeroed stage histories (ctor of every stage)
+            const size_t half = (size_t)b->channels * b->hist_stride * 2;
+            if (hipMemset(b->d_hist + b->hist_cur * half + (size_t)i * b->hist_stride * 2, 0,
+                          (size_t)b->hist_stride * 8) != hipSuccess) {
+                fail(CSDR_EHIP, "hipMemset failed");
+                return -1.0;
+            }
+            c.set_frequency(c.nco_freq);                          // :169, re-adds the CW offset
+        }
+        out = c.out_rate;
+    }
+    return out;
+}
+
+int csdr_downconvert_batch_get_stages(csdr_downconvert_batch *b, int channel, int *codes, int cap)
+{
+    if (!b || channel < 0 || channel >= b->channels) return fail(CSDR_EINVAL, "bad handle/channel");
+    const DcPlan &p = b->plans[b->plan_of[channel]];
+    for (int s = 0; s < p.nstages && s < cap; s++) codes[s] = p.kind[s];
+    return p.nstages;
+}
+
+double csdr_downconvert_batch_get_nco_freq(csdr_downconvert_batch *b, int channel)
+{
+    if (!b || channel < 0 || channel >= b->channels) return 0.0;
+    return b->ch[channel].nco_freq;
+}
+
+int csdr_downconvert_batch_out_count(csdr_downconvert_batch *b, int channel, int n_in)
+{
+    if (!b || channel < 0 || channel >= b->channels) return fail(CSDR_EINVAL, "bad handle/channel");
+    return n_in >> b->plans[b->plan_of[channel]].nstages;
+}
+
+int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
+                                   int n_per_channel, float *d_out, long long out_stride, void *stream)
+{
+    if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad handle or null buffer");
+    if (n_per_channel <= 0 || (n_per_channel & 1)) return fail(CSDR_EINVAL, "n_per_channel must be even and > 0");
+    if ((((uintptr_t)d_in | (uintptr_t)d_out) & 15) || (in_stride & 1) || in_stride < n_per_channel)
+        return fail(CSDR_EINVAL, "buffers must be 16-byte aligned, strides even and >= n");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t pi = 0; pi < b->plans.size(); pi++)
+        for (int i = 0; i < b->channels; i++)
+            if (b->plan_of[i] == (int)pi && (n_per_channel & ((1 << b->plans[pi].nstages) - 1)))
+                return fail(CSDR_EINVAL, "n_per_channel (%d) must be a multiple of 2^%d for channel %d "
+                            "(reference: InLength must be a multiple of 2^stages, downconvert.cpp:181-183)",
+                            n_per_channel, b->plans[pi].nstages, i);
+    // NCO state of every channel at the start of this call
+    std::vector<DcChan> hc(b->channels);
+    for (int i = 0; i < b->channels; i++) { hc[i].phase = b->ch[i].phase; hc[i].inc = b->ch[i].inc; hc[i].age = b->ch[i].age; }
+    CSDR_HIP(hipMemcpyAsync(b->d_chan, hc.data(), sizeof(DcChan) * b->channels, hipMemcpyHostToDevice, s));
+    const size_t half = (size_t)b->channels * b->hist_stride * 2;
+    std::vector<int> list;
+    size_t list_off = 0;
+    std::vector<int> all_lists(b->channels);
+    std::vector<DcArgs> launches;
+    for (size_t pi = 0; pi < b->plans.size(); pi++) {
+        list.clear();
+        for (int i = 0; i < b->channels; i++) if (b->plan_of[i] == (int)pi) list.push_back(i);
+        if (list.empty()) continue;
+        memcpy(all_lists.data() + list_off, list.data(), list.size() * sizeof(int));
+        const DcPlan &p = b->plans[pi];
+        DcArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = (const dc_v2f *)d_in; a.in_stride = in_stride;
+        a.out = (dc_v2f *)d_out; a.out_stride = out_stride;
+        a.hist = (const dc_v2f *)(b->d_hist + b->hist_cur * half);
+        a.hist_next = (dc_v2f *)(b->d_hist + (b->hist_cur ^ 1) * half);
+        a.hist_stride = b->hist_stride;
+        a.chan = b->d_chan; a.chan_list = b->d_list + list_off; a.amp = b->d_amp;
+        a.nchan = (int)list.size(); a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
+        for (int q = 0; q < p.nstages; q++) a.st[q] = p.st[q];
+        // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long
+        long min_seg = (long)DC_TILE_SAMPLES * 8;
+        if (min_seg < (long)p.W * 8) min_seg = (long)p.W * 8;
+        long nseg = (1024 + a.nchan - 1) / a.nchan;
+        if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
+        if (nseg < 1) nseg = 1;
+        long seg_len = (n_per_channel + nseg - 1) / nseg;
+        seg_len = (seg_len + DC_TILE_SAMPLES - 1) / DC_TILE_SAMPLES * DC_TILE_SAMPLES;
+        a.seg_len = (int)seg_len;
+        a.nseg = (int)((n_per_channel + seg_len - 1) / seg_len);
+        list_off += list.size();
+        launches.push_back(a);
+    }
+    CSDR_HIP(hipMemcpyAsync(b->d_list, all_lists.data(), sizeof(int) * b->channels, hipMemcpyHostToDevice, s));
+    // a call shorter than a channel's warm-up keeps part of the old history: every row of the
+    // next history half is fully rewritten by the kernel (tail copy + new samples)
+    for (auto &la : launches) CSDR_HIP(downconv_launch(la, s));
+    b->hist_cur ^= 1;
+    for (int i = 0; i < b->channels; i++) {
+        b->ch[i].phase += b->ch[i].inc * (unsigned long long)n_per_channel;
+        b->ch[i].age += (unsigned long long)n_per_channel;
+    }
+    return CSDR_OK;
+}
+
+}  // extern "C"
+
+/* ---------------- single-channel host form: CDownConvert drop-in ---------------- */
+struct csdr_downconvert {
+    csdr_downconvert_batch *b;
+    float *d_in, *d_out;
+    size_t cap;
+    std::vector<float> stage;
+};
+
+extern "C" {
+
+csdr_downconvert *csdr_downconvert_create(int device)
+{
+    csdr_downconvert_batch *b = csdr_downconvert_batch_create(device, 1);
+    if (!b) return nullptr;
+    csdr_downconvert *d = new csdr_downconvert();
+    d->b = b; d->d_in = d->d_out = nullptr; d->cap = 0;
+    return d;
+}
+void csdr_downconvert_destroy(csdr_downconvert *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->b->device);
+    if (d->d_in) (void)hipFree(d->d_in);
+    if (d->d_out) (void)hipFree(d->d_out);
+    csdr_downconvert_batch_destroy(d->b);
+    delete d;
+}
+int csdr_downconvert_set_cw_offset(csdr_downconvert *d, double offset)
+{ return d ? csdr_downconvert_batch_set_cw_offset(d->b, 0, offset) : fail(CSDR_EINVAL, "bad handle"); }
+int csdr_downconvert_set_frequency(csdr_downconvert *d, double freq)
+{ return d ? csdr_downconvert_batch_set_frequency(d->b, 0, freq) : fail(CSDR_EINVAL, "bad handle"); }
+double csdr_downconvert_set_data_rate(csdr_downconvert *d, double in_rate, double max_bw)
+{ if (!d) { fail(CSDR_EINVAL, "bad handle"); return -1.0; } return csdr_downconvert_batch_set_data_rate(d->b, 0, in_rate, max_bw); }
+int csdr_downconvert_get_stages(csdr_downconvert *d, int *codes, int cap)
+{ return d ? csdr_downconvert_batch_get_stages(d->b, 0, codes, cap) : fail(CSDR_EINVAL, "bad handle"); }
+double csdr_downconvert_get_nco_freq(csdr_downconvert *d)
+{ return d ? csdr_downconvert_batch_get_nco_freq(d->b, 0) : 0.0; }
+
+int csdr_downconvert_process(csdr_downconvert *d, int n, const double *in_iq, double *out_iq)
+{
+    if (!d || n < 0 || (n > 0 && (!in_iq || !out_iq))) return fail(CSDR_EINVAL, "bad argument");
+    if (n == 0) return 0;
+    if (!device_ok(d->b->device)) return CSDR_EHIP;
+    if ((size_t)n > d->cap) {
+        if (d->d_in) (void)hipFree(d->d_in);
+        if (d->d_out) (void)hipFree(d->d_out);
+        d->d_in = d->d_out = nullptr; d->cap = 0;
+        CSDR_HIP(hipMalloc((void **)&d->d_in, (size_t)n * 8));
+        CSDR_HIP(hipMalloc((void **)&d->d_out, (size_t)n * 8));
+        d->cap = n;
+    }
+    d->stage.resize(2 * (size_t)n);
+    for (size_t i = 0; i < 2 * (size_t)n; i++) d->stage[i] = (float)in_iq[i];
+    CSDR_HIP(hipMemcpy(d->d_in, d->stage.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    int rc = csdr_downconvert_batch_process(d->b, d->d_in, n, n, d->d_out, n, nullptr);
+    if (rc) return rc;
+    const int nout = csdr_downconvert_batch_out_count(d->b, 0, n);
+    CSDR_HIP(hipMemcpy(d->stage.data(), d->d_out, (size_t)nout * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < 2 * (size_t)nout; i++) out_iq[i] = (double)d->stage[i];
+    return nout;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// downconv_kernels.h -- launch interface of the NCO + decimator cascade kernel (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace csdr {
+
+constexpr int DC_MAX_STAGES = 9;     // MAX_DECSTAGES-1, reference dsp/downconvert.h:18
+constexpr int DC_MAX_PAIRS = 13;     // 51-tap half band: 13 symmetric even-tap pairs + centre
+constexpr int DC_AMP_N = 512;        // NCO amplitude envelope table length
+constexpr int DC_TILE_SAMPLES = 4096;
+
+typedef float dc_v2f __attribute__((ext_vector_type(2)));
+
+// one decimate-by-2 stage: y[j] = ccoef*xe[2j+center] + sum_q c[q]*(xe[2j+a[q]] + xe[2j+b[q]]),
+// xe = [hist samples of stage history | stage input]
+struct DcStage {
+    int hist, npairs, center;
+    float ccoef;
+    short a[DC_MAX_PAIRS], b[DC_MAX_PAIRS];
+    float c[DC_MAX_PAIRS];
+};
+
+struct DcChan {                      // per-channel NCO state at the start of the call
+    unsigned long long phase;        // angle of the stored phasor Osc1, 2^64 = one turn
+    unsigned long long inc;          // per-sample increment
+    unsigned long long age;          // samples mixed so far (selects the amplitude a_n)
+};
+
+struct DcArgs {
+    const dc_v2f *in;  long in_stride;       // raw IQ [channels][in_stride]
+    dc_v2f *out;       long out_stride;      // [channels][out_stride], n_in >> nstages valid
+    const dc_v2f *hist; dc_v2f *hist_next;   // [channels][hist_stride], first W valid: mixed samples, ping-pong
+    long hist_stride;
+    const DcChan *chan;                      // [channels]
+    const int *chan_list;                    // optional [nchan] channel ids of this launch
+    const float *amp;                        // [DC_AMP_N] amplitude envelope a_n
+    int nchan, n_in, nstages, W, seg_len, nseg;
+    int roff[DC_MAX_STAGES + 2];
+    DcStage st[DC_MAX_STAGES];
+};
+
+hipError_t downconv_launch(DcArgs &a, hipStream_t stream);
+
+}  // namespace csdr

@@ -132,3 +132,105 @@ class FastFirBatch:
             self.close()
         except Exception:
             pass
+
+
+class CDownConvert:
+    """dsp/downconvert.h:24-120 -- NCO + decimate-by-2^n chain, host double buffers."""
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_downconvert_create(device), "csdr_downconvert_create")
+
+    def SetCwOffset(self, offset):
+        check(lib().csdr_downconvert_set_cw_offset(self.h, offset))
+
+    def SetFrequency(self, NcoFreq):
+        check(lib().csdr_downconvert_set_frequency(self.h, NcoFreq))
+
+    def SetDataRate(self, InRate, MaxBW):
+        r = lib().csdr_downconvert_set_data_rate(self.h, InRate, MaxBW)
+        if r < 0:
+            raise _capi.CsdrError(_capi.last_error())
+        return r
+
+    def ProcessData(self, InData):
+        a = _c128(InData)
+        out = np.empty(len(a), dtype=np.complex128)
+        k = check(lib().csdr_downconvert_process(self.h, len(a), _vp(a), _vp(out)), "csdr_downconvert_process")
+        return out[:k]
+
+    def stages(self):
+        codes = np.zeros(16, dtype=np.int32)
+        n = check(lib().csdr_downconvert_get_stages(self.h, _vp(codes), 16))
+        return list(int(c) for c in codes[:n])
+
+    def nco_freq(self):
+        return lib().csdr_downconvert_get_nco_freq(self.h)
+
+    def close(self):
+        if self.h:
+            lib().csdr_downconvert_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DownConvertBatch:
+    """Batched, device-resident CDownConvert over [channels][T] interleaved fp32 I/Q."""
+
+    def __init__(self, channels, device=0):
+        self.channels, self.device = channels, device
+        self.h = check_ptr(lib().csdr_downconvert_batch_create(device, channels), "csdr_downconvert_batch_create")
+
+    def set_cw_offset(self, offset, channel=-1):
+        check(lib().csdr_downconvert_batch_set_cw_offset(self.h, channel, offset))
+
+    def set_frequency(self, freq, channel=-1):
+        check(lib().csdr_downconvert_batch_set_frequency(self.h, channel, freq))
+
+    def set_data_rate(self, in_rate, max_bw, channel=-1):
+        r = lib().csdr_downconvert_batch_set_data_rate(self.h, channel, in_rate, max_bw)
+        if r < 0:
+            raise _capi.CsdrError(_capi.last_error())
+        return r
+
+    def stages(self, channel=0):
+        codes = np.zeros(16, dtype=np.int32)
+        n = check(lib().csdr_downconvert_batch_get_stages(self.h, channel, _vp(codes), 16))
+        return list(int(c) for c in codes[:n])
+
+    def out_count(self, channel, n_in):
+        return check(lib().csdr_downconvert_batch_out_count(self.h, channel, n_in))
+
+    def process_ptr(self, d_in, in_stride, n_per_channel, d_out, out_stride, stream=None):
+        check(lib().csdr_downconvert_batch_process(self.h, C.c_void_p(d_in), in_stride, n_per_channel,
+                                                   C.c_void_p(d_out), out_stride,
+                                                   C.c_void_p(stream) if stream else None),
+              "csdr_downconvert_batch_process")
+
+    def process(self, x):
+        """x: complex [channels, T] -> list of complex64 arrays (one per channel)."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        T = x.shape[1]
+        din = DeviceBuffer(x.nbytes, self.device)
+        dout = DeviceBuffer(x.nbytes, self.device)
+        din.upload(x)
+        self.process_ptr(din.ptr, T, T, dout.ptr, T)
+        sync(self.device)
+        y = dout.download(np.complex64, x.size).reshape(x.shape)
+        din.free(); dout.free()
+        return [y[c, :self.out_count(c, T)].copy() for c in range(self.channels)]
+
+    def close(self):
+        if self.h:
+            lib().csdr_downconvert_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

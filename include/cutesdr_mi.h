@@ -78,6 +78,48 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
 /* copy of the designed frequency response H[k] (natural order, fp64 pairs) for tests */
 int csdr_fastfir_batch_get_response(csdr_fastfir_batch *b, int channel, double *h_out);
 
+/* ----------------------------------------------------------------------------------------
+ * CDownConvert -- NCO mixer + decimate-by-2^n cascade (dsp/downconvert.h:24-120).
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_downconvert csdr_downconvert;
+
+/* CDownConvert::CDownConvert (downconvert.cpp:60-73): 100 kHz in, no stages, phasor 1+0j */
+csdr_downconvert *csdr_downconvert_create(int device);
+void csdr_downconvert_destroy(csdr_downconvert *d);
+/* CDownConvert::SetCwOffset (downconvert.h:30) */
+int csdr_downconvert_set_cw_offset(csdr_downconvert *d, double offset);
+/* CDownConvert::SetFrequency (downconvert.cpp:98-107); stores freq + CW offset */
+int csdr_downconvert_set_frequency(csdr_downconvert *d, double freq);
+/* CDownConvert::SetDataRate (downconvert.cpp:114-173): rebuilds the stage list when
+ * (in_rate, max_bw) change, re-applies the stored frequency, returns the output rate */
+double csdr_downconvert_set_data_rate(csdr_downconvert *d, double in_rate, double max_bw);
+/* CDownConvert::ProcessData (downconvert.cpp:186-263): n interleaved double pairs in,
+ * n / 2^stages out (n must be a multiple of 2^stages and even, as in the reference);
+ * in == out allowed.  The reference also scribbles intermediate data over pInData; this
+ * implementation leaves the input untouched. */
+int csdr_downconvert_process(csdr_downconvert *d, int n, const double *in_iq, double *out_iq);
+/* introspection for tests: stage codes (3 = CIC3, else half-band length), stored NCO freq */
+int csdr_downconvert_get_stages(csdr_downconvert *d, int *codes, int cap);
+double csdr_downconvert_get_nco_freq(csdr_downconvert *d);
+
+/* batched device-resident form; channel = -1 addresses every channel */
+typedef struct csdr_downconvert_batch csdr_downconvert_batch;
+csdr_downconvert_batch *csdr_downconvert_batch_create(int device, int channels);
+void csdr_downconvert_batch_destroy(csdr_downconvert_batch *b);
+int csdr_downconvert_batch_set_cw_offset(csdr_downconvert_batch *b, int channel, double offset);
+int csdr_downconvert_batch_set_frequency(csdr_downconvert_batch *b, int channel, double freq);
+double csdr_downconvert_batch_set_data_rate(csdr_downconvert_batch *b, int channel, double in_rate,
+                                            double max_bw);
+int csdr_downconvert_batch_get_stages(csdr_downconvert_batch *b, int channel, int *codes, int cap);
+double csdr_downconvert_batch_get_nco_freq(csdr_downconvert_batch *b, int channel);
+/* samples channel `channel` produces for n_in input samples (n_in >> stages) */
+int csdr_downconvert_batch_out_count(csdr_downconvert_batch *b, int channel, int n_in);
+/* d_in [channels][in_stride] -> d_out [channels][out_stride], interleaved fp32 I/Q on the
+ * device; n_per_channel even and a multiple of every channel's 2^stages.  Asynchronous. */
+int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
+                                   int n_per_channel, float *d_out, long long out_stride,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

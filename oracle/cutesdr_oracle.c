@@ -433,6 +433,7 @@ static int dec_hb(dc_stage *s, int n, orc_cpx *x)
     int L = s->kind, c = (L - 1) / 2, i, j, nout = 0;
     orc_cpx *w = s->scratch;
     if (n < L) return n / 2;                 /* :291-292, nothing written */
+    if (n + L - 1 > DC_HB_SCRATCH) return -1;  /* reference would overrun its scratch buffer */
     memcpy(w + (L - 1), x, sizeof(orc_cpx) * n);
     for (i = 0; i < n; i += 2) {
         double ar = w[i].re * s->h[0], ai = w[i].im * s->h[0];

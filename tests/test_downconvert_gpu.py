@@ -1,0 +1,102 @@
+"""GPU parity of the NCO + decimator cascade kernel (K2) against the fp64 oracle, through the
+C ABI.  Tolerance: |err| <= 1e-5 * full scale (32767) per output sample (K2),
+sample counts exact."""
+import numpy as np
+import pytest
+from util_signals import tones_plus_noise, FULL_SCALE
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5 * FULL_SCALE
+
+
+def run_oracle(oracle, in_rate, bw, freq, chunks, cw=0.0):
+    dc = oracle.CDownConvert()
+    dc.SetCwOffset(cw)
+    dc.SetDataRate(in_rate, bw)
+    dc.SetFrequency(freq)
+    return dc, [dc.ProcessData(c) for c in chunks]
+
+
+@pytest.mark.parametrize("in_rate,bw,chain,out_rate", [
+    (2e6, 15000, [11, 11, 15, 19, 31], 62500),
+    (2e6, 10000, [11, 11, 11, 15, 23, 51], 31250),
+    (2e6, 20000, [11, 11, 15, 23, 51], 62500),
+    (2e6, 1000, [3, 3, 11, 11, 11, 11, 15], 15625),
+    (10e6, 15000, [3, 11, 11, 11, 11, 15, 27], 78125),
+])
+def test_host_cdownconvert_matches_oracle(oracle, in_rate, bw, chain, out_rate):
+    import cutesdr_amd as ca
+    dc = ca.CDownConvert()
+    assert dc.SetDataRate(in_rate, bw) == out_rate
+    assert dc.stages() == chain
+    dc.SetFrequency(-100e3)
+    n_call = 19968 if in_rate == 2e6 else 99840          # m_InBufLimit windows (demodulator.cpp:145-146)
+    x = tones_plus_noise(3, 5 * n_call, in_rate, [100e3 + 1000.0, 100e3 - 4000.0, 380e3])
+    chunks = [x[i * n_call:(i + 1) * n_call] for i in range(5)]
+    _, refs = run_oracle(oracle, in_rate, bw, -100e3, chunks)
+    for c, ref in zip(chunks, refs):
+        got = dc.ProcessData(c)
+        assert len(got) == len(ref) == n_call >> len(chain)
+        assert np.abs(got - ref).max() <= TOL
+
+
+def test_nco_startup_envelope_and_cw_double_add(oracle):
+    import cutesdr_amd as ca
+    dc = ca.CDownConvert()
+    dc.SetCwOffset(700)
+    dc.SetFrequency(1000)
+    assert dc.nco_freq() == 1700
+    assert dc.SetDataRate(2e6, 1e9) == 2e6          # no stage fits: pure mixer
+    assert dc.stages() == []
+    assert dc.nco_freq() == 2400                    # SetDataRate re-adds the CW offset (App. A.2)
+    ref = oracle.CDownConvert()
+    ref.SetCwOffset(700); ref.SetFrequency(1000); ref.SetDataRate(2e6, 1e9)
+    x = np.full(4096, 20000.0 + 0j)
+    for _ in range(3):                              # phase and amplitude continue across calls
+        got, want = dc.ProcessData(x), ref.ProcessData(x)
+        assert len(got) == 4096
+        assert np.abs(got - want).max() <= 20000.0 * 4e-6
+    # retune keeps the phasor (phase continuous), only the increment changes
+    dc.SetFrequency(-250e3); ref.SetFrequency(-250e3)
+    got, want = dc.ProcessData(x), ref.ProcessData(x)
+    assert np.abs(got - want).max() <= 20000.0 * 4e-6
+
+
+def test_small_calls_are_chunking_independent(oracle):
+    """Calls shorter than the cascade's warm-up length (and shorter than the reference can take:
+    below 2*(taps-1) samples at a stage its in-place history copy reads overwritten data,
+    downconvert.cpp:314-317, and below `taps` it skips the stage, :291-292 -- the host never goes
+    there, it feeds 19968 samples per call).  Here the stream semantics simply continue: the
+    output must not depend on how the input is chunked, and must match the oracle fed in
+    host-sized chunks."""
+    import cutesdr_amd as ca
+    x = tones_plus_noise(5, 19968 * 2, 2e6, [-50e3 + 2000.0, 300e3])
+    ref = oracle.CDownConvert(); ref.SetDataRate(2e6, 15000); ref.SetFrequency(50e3)
+    want = np.concatenate([ref.ProcessData(x[:19968]), ref.ProcessData(x[19968:])])
+    for chunk in (256, 512, 4992):
+        dc = ca.CDownConvert(); dc.SetDataRate(2e6, 15000); dc.SetFrequency(50e3)
+        got = np.concatenate([dc.ProcessData(x[i:i + chunk]) for i in range(0, len(x), chunk)])
+        assert len(got) == len(want)
+        assert np.abs(got - want).max() <= TOL, chunk
+
+
+def test_batch_mixed_chains_segments_and_state(oracle):
+    import cutesdr_amd as ca
+    C, T = 6, 1 << 19                                # long enough to be cut into segments
+    setups = [(15000, -100e3), (10000, 40e3), (20000, -333e3), (1000, 7e3), (15000, 0.0), (10000, -1e3)]
+    b = ca.DownConvertBatch(C)
+    refs = []
+    for c, (bw, f) in enumerate(setups):
+        assert b.set_data_rate(2e6, bw, channel=c) > 0
+        b.set_frequency(f, channel=c)
+        r = oracle.CDownConvert(); r.SetDataRate(2e6, bw); r.SetFrequency(f)
+        refs.append(r)
+    x = np.stack([tones_plus_noise(20 + c, 2 * T, 2e6, [-setups[c][1] + 700.0, 450e3]) for c in range(C)])
+    for part in (x[:, :T], x[:, T:]):
+        got = b.process(part)
+        for c in range(C):
+            # the oracle, like the reference, has a 32768-sample half-band scratch buffer
+            # (MAX_HALF_BAND_BUFSIZE, downconvert.cpp:54): feed it in 65536-sample pieces
+            want = np.concatenate([refs[c].ProcessData(part[c][i:i + 65536]) for i in range(0, T, 65536)])
+            assert len(got[c]) == len(want)
+            assert np.abs(got[c] - want).max() <= TOL, c
