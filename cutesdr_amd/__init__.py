@@ -6,6 +6,5 @@ package is the host-side mirror of the reference's class surface used by tests a
 it is plumbing over the C ABI and contains no signal processing of its own.
 """
 from . import _capi  # noqa: F401
-from .host import (CFastFIR, FastFirBatch, CDownConvert, DownConvertBatch, DeviceBuffer)  # noqa: F401
+from .host import *  # noqa: F401,F403
 
-__all__ = ["CFastFIR", "FastFirBatch", "CDownConvert", "DownConvertBatch", "DeviceBuffer"]

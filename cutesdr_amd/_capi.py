@@ -22,9 +22,7 @@ _lib = None
 
 def declared_symbols():
     """Every function name the public header declares."""
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(csdr_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(prototypes())
 
 
 def lib():
@@ -42,46 +40,37 @@ def lib():
 P, D, I, LL, U64 = C.c_void_p, C.c_double, C.c_int, C.c_longlong, C.c_ulonglong
 
 
+def _ctype(t):
+    t = t.replace("const", "").strip()
+    if "*" in t:
+        return C.c_char_p if t.replace(" ", "") == "char*" else P
+    return {"int": I, "double": D, "void": None, "long long": LL, "unsigned long long": U64}[t]
+
+
+def prototypes():
+    """Parse include/cutesdr_mi.h: {name: (restype, [argtypes])}."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"typedef struct csdr_demod_info \{.*?\} csdr_demod_info;", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(csdr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        argt = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                argt.append(_ctype(a if a.endswith("*") else re.sub(r"\s*[A-Za-z_][A-Za-z0-9_]*$", "", a)))
+        out[name] = (_ctype(ret), argt)
+    return out
+
+
 def _declare(L):
-    def f(name, res, *args):
+    for name, (res, args) in prototypes().items():
         fn = getattr(L, name)
         fn.restype = res
-        fn.argtypes = list(args)
-    f("csdr_version", I)
-    f("csdr_last_error", C.c_char_p)
-    f("csdr_device_count", I)
-    f("csdr_dev_alloc", P, I, U64)
-    f("csdr_dev_free", I, I, P)
-    f("csdr_dev_upload", I, I, P, P, U64)
-    f("csdr_dev_download", I, I, P, P, U64)
-    f("csdr_dev_sync", I, I)
-    f("csdr_fastfir_create", P, I, I)
-    f("csdr_fastfir_destroy", None, P)
-    f("csdr_fastfir_setup", I, P, D, D, D, D)
-    f("csdr_fastfir_process", I, P, I, P, P)
-    f("csdr_fastfir_batch_create", P, I, I, I)
-    f("csdr_fastfir_batch_destroy", None, P)
-    f("csdr_fastfir_batch_setup", I, P, I, D, D, D, D)
-    f("csdr_fastfir_batch_reset", I, P)
-    f("csdr_fastfir_batch_process", I, P, P, LL, I, P, LL, P, I)
-    f("csdr_fastfir_batch_get_response", I, P, I, P)
-    f("csdr_downconvert_create", P, I)
-    f("csdr_downconvert_destroy", None, P)
-    f("csdr_downconvert_set_cw_offset", I, P, D)
-    f("csdr_downconvert_set_frequency", I, P, D)
-    f("csdr_downconvert_set_data_rate", D, P, D, D)
-    f("csdr_downconvert_process", I, P, I, P, P)
-    f("csdr_downconvert_get_stages", I, P, P, I)
-    f("csdr_downconvert_get_nco_freq", D, P)
-    f("csdr_downconvert_batch_create", P, I, I)
-    f("csdr_downconvert_batch_destroy", None, P)
-    f("csdr_downconvert_batch_set_cw_offset", I, P, I, D)
-    f("csdr_downconvert_batch_set_frequency", I, P, I, D)
-    f("csdr_downconvert_batch_set_data_rate", D, P, I, D, D)
-    f("csdr_downconvert_batch_get_stages", I, P, I, P, I)
-    f("csdr_downconvert_batch_get_nco_freq", D, P, I)
-    f("csdr_downconvert_batch_out_count", I, P, I, I)
-    f("csdr_downconvert_batch_process", I, P, P, LL, I, P, LL, P)
+        fn.argtypes = args
 
 
 def last_error():

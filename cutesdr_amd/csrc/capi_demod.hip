@@ -1,0 +1,412 @@
+// capi_demod.hip -- C ABI of the full receive chain, CDemodulator (dsp/demodulator.h:56-100):
+// CDownConvert -> CFastFIR -> CSMeter -> CAgc -> AM/SAM/FM/SSB demodulator, device resident
+// between the stages.  Two forms: the single-channel host object that mirrors
+// CDemodulator::ProcessData call for call, and the batched multi-channel form.
+#include "capi_common.hpp"
+#include "pc_unit.hpp"
+#include <cstring>
+#include <map>
+#include <vector>
+
+using namespace csdr;
+
+extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
+                                                    const int *d_in_rows, int n_per_channel, float *d_out,
+                                                    long long out_stride, void *stream);
+
+namespace {
+
+// move the not-yet-filtered tail of every row to the front of the staging buffer
+__global__ void shift_rows_kernel(float *buf, long stride, int src_off, int count)
+{
+    float2 *row = reinterpret_cast<float2 *>(buf) + (long)blockIdx.x * stride;
+    // src_off >= count whenever at least one hop was consumed, so the ranges do not overlap
+    for (int i = threadIdx.x; i < count; i += blockDim.x) row[i] = row[src_off + i];
+}
+
+// `rows` channels that share one decimator plan: staging, pending counts, the three stage objects
+struct ChainCore {
+    int device = 0, rows = 0, fft_n = 2048, L = 1024;
+    csdr_downconvert_batch *dc = nullptr;
+    csdr_fastfir_batch *ff = nullptr;
+    PcUnit pc;
+    float *d_stage = nullptr, *d_filt = nullptr;
+    long cap = 0;                       // staging capacity per row (complex samples)
+    int pending = 0;                    // decimated samples waiting for a full hop (same in every row)
+    int last_out = 0;
+
+    ~ChainCore()
+    {
+        if (dc) csdr_downconvert_batch_destroy(dc);
+        if (ff) csdr_fastfir_batch_destroy(ff);
+        if (d_stage) (void)hipFree(d_stage);
+        if (d_filt) (void)hipFree(d_filt);
+    }
+    int init(int dev, int nrows, int n)
+    {
+        device = dev; rows = nrows; fft_n = n; L = n / 2;
+        dc = csdr_downconvert_batch_create(dev, nrows);
+        ff = csdr_fastfir_batch_create(dev, nrows, n);
+        if (!dc || !ff) return CSDR_EHIP;
+        return pc.init(dev, nrows);
+    }
+    int ensure(long need)
+    {
+        if (need <= cap) return CSDR_OK;
+        need = (need + L + 1023) / 1024 * 1024;
+        float *ns = nullptr, *nf = nullptr;
+        CSDR_HIP(hipMalloc((void **)&ns, (size_t)rows * need * 8));
+        CSDR_HIP(hipMalloc((void **)&nf, (size_t)rows * need * 8));
+        if (d_stage && pending > 0)
+            CSDR_HIP(hipMemcpy2D(ns, (size_t)need * 8, d_stage, (size_t)cap * 8, (size_t)pending * 8, rows,
+                                 hipMemcpyDeviceToDevice));
+        if (d_stage) (void)hipFree(d_stage);
+        if (d_filt) (void)hipFree(d_filt);
+        d_stage = ns; d_filt = nf; cap = need;
+        return CSDR_OK;
+    }
+    // one pass of the chain over n input samples per row (demodulator.cpp:172-207); returns the
+    // audio samples produced per row (0 or a multiple of the FastFIR hop)
+    int step(const float *d_in, long in_stride, const int *d_in_rows, int n, float *d_out, long out_stride,
+             const int *d_out_rows, bool stereo, hipStream_t s)
+    {
+        const int m = csdr_downconvert_batch_out_count(dc, 0, n);
+        if (m < 0) return m;
+        int rc = ensure((long)pending + m);
+        if (rc) return rc;
+        rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, d_stage + 2 * (size_t)pending,
+                                                  cap, s);
+        if (rc) return rc;
+        const int total = pending + m, nb = total / L;
+        last_out = 0;
+        if (nb > 0) {
+            rc = csdr_fastfir_batch_process(ff, d_stage, cap, nb * L, d_filt, cap, s, 0);
+            if (rc) return rc;
+            rc = pc.run(PC_DO_SMETER | PC_DO_AGC | PC_DO_DEMOD | (stereo ? PC_STEREO : 0), d_filt, cap, d_out,
+                        out_stride, nb, L, s, d_out_rows);
+            if (rc) return rc;
+            const int rest = total - nb * L;
+            if (rest > 0) {
+                hipLaunchKernelGGL(shift_rows_kernel, dim3(rows), dim3(256), 0, s, d_stage, cap, nb * L, rest);
+                CSDR_HIP(hipGetLastError());
+            }
+            pending = rest;
+            last_out = nb * L;
+        } else {
+            pending = total;
+        }
+        return last_out;
+    }
+};
+
+struct DemodInfo {                      // csdr_demod_info
+    int HiCut, HiCutmin, HiCutmax, LowCut, LowCutmin, LowCutmax, FilterClickResolution, Offset, SquelchValue;
+    int AgcSlope, AgcThresh, AgcManualGain, AgcDecay, AgcOn, AgcHangOn, Symetric;
+};
+
+// per-channel CDemodulator bookkeeping (host side)
+struct ChanCfg {
+    int mode = -1;
+    int pending = -1;                   // batch form: mode requested before commit
+    DemodInfo info{};
+    double out_rate = 48000.0, want_bw = 48000.0, cw_off = 0.0;
+};
+
+// CDemodulator::SetDemod (dsp/demodulator.cpp:107-157) for row r of core k
+int apply_set_demod(ChainCore &k, int r, ChanCfg &c, double in_rate, int mode, const DemodInfo &info)
+{
+    c.info = info;
+    int rc;
+    if (c.mode != mode) {
+        c.mode = mode;
+        if (mode == PC_MODE_LSB || mode == PC_MODE_CWL) c.want_bw = -info.LowCutmin;
+        else c.want_bw = info.HiCutmax;
+        c.out_rate = csdr_downconvert_batch_set_data_rate(k.dc, r, in_rate, c.want_bw);
+        if (c.out_rate < 0) return CSDR_EHIP;
+        if ((rc = k.pc.pull(r))) return rc;
+        PcChannel &h = k.pc.h[r];
+        h.mode = mode;
+        switch (mode) {                 // new demodulator object = fresh state
+        case PC_MODE_AM:  am_init(h.am, k.pc.fir_am[r], c.out_rate); break;
+        case PC_MODE_SAM: sam_init(h.sam, k.pc.fir_sam[r], c.out_rate); break;
+        case PC_MODE_FM:  fm_init(h.fm, k.pc.fir_fm[r], c.out_rate); break;
+        default: break;
+        }
+        if ((rc = k.pc.push(r))) return rc;
+    }
+    c.cw_off = info.Offset;
+    csdr_downconvert_batch_set_cw_offset(k.dc, r, c.cw_off);
+    rc = csdr_fastfir_batch_setup(k.ff, k.rows == 1 ? -1 : r, info.LowCut, info.HiCut, c.cw_off, c.out_rate);
+    if (rc < 0 && rc != CSDR_EINVAL) return rc;      // EINVAL = reference's "parameter error": keep old taps
+    rc = k.pc.agc_set(r, info.AgcOn, info.AgcHangOn, info.AgcThresh, info.AgcManualGain, info.AgcSlope,
+                      info.AgcDecay, c.out_rate);
+    if (rc) return rc;
+    if ((rc = k.pc.smeter_rate_set(r, c.out_rate))) return rc;
+    if (mode == PC_MODE_FM || mode == PC_MODE_AM) {
+        if ((rc = k.pc.pull(r))) return rc;
+        PcChannel &h = k.pc.h[r];
+        if (mode == PC_MODE_FM) {
+            fm_set_squelch(h.fm, info.SquelchValue);
+            fm_set_bw(h.fm, k.pc.fir_fm[r], c.out_rate, (double)info.HiCut);     // fmdemod.cpp:160-164
+        } else {
+            am_bandwidth(h.am, k.pc.fir_am[r], c.out_rate, (info.HiCut - info.LowCut) / 2.0);
+        }
+        if ((rc = k.pc.push(r))) return rc;
+    }
+    return CSDR_OK;
+}
+
+}  // namespace
+
+/* =================== single-channel host form: CDemodulator drop-in =================== */
+struct csdr_demod {
+    ChainCore k;
+    ChanCfg c;
+    double in_rate = 0.0;
+    int limit = 1000;                   // m_InBufLimit (demodulator.cpp:54)
+    std::vector<float> inbuf;           // m_pDemodInBuf as fp32 pairs
+    int pos = 0;
+    float *d_in = nullptr, *d_out = nullptr;
+    size_t cap_in = 0, cap_out = 0;
+    std::vector<float> st;
+    ~csdr_demod()
+    {
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+    }
+};
+
+/* =================== batched device-resident form =================== */
+struct csdr_demod_batch {
+    int device, channels, fft_n;
+    double in_rate = 0.0;
+    std::vector<ChanCfg> cfg;
+    std::vector<int> core_of, row_of;                 // channel -> (core, row)
+    std::vector<ChainCore *> cores;                   // one per distinct decimator plan
+    std::vector<std::vector<int>> members;            // core -> channel ids (row order)
+    std::vector<int *> d_rows;                        // core -> device array of channel ids
+    std::map<long long, int> core_by_bw;
+    ~csdr_demod_batch()
+    {
+        for (auto *k : cores) delete k;
+        for (auto *p : d_rows) if (p) (void)hipFree(p);
+    }
+};
+
+extern "C" {
+
+csdr_demod *csdr_demod_create(int device, int fastfir_n)
+{
+    if (!device_ok(device)) return nullptr;
+    csdr_demod *d = new csdr_demod();
+    if (d->k.init(device, 1, fastfir_n) != CSDR_OK) { delete d; return nullptr; }
+    d->inbuf.resize(2 * 250000);                      // MAX_INBUFSIZE (demodulator.h:30)
+    csdr_downconvert_batch_set_cw_offset(d->k.dc, 0, 0.0);      // ctor: SetDemodFreq(0.0)
+    csdr_downconvert_batch_set_frequency(d->k.dc, 0, 0.0);
+    return d;
+}
+void csdr_demod_destroy(csdr_demod *d) { delete d; }
+
+/* CDemodulator::SetInputSampleRate (demodulator.cpp:92-99) */
+int csdr_demod_set_input_rate(csdr_demod *d, double rate)
+{
+    if (!d) return fail(CSDR_EINVAL, "bad handle");
+    if (d->in_rate != rate) {
+        d->in_rate = rate;
+        const double r = csdr_downconvert_batch_set_data_rate(d->k.dc, 0, rate, d->c.want_bw);
+        if (r < 0) return CSDR_EHIP;
+        d->c.out_rate = r;
+    }
+    return CSDR_OK;
+}
+/* CDemodulator::SetDemod (demodulator.cpp:107-157) */
+int csdr_demod_set_demod(csdr_demod *d, int mode, const csdr_demod_info *info)
+{
+    if (!d || !info || mode < 0 || mode > 6) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(d->k.device)) return CSDR_EHIP;
+    DemodInfo di;
+    memcpy(&di, info, sizeof(di));
+    int rc = apply_set_demod(d->k, 0, d->c, d->in_rate, mode, di);
+    if (rc) return rc;
+    d->limit = (int)((d->c.out_rate / 100.0) * d->in_rate / d->c.out_rate);
+    d->limit &= 0xFFFFFF00;
+    return CSDR_OK;
+}
+/* CDemodulator::SetDemodFreq (demodulator.h:68-69) */
+int csdr_demod_set_freq(csdr_demod *d, double freq)
+{
+    if (!d) return fail(CSDR_EINVAL, "bad handle");
+    csdr_downconvert_batch_set_cw_offset(d->k.dc, 0, d->c.cw_off);
+    return csdr_downconvert_batch_set_frequency(d->k.dc, 0, freq);
+}
+double csdr_demod_get_output_rate(csdr_demod *d) { return d ? d->c.out_rate : 0.0; }
+double csdr_demod_get_smeter_peak(csdr_demod *d) { return d ? d->k.pc.smeter_peak(0) : 0.0; }
+double csdr_demod_get_smeter_ave(csdr_demod *d) { return d ? d->k.pc.smeter_ave(0) : 0.0; }
+int csdr_demod_get_buf_limit(csdr_demod *d) { return d ? d->limit : fail(CSDR_EINVAL, "bad handle"); }
+
+/* CDemodulator::ProcessData (demodulator.cpp:163-215 mono, :221-273 stereo).  Every inner pass
+ * writes its output at out[0] and the return value is the SUM over the passes, exactly as the
+ * reference does; append != 0 selects the batch-harness form that appends. */
+static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out, bool stereo, bool append)
+{
+    if (!d || n < 0 || (n && (!in_iq || !out))) return fail(CSDR_EINVAL, "bad argument");
+    if (d->limit <= 0 || d->limit > 250000) return fail(CSDR_ESTATE, "input buffer limit %d out of range", d->limit);
+    if (!device_ok(d->k.device)) return CSDR_EHIP;
+    int ret = 0;
+    for (int i = 0; i < n; i++) {
+        d->inbuf[2 * d->pos] = (float)in_iq[2 * i];
+        d->inbuf[2 * d->pos + 1] = (float)in_iq[2 * i + 1];
+        if (++d->pos >= d->limit) {
+            const int len = d->pos;
+            d->pos = 0;
+            if ((size_t)len > d->cap_in) {
+                if (d->d_in) (void)hipFree(d->d_in);
+                d->d_in = nullptr; d->cap_in = 0;
+                CSDR_HIP(hipMalloc((void **)&d->d_in, (size_t)len * 8));
+                d->cap_in = len;
+            }
+            const size_t need_out = (size_t)len + d->k.L;
+            if (need_out > d->cap_out) {
+                if (d->d_out) (void)hipFree(d->d_out);
+                d->d_out = nullptr; d->cap_out = 0;
+                CSDR_HIP(hipMalloc((void **)&d->d_out, need_out * 8));
+                d->cap_out = need_out;
+            }
+            CSDR_HIP(hipMemcpy(d->d_in, d->inbuf.data(), (size_t)len * 8, hipMemcpyHostToDevice));
+            const int k = d->k.step(d->d_in, len, nullptr, len, d->d_out, (long)d->cap_out, nullptr, stereo, nullptr);
+            if (k < 0) return k;
+            if (k > 0) {
+                const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
+                d->st.resize(nf);
+                CSDR_HIP(hipMemcpy(d->st.data(), d->d_out, nf * 4, hipMemcpyDeviceToHost));
+                double *dst = append ? out + (stereo ? 2 : 1) * (size_t)ret : out;
+                for (size_t j = 0; j < nf; j++) dst[j] = (double)d->st[j];
+            }
+            ret += k;
+        }
+    }
+    return ret;
+}
+int csdr_demod_process_mono(csdr_demod *d, int n, const double *in_iq, double *out)
+{ return demod_process(d, n, in_iq, out, false, false); }
+int csdr_demod_process_stereo(csdr_demod *d, int n, const double *in_iq, double *out_iq)
+{ return demod_process(d, n, in_iq, out_iq, true, false); }
+int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, double *out)
+{ return demod_process(d, n, in_iq, out, false, true); }
+
+/* ------------------------------- batch ------------------------------- */
+csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_n)
+{
+    if (channels < 1) { fail(CSDR_EINVAL, "channels >= 1"); return nullptr; }
+    if (!device_ok(device)) return nullptr;
+    csdr_demod_batch *b = new csdr_demod_batch();
+    b->device = device; b->channels = channels; b->fft_n = fastfir_n;
+    b->cfg.assign(channels, ChanCfg());
+    b->core_of.assign(channels, -1); b->row_of.assign(channels, -1);
+    return b;
+}
+void csdr_demod_batch_destroy(csdr_demod_batch *b) { delete b; }
+int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (!b->cores.empty() && rate != b->in_rate)
+        return fail(CSDR_ESTATE, "set the input rate before configuring channels");
+    b->in_rate = rate;
+    return CSDR_OK;
+}
+/* Configure every channel, then call csdr_demod_batch_commit() once: channels that decimate by
+ * the same chain are grouped and run together. */
+int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const csdr_demod_info *info)
+{
+    if (!b || !info || channel < 0 || channel >= b->channels || mode < 0 || mode > 6)
+        return fail(CSDR_EINVAL, "bad argument");
+    ChanCfg &c = b->cfg[channel];
+    if (b->core_of[channel] >= 0) {
+        // already committed: only parameter changes that keep the decimator chain are accepted
+        DemodInfo di; memcpy(&di, info, sizeof(di));
+        const double bw = (mode == PC_MODE_LSB || mode == PC_MODE_CWL) ? -di.LowCutmin : di.HiCutmax;
+        if (bw != c.want_bw) return fail(CSDR_ESTATE, "channel %d: a mode change that alters the decimator "
+                                         "chain needs a new batch object", channel);
+        return apply_set_demod(*b->cores[b->core_of[channel]], b->row_of[channel], c, b->in_rate, mode, di);
+    }
+    memcpy(&c.info, info, sizeof(DemodInfo));
+    c.pending = mode;                    // applied at commit
+    c.want_bw = (mode == PC_MODE_LSB || mode == PC_MODE_CWL) ? -c.info.LowCutmin : c.info.HiCutmax;
+    return CSDR_OK;
+}
+int csdr_demod_batch_commit(csdr_demod_batch *b)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    if (!b->cores.empty()) return fail(CSDR_ESTATE, "already committed");
+    std::map<long long, std::vector<int>> groups;
+    for (int c = 0; c < b->channels; c++) {
+        if (b->cfg[c].pending < 0)
+            return fail(CSDR_ESTATE, "channel %d has no demodulator configured", c);
+        groups[(long long)llround(b->cfg[c].want_bw * 1000.0)].push_back(c);
+    }
+    for (auto &g : groups) {
+        ChainCore *k = new ChainCore();
+        if (k->init(b->device, (int)g.second.size(), b->fft_n) != CSDR_OK) { delete k; return CSDR_EHIP; }
+        const int ki = (int)b->cores.size();
+        b->cores.push_back(k);
+        b->members.push_back(g.second);
+        int *dr = nullptr;
+        CSDR_HIP(hipMalloc((void **)&dr, sizeof(int) * g.second.size()));
+        CSDR_HIP(hipMemcpy(dr, g.second.data(), sizeof(int) * g.second.size(), hipMemcpyHostToDevice));
+        b->d_rows.push_back(dr);
+        for (size_t r = 0; r < g.second.size(); r++) {
+            const int c = g.second[r];
+            b->core_of[c] = ki; b->row_of[c] = (int)r;
+            const int mode = b->cfg[c].pending;
+            DemodInfo di = b->cfg[c].info;
+            csdr_downconvert_batch_set_frequency(k->dc, (int)r, 0.0);
+            int rc = apply_set_demod(*k, (int)r, b->cfg[c], b->in_rate, mode, di);
+            if (rc) return rc;
+        }
+    }
+    return CSDR_OK;
+}
+int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq)
+{
+    if (!b || channel < 0 || channel >= b->channels) return fail(CSDR_EINVAL, "bad argument");
+    if (b->core_of[channel] < 0) return fail(CSDR_ESTATE, "commit first");
+    ChainCore &k = *b->cores[b->core_of[channel]];
+    csdr_downconvert_batch_set_cw_offset(k.dc, b->row_of[channel], b->cfg[channel].cw_off);
+    return csdr_downconvert_batch_set_frequency(k.dc, b->row_of[channel], freq);
+}
+double csdr_demod_batch_get_output_rate(csdr_demod_batch *b, int channel)
+{
+    if (!b || channel < 0 || channel >= b->channels) return 0.0;
+    return b->cfg[channel].out_rate;
+}
+double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel)
+{
+    if (!b || channel < 0 || channel >= b->channels || b->core_of[channel] < 0) return 0.0;
+    return b->cores[b->core_of[channel]]->pc.smeter_ave(b->row_of[channel]);
+}
+/* d_in: [channels][in_stride] complex fp32; d_out: [channels][out_stride] fp32 mono audio.
+ * Chunking: one call = one pass of the chain over n_per_channel samples (the host form uses
+ * m_InBufLimit-sized passes; the decimator and filter are chunking independent, the squelch
+ * decision is taken once per FastFIR hop either way).  Asynchronous. */
+int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                             float *d_out, long long out_stride, void *stream)
+{
+    if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad argument");
+    if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    for (size_t ki = 0; ki < b->cores.size(); ki++) {
+        int rc = b->cores[ki]->step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride,
+                                    b->d_rows[ki], false, (hipStream_t)stream);
+        if (rc < 0) return rc;
+    }
+    return CSDR_OK;
+}
+/* audio samples channel `channel` received in the last process call */
+int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel)
+{
+    if (!b || channel < 0 || channel >= b->channels || b->core_of[channel] < 0) return fail(CSDR_EINVAL, "bad argument");
+    return b->cores[b->core_of[channel]]->last_out;
+}
+
+}  // extern "C"

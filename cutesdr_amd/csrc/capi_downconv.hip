@@ -49,6 +49,10 @@ static int find_plan(csdr_downconvert_batch *b, double in_rate, double max_bw)
     return (int)b->plans.size() - 1;
 }
 
+extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
+                                                    const int *d_in_rows, int n_per_channel, float *d_out,
+                                                    long long out_stride, void *stream);
+
 extern "C" {
 
 csdr_downconvert_batch *csdr_downconvert_batch_create(int device, int channels)
@@ -155,10 +159,18 @@ int csdr_downconvert_batch_out_count(csdr_downconvert_batch *b, int channel, int
 int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                    int n_per_channel, float *d_out, long long out_stride, void *stream)
 {
+    return csdr__downconvert_batch_process_rows(b, d_in, in_stride, nullptr, n_per_channel, d_out, out_stride, stream);
+}
+
+/* internal (not in the public header): input row of channel c is in_rows[c] (device array) */
+int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
+                                         const int *d_in_rows, int n_per_channel, float *d_out,
+                                         long long out_stride, void *stream)
+{
     if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad handle or null buffer");
     if (n_per_channel <= 0 || (n_per_channel & 1)) return fail(CSDR_EINVAL, "n_per_channel must be even and > 0");
-    if ((((uintptr_t)d_in | (uintptr_t)d_out) & 15) || (in_stride & 1) || in_stride < n_per_channel)
-        return fail(CSDR_EINVAL, "buffers must be 16-byte aligned, strides even and >= n");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 7) || (in_stride & 1) || in_stride < n_per_channel)
+        return fail(CSDR_EINVAL, "input must be 16-byte aligned (output 8), input stride even and >= n");
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t s = (hipStream_t)stream;
     for (size_t pi = 0; pi < b->plans.size(); pi++)
@@ -189,7 +201,7 @@ int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in,
         a.hist = (const dc_v2f *)(b->d_hist + b->hist_cur * half);
         a.hist_next = (dc_v2f *)(b->d_hist + (b->hist_cur ^ 1) * half);
         a.hist_stride = b->hist_stride;
-        a.chan = b->d_chan; a.chan_list = b->d_list + list_off; a.amp = b->d_amp;
+        a.chan = b->d_chan; a.chan_list = b->d_list + list_off; a.amp = b->d_amp; a.in_rows = d_in_rows;
         a.nchan = (int)list.size(); a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
         for (int q = 0; q < p.nstages; q++) a.st[q] = p.st[q];
         // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long

@@ -33,6 +33,7 @@ struct DcArgs {
     long hist_stride;
     const DcChan *chan;                      // [channels]
     const int *chan_list;                    // optional [nchan] channel ids of this launch
+    const int *in_rows;                      // optional [channels]: input row of each channel id
     const float *amp;                        // [DC_AMP_N] amplitude envelope a_n
     int nchan, n_in, nstages, W, seg_len, nseg;
     int roff[DC_MAX_STAGES + 2];

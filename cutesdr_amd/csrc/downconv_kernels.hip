@@ -55,7 +55,7 @@ void downconv_kernel(DcArgs a)
     for (int s = 0; s < ns; s++)
         for (int i = t; i < a.st[s].hist; i += DC_T) lds[roff[s] + i] = v2f{0.f, 0.f};
 
-    const v2f *in = a.in + (long)ch * a.in_stride;
+    const v2f *in = a.in + (long)(a.in_rows ? a.in_rows[ch] : ch) * a.in_stride;
     v2f *out = a.out + (long)ch * a.out_stride;
     const v2f *hist = a.hist + (long)ch * a.hist_stride;
     v2f *hist_next = a.hist_next + (long)ch * a.hist_stride;

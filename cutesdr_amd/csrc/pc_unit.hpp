@@ -1,0 +1,122 @@
+// pc_unit.hpp -- device-side state block of `channels` post-filter chains (S-meter, AGC,
+// demodulator) with its host mirror; shared by the leaf objects and the CDemodulator chain.
+#pragma once
+#include <vector>
+#include <cstring>
+#include "capi_common.hpp"
+#include "postchain.h"
+#include "pc_host.hpp"
+
+namespace csdr {
+
+struct PcUnit {
+    int device = 0, channels = 0;
+    PcChannel *d_chan = nullptr;
+    float *d_dly = nullptr, *d_mag = nullptr, *d_scratch = nullptr;
+    long scratch_cap = 0;
+    bool no_output = false;
+    std::vector<PcChannel> h;            // host mirror (authoritative for parameters)
+    std::vector<HostAgc> hagc;
+    std::vector<HostFir> fir_am, fir_sam, fir_fm;
+
+    ~PcUnit()
+    {
+        if (d_chan) (void)hipFree(d_chan);
+        if (d_dly) (void)hipFree(d_dly);
+        if (d_mag) (void)hipFree(d_mag);
+        if (d_scratch) (void)hipFree(d_scratch);
+    }
+    int init(int dev, int nch)
+    {
+        device = dev; channels = nch;
+        h.resize(nch); hagc.resize(nch); fir_am.resize(nch); fir_sam.resize(nch); fir_fm.resize(nch);
+        for (int c = 0; c < nch; c++) {
+            memset(&h[c], 0, sizeof(PcChannel));
+            h[c].mode = PC_MODE_NONE;
+            smeter_init(h[c].sm);
+            h[c].agc.on = 1; h[c].agc.dly_n = 1; h[c].agc.win_n = 1;      // agc.cpp:80-89
+            h[c].agc.peak = -16.0; h[c].agc.attack_ave = -5.0; h[c].agc.decay_ave = -5.0;
+        }
+        CSDR_HIP(hipMalloc((void **)&d_chan, sizeof(PcChannel) * nch));
+        CSDR_HIP(hipMalloc((void **)&d_dly, sizeof(float) * 2 * PC_AGC_RING * nch));
+        CSDR_HIP(hipMalloc((void **)&d_mag, sizeof(float) * PC_AGC_RING * nch));
+        CSDR_HIP(hipMemset(d_dly, 0, sizeof(float) * 2 * PC_AGC_RING * nch));
+        std::vector<float> m16((size_t)PC_AGC_RING * nch, -16.0f);
+        CSDR_HIP(hipMemcpy(d_mag, m16.data(), m16.size() * 4, hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(d_chan, h.data(), sizeof(PcChannel) * nch, hipMemcpyHostToDevice));
+        return CSDR_OK;
+    }
+    int pull(int c)      // device -> host mirror (state advances on the device)
+    {
+        CSDR_HIP(hipSetDevice(device));
+        CSDR_HIP(hipDeviceSynchronize());
+        CSDR_HIP(hipMemcpy(&h[c], d_chan + c, sizeof(PcChannel), hipMemcpyDeviceToHost));
+        return CSDR_OK;
+    }
+    int push(int c)
+    {
+        CSDR_HIP(hipSetDevice(device));
+        CSDR_HIP(hipMemcpy(d_chan + c, &h[c], sizeof(PcChannel), hipMemcpyHostToDevice));
+        return CSDR_OK;
+    }
+    int agc_rings_clear(int c)
+    {
+        CSDR_HIP(hipMemset(d_dly + (size_t)c * 2 * PC_AGC_RING, 0, sizeof(float) * 2 * PC_AGC_RING));
+        std::vector<float> m16(PC_AGC_RING, -16.0f);
+        CSDR_HIP(hipMemcpy(d_mag + (size_t)c * PC_AGC_RING, m16.data(), m16.size() * 4, hipMemcpyHostToDevice));
+        return CSDR_OK;
+    }
+    // CAgc::SetParameters
+    int agc_set(int c, int on, int hang, int thresh, int manual, int slope, int decay, double fs)
+    {
+        int rc = pull(c);
+        if (rc) return rc;
+        const int ch = hagc[c].set(h[c].agc, on != 0, hang != 0, thresh, manual, slope, decay, fs);
+        if (ch == 0) return CSDR_OK;
+        if (ch == 2 && (rc = agc_rings_clear(c))) return rc;
+        return push(c);
+    }
+    int smeter_rate_set(int c, double fs)
+    {
+        if (h[c].sm.fs == fs) return CSDR_OK;
+        int rc = pull(c);
+        if (rc) return rc;
+        smeter_rate(h[c].sm, fs);
+        return push(c);
+    }
+    // CSMeter::GetPeak resets the peak (smeter.cpp:98-103)
+    double smeter_peak(int c)
+    {
+        if (pull(c)) return 0.0;
+        const double x = h[c].sm.peak_mag;
+        h[c].sm.peak_mag = 0;
+        (void)push(c);
+        return x + 5.0;
+    }
+    double smeter_ave(int c)
+    {
+        if (pull(c)) return 0.0;
+        return h[c].sm.ave_mag + 5.0;
+    }
+    int run(int flags, const float *d_in, long in_stride, float *d_out, long out_stride, int nbursts,
+            int burst, hipStream_t stream, const int *d_out_rows = nullptr)
+    {
+        CSDR_HIP(hipSetDevice(device));
+        if (burst > scratch_cap) {
+            if (d_scratch) (void)hipFree(d_scratch);
+            d_scratch = nullptr; scratch_cap = 0;
+            CSDR_HIP(hipMalloc((void **)&d_scratch, sizeof(float) * (size_t)burst * channels));
+            scratch_cap = burst;
+        }
+        PcArgs a;
+        a.chan = d_chan; a.agc_dly = d_dly; a.agc_mag = d_mag;
+        a.in = d_in; a.in_stride = in_stride;
+        a.out = no_output ? nullptr : d_out; a.out_stride = out_stride; a.out_rows = d_out_rows;
+        a.scratch = d_scratch; a.scratch_stride = scratch_cap;
+        a.channels = channels; a.nbursts = nbursts; a.burst = burst; a.flags = flags;
+        CSDR_HIP(postchain_launch(a, stream));
+        return CSDR_OK;
+    }
+};
+
+}  // namespace csdr

@@ -234,3 +234,290 @@ class DownConvertBatch:
             self.close()
         except Exception:
             pass
+
+
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+class _Obj:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            getattr(lib(), self._destroy)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CAgc(_Obj):
+    """dsp/agc.h:19-62"""
+    _destroy = "csdr_agc_destroy"
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_agc_create(device), "csdr_agc_create")
+
+    def SetParameters(self, AgcOn, UseHang, Threshold, ManualGain, Slope, Decay, SampleRate):
+        check(lib().csdr_agc_set_parameters(self.h, int(AgcOn), int(UseHang), Threshold, ManualGain, Slope, Decay, SampleRate))
+
+    def ProcessData(self, x):
+        if np.iscomplexobj(x):
+            a = _c128(x); out = np.empty_like(a)
+            check(lib().csdr_agc_process_cpx(self.h, len(a), _vp(a), _vp(out)), "agc_process_cpx")
+        else:
+            a = _f64(x); out = np.empty_like(a)
+            check(lib().csdr_agc_process_real(self.h, len(a), _vp(a), _vp(out)), "agc_process_real")
+        return out
+
+
+class CSMeter(_Obj):
+    """dsp/smeter.h:13-28"""
+    _destroy = "csdr_smeter_destroy"
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_smeter_create(device), "csdr_smeter_create")
+
+    def ProcessData(self, x, SampleRate):
+        a = _c128(x)
+        check(lib().csdr_smeter_process(self.h, len(a), _vp(a), SampleRate), "smeter_process")
+
+    def GetPeak(self):
+        return lib().csdr_smeter_get_peak(self.h)
+
+    def GetAve(self):
+        return lib().csdr_smeter_get_ave(self.h)
+
+
+class CFir(_Obj):
+    """dsp/fir.h:20-43"""
+    _destroy = "csdr_fir_destroy"
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_fir_create(device), "csdr_fir_create")
+
+    def InitConstFir(self, coef):
+        c = _f64(coef)
+        check(lib().csdr_fir_init_const(self.h, len(c), _vp(c)))
+
+    def InitLPFilter(self, Scale, Astop, Fpass, Fstop, Fsamprate):
+        return check(lib().csdr_fir_init_lp(self.h, Scale, Astop, Fpass, Fstop, Fsamprate))
+
+    def InitHPFilter(self, Scale, Astop, Fpass, Fstop, Fsamprate):
+        return check(lib().csdr_fir_init_hp(self.h, Scale, Astop, Fpass, Fstop, Fsamprate))
+
+    def GenerateHBFilter(self, FreqOffset):
+        check(lib().csdr_fir_generate_hb(self.h, FreqOffset))
+
+    def taps(self):
+        c = np.zeros(75); i = np.zeros(75); q = np.zeros(75)
+        n = check(lib().csdr_fir_get_taps(self.h, _vp(c), _vp(i), _vp(q)))
+        return c[:n], i[:n], q[:n]
+
+    def ProcessFilter(self, x):
+        if np.iscomplexobj(x):
+            a = _c128(x); out = np.empty_like(a)
+            check(lib().csdr_fir_process_cpx(self.h, len(a), _vp(a), _vp(out)))
+        else:
+            a = _f64(x); out = np.empty_like(a)
+            check(lib().csdr_fir_process_real(self.h, len(a), _vp(a), _vp(out)))
+        return out
+
+
+class CIir(_Obj):
+    """dsp/iir.h:17-39"""
+    _destroy = "csdr_iir_destroy"
+    KIND = {"LP": 0, "HP": 1, "BP": 2, "BR": 3}
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_iir_create(device), "csdr_iir_create")
+
+    def Init(self, kind, F0Freq, FilterQ, SampleRate):
+        check(lib().csdr_iir_init(self.h, self.KIND[kind], F0Freq, FilterQ, SampleRate))
+
+    def coefs(self):
+        c = np.zeros(5); check(lib().csdr_iir_get_coefs(self.h, _vp(c))); return c
+
+    def ProcessFilter(self, x):
+        if np.iscomplexobj(x):
+            a = _c128(x); out = np.empty_like(a)
+            check(lib().csdr_iir_process_cpx(self.h, len(a), _vp(a), _vp(out)))
+        else:
+            a = _f64(x); out = np.empty_like(a)
+            check(lib().csdr_iir_process_real(self.h, len(a), _vp(a), _vp(out)))
+        return out
+
+
+class _Demod(_Obj):
+    _prefix = None
+
+    def _run(self, x, stereo, *extra):
+        a = _c128(x)
+        if stereo:
+            out = np.empty_like(a)
+            k = check(getattr(lib(), self._prefix + "_process_stereo")(self.h, len(a), *extra, _vp(a), _vp(out)))
+        else:
+            out = np.empty(len(a))
+            k = check(getattr(lib(), self._prefix + "_process_mono")(self.h, len(a), *extra, _vp(a), _vp(out)))
+        return out[:k]
+
+
+class CAmDemod(_Demod):
+    """dsp/amdemod.h:14-25"""
+    _destroy, _prefix = "csdr_amdemod_destroy", "csdr_amdemod"
+
+    def __init__(self, samplerate, device=0):
+        self.h = check_ptr(lib().csdr_amdemod_create(device, samplerate), "csdr_amdemod_create")
+
+    def SetBandwidth(self, Bandwidth):
+        check(lib().csdr_amdemod_set_bandwidth(self.h, Bandwidth))
+
+    def ProcessData(self, x, stereo=False):
+        return self._run(x, stereo)
+
+
+class CSamDemod(_Demod):
+    """dsp/samdemod.h:14-32"""
+    _destroy, _prefix = "csdr_samdemod_destroy", "csdr_samdemod"
+
+    def __init__(self, samplerate, device=0):
+        self.h = check_ptr(lib().csdr_samdemod_create(device, samplerate), "csdr_samdemod_create")
+
+    def ProcessData(self, x, stereo=False):
+        return self._run(x, stereo)
+
+
+class CFmDemod(_Demod):
+    """dsp/fmdemod.h:17-54"""
+    _destroy, _prefix = "csdr_fmdemod_destroy", "csdr_fmdemod"
+
+    def __init__(self, samplerate, device=0):
+        self.h = check_ptr(lib().csdr_fmdemod_create(device, samplerate), "csdr_fmdemod_create")
+
+    def SetSquelch(self, Value):
+        check(lib().csdr_fmdemod_set_squelch(self.h, Value))
+
+    def squelched(self):
+        return bool(check(lib().csdr_fmdemod_get_squelched(self.h)))
+
+    def ProcessData(self, x, FmBW, stereo=False):
+        return self._run(x, stereo, float(FmBW))
+
+
+def ssb_demod(x, stereo=False):
+    """dsp/ssbdemod.cpp:48-60"""
+    a = _c128(x)
+    if stereo:
+        out = np.empty_like(a); check(lib().csdr_ssbdemod_process_stereo(len(a), _vp(a), _vp(out)))
+    else:
+        out = np.empty(len(a)); check(lib().csdr_ssbdemod_process_mono(len(a), _vp(a), _vp(out)))
+    return out
+
+
+class DemodInfo(C.Structure):
+    """tDemodInfo (dsp/demodulator.h:35-54) without the QString label"""
+    _fields_ = [(n, C.c_int) for n in (
+        "HiCut", "HiCutmin", "HiCutmax", "LowCut", "LowCutmin", "LowCutmax",
+        "FilterClickResolution", "Offset", "SquelchValue",
+        "AgcSlope", "AgcThresh", "AgcManualGain", "AgcDecay",
+        "AgcOn", "AgcHangOn", "Symetric")]
+
+
+DEMOD_AM, DEMOD_SAM, DEMOD_FM, DEMOD_USB, DEMOD_LSB, DEMOD_CWU, DEMOD_CWL = range(7)
+
+
+class CDemodulator(_Obj):
+    """dsp/demodulator.h:56-100 -- the whole chain, host double buffers, reference call semantics."""
+    _destroy = "csdr_demod_destroy"
+
+    def __init__(self, fastfir_n=2048, device=0):
+        self.n = fastfir_n
+        self.h = check_ptr(lib().csdr_demod_create(device, fastfir_n), "csdr_demod_create")
+
+    def SetInputSampleRate(self, InputRate):
+        check(lib().csdr_demod_set_input_rate(self.h, InputRate))
+
+    def SetDemod(self, Mode, CurrentDemodInfo):
+        check(lib().csdr_demod_set_demod(self.h, Mode, C.byref(CurrentDemodInfo)), "csdr_demod_set_demod")
+
+    def SetDemodFreq(self, Freq):
+        check(lib().csdr_demod_set_freq(self.h, Freq))
+
+    def GetOutputRate(self):
+        return lib().csdr_demod_get_output_rate(self.h)
+
+    def GetSMeterPeak(self):
+        return lib().csdr_demod_get_smeter_peak(self.h)
+
+    def GetSMeterAve(self):
+        return lib().csdr_demod_get_smeter_ave(self.h)
+
+    def buf_limit(self):
+        return check(lib().csdr_demod_get_buf_limit(self.h))
+
+    def ProcessData(self, x, stereo=False):
+        a = _c128(x)
+        cap = len(a) + self.n + 65536
+        if stereo:
+            out = np.zeros(cap, dtype=np.complex128)
+            k = check(lib().csdr_demod_process_stereo(self.h, len(a), _vp(a), _vp(out)), "csdr_demod_process_stereo")
+        else:
+            out = np.zeros(cap)
+            k = check(lib().csdr_demod_process_mono(self.h, len(a), _vp(a), _vp(out)), "csdr_demod_process_mono")
+        return k, out
+
+    def process_append(self, x):
+        a = _c128(x)
+        out = np.zeros(len(a) + self.n + 65536)
+        k = check(lib().csdr_demod_process_mono_append(self.h, len(a), _vp(a), _vp(out)), "process_append")
+        return out[:k]
+
+
+class DemodBatch(_Obj):
+    """Batched device-resident receive chains: [channels][T] fp32 I/Q in, mono fp32 audio out."""
+    _destroy = "csdr_demod_batch_destroy"
+
+    def __init__(self, channels, fastfir_n=2048, device=0):
+        self.channels, self.n, self.device = channels, fastfir_n, device
+        self.h = check_ptr(lib().csdr_demod_batch_create(device, channels, fastfir_n), "csdr_demod_batch_create")
+
+    def set_input_rate(self, rate):
+        check(lib().csdr_demod_batch_set_input_rate(self.h, rate))
+
+    def set_demod(self, channel, mode, info):
+        check(lib().csdr_demod_batch_set_demod(self.h, channel, mode, C.byref(info)), "batch_set_demod")
+
+    def commit(self):
+        check(lib().csdr_demod_batch_commit(self.h), "batch_commit")
+
+    def set_freq(self, channel, freq):
+        check(lib().csdr_demod_batch_set_freq(self.h, channel, freq))
+
+    def output_rate(self, channel):
+        return lib().csdr_demod_batch_get_output_rate(self.h, channel)
+
+    def smeter_ave(self, channel):
+        return lib().csdr_demod_batch_get_smeter_ave(self.h, channel)
+
+    def out_count(self, channel):
+        return check(lib().csdr_demod_batch_out_count(self.h, channel))
+
+    def process_ptr(self, d_in, in_stride, n, d_out, out_stride, stream=None):
+        check(lib().csdr_demod_batch_process(self.h, C.c_void_p(d_in), in_stride, n, C.c_void_p(d_out), out_stride,
+                                             C.c_void_p(stream) if stream else None), "csdr_demod_batch_process")
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        T = x.shape[1]
+        din = DeviceBuffer(x.nbytes, self.device)
+        dout = DeviceBuffer(4 * self.channels * (T + self.n), self.device)
+        din.upload(x)
+        self.process_ptr(din.ptr, T, T, dout.ptr, T + self.n)
+        sync(self.device)
+        y = dout.download(np.float32, self.channels * (T + self.n)).reshape(self.channels, T + self.n)
+        din.free(); dout.free()
+        return [y[c, :self.out_count(c)].copy() for c in range(self.channels)]

@@ -120,6 +120,133 @@ int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in,
                                    int n_per_channel, float *d_out, long long out_stride,
                                    void *stream);
 
+/* ----------------------------------------------------------------------------------------
+ * CAgc (dsp/agc.h:19-62), CSMeter (dsp/smeter.h:13-28), CFir (dsp/fir.h:20-43),
+ * CIir (dsp/iir.h:17-39) -- the leaf objects the reference also exposes on their own.
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_agc csdr_agc;
+csdr_agc *csdr_agc_create(int device);
+void csdr_agc_destroy(csdr_agc *a);
+/* CAgc::SetParameters (agc.cpp:104-167) */
+int csdr_agc_set_parameters(csdr_agc *a, int on, int use_hang, int threshold, int manual_gain,
+                            int slope, int decay, double sample_rate);
+/* CAgc::ProcessData complex (agc.cpp:174-296) / real (agc.cpp:301-401); in == out allowed */
+int csdr_agc_process_cpx(csdr_agc *a, int n, const double *in_iq, double *out_iq);
+int csdr_agc_process_real(csdr_agc *a, int n, const double *in, double *out);
+
+typedef struct csdr_smeter csdr_smeter;
+csdr_smeter *csdr_smeter_create(int device);
+void csdr_smeter_destroy(csdr_smeter *s);
+/* CSMeter::ProcessData (smeter.cpp:62-93), GetPeak (:98-103, resets the peak), GetAve (:108-112) */
+int csdr_smeter_process(csdr_smeter *s, int n, const double *in_iq, double sample_rate);
+double csdr_smeter_get_peak(csdr_smeter *s);
+double csdr_smeter_get_ave(csdr_smeter *s);
+
+typedef struct csdr_fir csdr_fir;
+csdr_fir *csdr_fir_create(int device);
+void csdr_fir_destroy(csdr_fir *f);
+/* CFir::InitConstFir (fir.cpp:133-153), InitLPFilter (:173-261), InitHPFilter (:278-367) return
+ * the tap count; GenerateHBFilter (:374-407) keeps the delay line */
+int csdr_fir_init_const(csdr_fir *f, int ntaps, const double *coef);
+int csdr_fir_init_lp(csdr_fir *f, double scale, double astop, double fpass, double fstop, double fs);
+int csdr_fir_init_hp(csdr_fir *f, double scale, double astop, double fpass, double fstop, double fs);
+int csdr_fir_generate_hb(csdr_fir *f, double freq_offset);
+int csdr_fir_get_taps(csdr_fir *f, double *coef, double *icoef, double *qcoef);   /* up to 75 each */
+/* CFir::ProcessFilter real (fir.cpp:72-92) / complex (:101-127) */
+int csdr_fir_process_real(csdr_fir *f, int n, const double *in, double *out);
+int csdr_fir_process_cpx(csdr_fir *f, int n, const double *in_iq, double *out_iq);
+
+typedef struct csdr_iir csdr_iir;
+csdr_iir *csdr_iir_create(int device);
+void csdr_iir_destroy(csdr_iir *f);
+/* CIir::InitLP/HP/BP/BR (iir.cpp:86-165): kind 0 LP, 1 HP, 2 BP, 3 BR */
+int csdr_iir_init(csdr_iir *f, int kind, double f0, double q, double sample_rate);
+int csdr_iir_get_coefs(csdr_iir *f, double *b0b1b2a1a2);
+/* CIir::ProcessFilter (iir.cpp:171-201) */
+int csdr_iir_process_real(csdr_iir *f, int n, const double *in, double *out);
+int csdr_iir_process_cpx(csdr_iir *f, int n, const double *in_iq, double *out_iq);
+
+/* ----------------------------------------------------------------------------------------
+ * Demodulators: CAmDemod (dsp/amdemod.h), CSamDemod (dsp/samdemod.h), CFmDemod
+ * (dsp/fmdemod.h), CSsbDemod (dsp/ssbdemod.h).  mono: n complex in -> n real out;
+ * stereo: n complex in -> n complex out.
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_amdemod csdr_amdemod;
+csdr_amdemod *csdr_amdemod_create(int device, double sample_rate);            /* amdemod.cpp:50-54 */
+void csdr_amdemod_destroy(csdr_amdemod *d);
+int csdr_amdemod_set_bandwidth(csdr_amdemod *d, double bandwidth);            /* :56-60 */
+int csdr_amdemod_process_mono(csdr_amdemod *d, int n, const double *in_iq, double *out);     /* :66-82 */
+int csdr_amdemod_process_stereo(csdr_amdemod *d, int n, const double *in_iq, double *out_iq); /* :87-104 */
+
+typedef struct csdr_samdemod csdr_samdemod;
+csdr_samdemod *csdr_samdemod_create(int device, double sample_rate);          /* samdemod.cpp:54-73 */
+void csdr_samdemod_destroy(csdr_samdemod *d);
+int csdr_samdemod_process_mono(csdr_samdemod *d, int n, const double *in_iq, double *out);     /* :78-110 */
+int csdr_samdemod_process_stereo(csdr_samdemod *d, int n, const double *in_iq, double *out_iq); /* :115-158 */
+
+typedef struct csdr_fmdemod csdr_fmdemod;
+csdr_fmdemod *csdr_fmdemod_create(int device, double sample_rate);            /* fmdemod.cpp:62-89 */
+void csdr_fmdemod_destroy(csdr_fmdemod *d);
+int csdr_fmdemod_set_squelch(csdr_fmdemod *d, int value);                     /* :95-98 */
+int csdr_fmdemod_process_mono(csdr_fmdemod *d, int n, double fm_bw, const double *in_iq, double *out);     /* :157-192 */
+int csdr_fmdemod_process_stereo(csdr_fmdemod *d, int n, double fm_bw, const double *in_iq, double *out_iq); /* :197-236 */
+int csdr_fmdemod_get_squelched(csdr_fmdemod *d);                              /* m_SquelchState, for tests */
+
+int csdr_ssbdemod_process_mono(int n, const double *in_iq, double *out);      /* ssbdemod.cpp:48-53 */
+int csdr_ssbdemod_process_stereo(int n, const double *in_iq, double *out_iq); /* :55-60 */
+
+/* ----------------------------------------------------------------------------------------
+ * CDemodulator -- the whole receive chain (dsp/demodulator.h:56-100).
+ * -------------------------------------------------------------------------------------- */
+/* POD mirror of tDemodInfo (dsp/demodulator.h:35-54) without the QString label */
+typedef struct csdr_demod_info {
+    int HiCut, HiCutmin, HiCutmax, LowCut, LowCutmin, LowCutmax;
+    int FilterClickResolution, Offset, SquelchValue;
+    int AgcSlope, AgcThresh, AgcManualGain, AgcDecay;
+    int AgcOn, AgcHangOn, Symetric;
+} csdr_demod_info;
+
+#define CSDR_DEMOD_AM 0      /* DEMOD_* (dsp/demodulator.h:20-26) */
+#define CSDR_DEMOD_SAM 1
+#define CSDR_DEMOD_FM 2
+#define CSDR_DEMOD_USB 3
+#define CSDR_DEMOD_LSB 4
+#define CSDR_DEMOD_CWU 5
+#define CSDR_DEMOD_CWL 6
+
+typedef struct csdr_demod csdr_demod;
+/* CDemodulator::CDemodulator (demodulator.cpp:47-60); fastfir_n 2048 is the reference's filter */
+csdr_demod *csdr_demod_create(int device, int fastfir_n);
+void csdr_demod_destroy(csdr_demod *d);
+int csdr_demod_set_input_rate(csdr_demod *d, double rate);                    /* :92-99 */
+int csdr_demod_set_demod(csdr_demod *d, int mode, const csdr_demod_info *info); /* :107-157 */
+int csdr_demod_set_freq(csdr_demod *d, double freq);                          /* demodulator.h:68-69 */
+double csdr_demod_get_output_rate(csdr_demod *d);
+double csdr_demod_get_smeter_peak(csdr_demod *d);
+double csdr_demod_get_smeter_ave(csdr_demod *d);
+int csdr_demod_get_buf_limit(csdr_demod *d);                                  /* m_InBufLimit */
+/* CDemodulator::ProcessData mono (:163-215) / stereo (:221-273): buffers n samples, runs the
+ * chain every m_InBufLimit samples, every pass writes at out[0], returns the summed count */
+int csdr_demod_process_mono(csdr_demod *d, int n, const double *in_iq, double *out);
+int csdr_demod_process_stereo(csdr_demod *d, int n, const double *in_iq, double *out_iq);
+/* same chain, passes append instead of overwriting (batch harness form) */
+int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, double *out);
+
+/* batched device-resident chain: configure every channel, commit once, then process */
+typedef struct csdr_demod_batch csdr_demod_batch;
+csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_n);
+void csdr_demod_batch_destroy(csdr_demod_batch *b);
+int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate);
+int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const csdr_demod_info *info);
+int csdr_demod_batch_commit(csdr_demod_batch *b);
+int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq);
+double csdr_demod_batch_get_output_rate(csdr_demod_batch *b, int channel);
+double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel);
+/* d_in [channels][in_stride] complex fp32 -> d_out [channels][out_stride] fp32 mono audio */
+int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
+                             int n_per_channel, float *d_out, long long out_stride, void *stream);
+int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
+
 #ifdef __cplusplus
 }
 #endif
