@@ -44,7 +44,7 @@ def _ctype(t):
     t = t.replace("const", "").strip()
     if "*" in t:
         return C.c_char_p if t.replace(" ", "") == "char*" else P
-    return {"int": I, "double": D, "void": None, "long long": LL, "unsigned long long": U64}[t]
+    return {"int": I, "double": D, "void": None, "long long": LL, "unsigned long long": U64, "float": C.c_float, "short": C.c_short}[t]
 
 
 def prototypes():

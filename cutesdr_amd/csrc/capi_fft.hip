@@ -1,0 +1,317 @@
+// capi_fft.hip -- C ABI for CFft (dsp/fft.h:24-85): display spectrum + plain transforms.
+#include "capi_common.hpp"
+#include "spectrum_kernels.h"
+#include "host_math.hpp"
+#include <cstring>
+#include <vector>
+
+using namespace csdr;
+
+static int log2_of(int n)
+{
+    int l = 0;
+    while ((1 << l) < n) l++;
+    return ((1 << l) == n) ? l : -1;
+}
+
+struct csdr_fft_batch {
+    int device, channels;
+    int size, last_size, ave_size, invert;       // m_FFTSize, m_LastFFTSize, m_AveSize, m_Invert
+    double kc, kb, db_comp, fs;
+    // screen mapping state (GetScreenIntegerFFTData)
+    int start_hz, stop_hz, bin_min, bin_max, plot_w;
+    std::vector<int> xlat;
+    float *d_win, *d_tw1, *d_tw2, *d_sum, *d_pwr, *d_ave;
+    int *d_cnt, *d_over;
+    std::vector<float> h_ave;
+    std::vector<int> h_over;
+};
+
+static void fft_free_dev(csdr_fft_batch *f)
+{
+    float **ps[] = {&f->d_win, &f->d_tw1, &f->d_tw2, &f->d_sum, &f->d_pwr, &f->d_ave};
+    for (auto p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+}
+
+static int fft_reset(csdr_fft_batch *f)
+{   // CFft::ResetFFT (fft.cpp:248-259): clears the averaged and summed buffers and both counters
+    const size_t nb = (size_t)f->channels * f->size * 4;
+    CSDR_HIP(hipMemset(f->d_ave, 0, nb));
+    CSDR_HIP(hipMemset(f->d_sum, 0, nb));
+    CSDR_HIP(hipMemset(f->d_cnt, 0, sizeof(int) * 2 * f->channels));
+    return CSDR_OK;
+}
+
+static int fft_set_params(csdr_fft_batch *f, int size, int invert, double db_comp, double fs)
+{   // CFft::SetFFTParams (fft.cpp:118-243)
+    if (size == 0) return CSDR_OK;
+    f->bin_min = f->bin_max = 0; f->start_hz = f->stop_hz = 0; f->plot_w = 0;
+    f->invert = invert; f->fs = fs;
+    if (f->db_comp != db_comp) { f->last_size = 0; f->db_comp = db_comp; }
+    int n = size < 512 ? 512 : (size > 65536 ? 65536 : size);
+    const int l2 = log2_of(n);
+    if (l2 < 11 || l2 > 14)
+        return fail(CSDR_EINVAL, "FFT size %d: this build transforms 2048..16384 points on the device "
+                    "(the reference accepts 512..65536)", n);
+    f->size = n;
+    if (f->last_size != n) {
+        f->last_size = n;
+        fft_free_dev(f);
+        const size_t nb = (size_t)f->channels * n * 4;
+        CSDR_HIP(hipMalloc((void **)&f->d_win, (size_t)n * 4));
+        CSDR_HIP(hipMalloc((void **)&f->d_tw1, 8192));
+        CSDR_HIP(hipMalloc((void **)&f->d_tw2, 8192));
+        CSDR_HIP(hipMalloc((void **)&f->d_sum, nb));
+        CSDR_HIP(hipMalloc((void **)&f->d_pwr, nb));
+        CSDR_HIP(hipMalloc((void **)&f->d_ave, nb));
+        CSDR_HIP(hipMemset(f->d_pwr, 0, nb));
+        f->kb = f->db_comp - 20 * std::log10((double)n * 32767.0 / 2.0);
+        f->kc = std::pow(10.0, (-220.0 - f->kb) / 10.0);
+        f->kb = f->kb / 10.0;
+        std::vector<float> win(n), tw1(2048), tw2(2048);
+        for (int i = 0; i < n; i++) win[i] = (float)(2.0 * (.5 - .5 * std::cos((kTwoPi * i) / (n - 1))));
+        for (int i = 0; i < 1024; i++) {
+            const double a = kTwoPi * (double)i / (double)n;
+            tw1[2 * i] = (float)std::cos(a); tw1[2 * i + 1] = (float)std::sin(a);
+        }
+        for (int k = 0; k < 32; k++)
+            for (int i = 0; i < 32; i++) {
+                const double a = kTwoPi * (double)(i * k) / 1024.0;
+                tw2[2 * (k * 32 + i)] = (float)std::cos(a); tw2[2 * (k * 32 + i) + 1] = (float)std::sin(a);
+            }
+        CSDR_HIP(hipMemcpy(f->d_win, win.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(f->d_tw1, tw1.data(), 8192, hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(f->d_tw2, tw2.data(), 8192, hipMemcpyHostToDevice));
+        f->xlat.assign(n, 0);
+    }
+    return fft_reset(f);
+}
+
+extern "C" {
+
+csdr_fft_batch *csdr_fft_batch_create(int device, int channels)
+{
+    if (channels < 1) { fail(CSDR_EINVAL, "channels >= 1"); return nullptr; }
+    if (!device_ok(device)) return nullptr;
+    csdr_fft_batch *f = new csdr_fft_batch();
+    f->device = device; f->channels = channels;
+    f->size = 1024; f->last_size = 0; f->ave_size = 1; f->invert = 0; f->db_comp = 0.0; f->fs = 1000;
+    f->d_win = f->d_tw1 = f->d_tw2 = f->d_sum = f->d_pwr = f->d_ave = nullptr;
+    f->d_cnt = nullptr; f->d_over = nullptr;
+    if (hipMalloc((void **)&f->d_cnt, sizeof(int) * 2 * channels) != hipSuccess ||
+        hipMalloc((void **)&f->d_over, sizeof(int) * channels) != hipSuccess ||
+        fft_set_params(f, 2048, 0, 0.0, 1000) != CSDR_OK) {          // ctor, fft.cpp:41-62
+        csdr_fft_batch_destroy(f);
+        return nullptr;
+    }
+    return f;
+}
+void csdr_fft_batch_destroy(csdr_fft_batch *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    fft_free_dev(f);
+    if (f->d_cnt) (void)hipFree(f->d_cnt);
+    if (f->d_over) (void)hipFree(f->d_over);
+    delete f;
+}
+int csdr_fft_batch_set_params(csdr_fft_batch *f, int size, int invert, double db_comp, double fs)
+{
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    return fft_set_params(f, size, invert, db_comp, fs);
+}
+int csdr_fft_batch_set_ave(csdr_fft_batch *f, int ave)
+{   // CFft::SetFFTAve (fft.cpp:103-113)
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    if (f->ave_size != ave) f->ave_size = ave > 0 ? ave : 1;
+    return fft_reset(f);
+}
+int csdr_fft_batch_reset(csdr_fft_batch *f)
+{
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    return fft_reset(f);
+}
+int csdr_fft_batch_size(csdr_fft_batch *f) { return f ? f->size : fail(CSDR_EINVAL, "bad handle"); }
+
+/* nframes frames of `size` samples per channel, back to back in each row; asynchronous */
+int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long in_stride, int nframes, void *stream)
+{
+    if (!f || !d_in || nframes < 0) return fail(CSDR_EINVAL, "bad argument");
+    if (nframes == 0) return CSDR_OK;
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    CSDR_HIP(hipMemsetAsync(f->d_over, 0, sizeof(int) * f->channels, (hipStream_t)stream));   // m_Overload = FALSE
+    SpectrumArgs a;
+    a.in = d_in; a.in_stride = in_stride; a.win = f->d_win; a.tw1 = f->d_tw1; a.tw2 = f->d_tw2;
+    a.sum = f->d_sum; a.pwr = f->d_pwr; a.ave = f->d_ave; a.counters = f->d_cnt; a.overload = f->d_over;
+    a.channels = f->channels; a.nframes = nframes; a.ave_size = f->ave_size;
+    a.kc = (float)f->kc; a.kb = f->kb;
+    CSDR_HIP(spectrum_launch(log2_of(f->size), a, (hipStream_t)stream));
+    return CSDR_OK;
+}
+/* copy of m_pFFTAveBuf of one channel (bels, display order), synchronises */
+int csdr_fft_batch_get_ave(csdr_fft_batch *f, int channel, float *out)
+{
+    if (!f || !out || channel < 0 || channel >= f->channels) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    CSDR_HIP(hipMemcpy(out, f->d_ave + (size_t)channel * f->size, (size_t)f->size * 4, hipMemcpyDeviceToHost));
+    return f->size;
+}
+int csdr_fft_batch_get_total_count(csdr_fft_batch *f, int channel)
+{
+    if (!f || channel < 0 || channel >= f->channels) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    int c[2];
+    CSDR_HIP(hipDeviceSynchronize());
+    CSDR_HIP(hipMemcpy(c, f->d_cnt + 2 * channel, sizeof(c), hipMemcpyDeviceToHost));
+    return c[1];
+}
+
+/* CFft::GetScreenIntegerFFTData (fft.cpp:308-410) on the N-float read-back of one channel.
+ * Returns 1 if the last PutInDisplayFFT saw an overload, 0 otherwise. */
+int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max_w, double max_db, double min_db,
+                              int start_hz, int stop_hz, int *out)
+{
+    if (!f || !out || channel < 0 || channel >= f->channels) return fail(CSDR_EINVAL, "bad argument");
+    const int n = f->size;
+    f->h_ave.resize(n);
+    int rc = csdr_fft_batch_get_ave(f, channel, f->h_ave.data());
+    if (rc < 0) return rc;
+    int over = 0;
+    CSDR_HIP(hipMemcpy(&over, f->d_over + channel, sizeof(int), hipMemcpyDeviceToHost));
+    const float *ave = f->h_ave.data();
+    int i, x, y, ymax = 10000, xprev = -1;
+    const double off = max_db / 10.0, gain = -10.0 / (max_db - min_db);
+    if (f->start_hz != start_hz || f->stop_hz != stop_hz || f->plot_w != max_w) {
+        const int maxbin = n - 1;
+        f->start_hz = start_hz; f->stop_hz = stop_hz; f->plot_w = max_w;
+        f->bin_min = (int)((double)start_hz * (double)n / f->fs) + n / 2;
+        f->bin_max = (int)((double)stop_hz * (double)n / f->fs) + n / 2;
+        if (f->bin_min < 0) f->bin_min = 0;
+        if (f->bin_min >= maxbin) f->bin_min = maxbin;
+        if (f->bin_max < 0) f->bin_max = 0;
+        if (f->bin_max >= maxbin) f->bin_max = maxbin;
+        if ((f->bin_max - f->bin_min) > f->plot_w) {
+            for (i = f->bin_min; i <= f->bin_max; i++)
+                f->xlat[i] = ((i - f->bin_min) * f->plot_w) / (f->bin_max - f->bin_min);
+        } else {
+            for (i = 0; i < f->plot_w && i < n; i++)
+                f->xlat[i] = f->bin_min + (i * (f->bin_max - f->bin_min)) / f->plot_w;
+        }
+    }
+    auto level = [&](int bin) {
+        int b = f->invert ? (n - bin) : bin;
+        if (b >= n) b = n - 1;                         // the reference reads one past the end here
+        int v = (int)((double)max_h * gain * ((double)ave[b] - off));
+        if (v < 0) v = 0;
+        if (v > max_h) v = max_h;
+        return v;
+    };
+    if ((f->bin_max - f->bin_min) > f->plot_w) {
+        for (i = f->bin_min; i <= f->bin_max; i++) {
+            y = level(i);
+            x = f->xlat[i];
+            if (x == xprev) {
+                if (y < ymax) { out[x] = y; ymax = y; }
+            } else {
+                out[x] = y; xprev = x; ymax = y;
+            }
+        }
+    } else {
+        for (x = 0; x < f->plot_w; x++) out[x] = level(f->xlat[x]);
+    }
+    return over ? 1 : 0;
+}
+
+}  // extern "C"
+
+/* ---------------- single-channel host form: CFft drop-in ---------------- */
+struct csdr_fft {
+    csdr_fft_batch *b;
+    float *d_buf; size_t cap;
+    std::vector<float> st;
+};
+
+static int fft_host_buf(csdr_fft *f, size_t n)
+{
+    if (n <= f->cap) return CSDR_OK;
+    if (f->d_buf) (void)hipFree(f->d_buf);
+    f->d_buf = nullptr; f->cap = 0;
+    CSDR_HIP(hipMalloc((void **)&f->d_buf, n * 8));
+    f->cap = n;
+    return CSDR_OK;
+}
+
+extern "C" {
+
+csdr_fft *csdr_fft_create(int device)
+{
+    csdr_fft_batch *b = csdr_fft_batch_create(device, 1);
+    if (!b) return nullptr;
+    csdr_fft *f = new csdr_fft();
+    f->b = b; f->d_buf = nullptr; f->cap = 0;
+    return f;
+}
+void csdr_fft_destroy(csdr_fft *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->b->device);
+    if (f->d_buf) (void)hipFree(f->d_buf);
+    csdr_fft_batch_destroy(f->b);
+    delete f;
+}
+int csdr_fft_set_params(csdr_fft *f, int size, int invert, double db_comp, double fs)
+{ return f ? csdr_fft_batch_set_params(f->b, size, invert, db_comp, fs) : fail(CSDR_EINVAL, "bad handle"); }
+int csdr_fft_set_ave(csdr_fft *f, int ave)
+{ return f ? csdr_fft_batch_set_ave(f->b, ave) : fail(CSDR_EINVAL, "bad handle"); }
+int csdr_fft_reset(csdr_fft *f)
+{ return f ? csdr_fft_batch_reset(f->b) : fail(CSDR_EINVAL, "bad handle"); }
+
+/* CFft::PutInDisplayFFT (fft.cpp:267-288): n should equal the FFT size; returns m_TotalCount */
+int csdr_fft_put_display(csdr_fft *f, int n, const double *in_iq)
+{
+    if (!f || n < 0 || (n && !in_iq)) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(f->b->device)) return CSDR_EHIP;
+    const int N = f->b->size;
+    int rc = fft_host_buf(f, (size_t)N);
+    if (rc) return rc;
+    f->st.assign(2 * (size_t)N, 0.f);                 // the reference keeps stale data past n; zeros here
+    const int m = n < N ? n : N;
+    for (size_t i = 0; i < 2 * (size_t)m; i++) f->st[i] = (float)in_iq[i];
+    CSDR_HIP(hipMemcpy(f->d_buf, f->st.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+    rc = csdr_fft_batch_put_display(f->b, f->d_buf, N, 1, nullptr);
+    if (rc) return rc;
+    return csdr_fft_batch_get_total_count(f->b, 0);
+}
+/* CFft::GetScreenIntegerFFTData (fft.cpp:308-410); returns the overload flag */
+int csdr_fft_get_screen(csdr_fft *f, int max_h, int max_w, double max_db, double min_db, int start_hz,
+                        int stop_hz, int *out)
+{ return f ? csdr_fft_batch_get_screen(f->b, 0, max_h, max_w, max_db, min_db, start_hz, stop_hz, out)
+           : fail(CSDR_EINVAL, "bad handle"); }
+int csdr_fft_get_ave(csdr_fft *f, float *out)
+{ return f ? csdr_fft_batch_get_ave(f->b, 0, out) : fail(CSDR_EINVAL, "bad handle"); }
+
+/* CFft::FwdFFT / RevFFT (fft.cpp:416-426): in-place N-point transform of interleaved doubles.
+ * The reference's FwdFFT also feeds the display average; this one does not. */
+static int fft_plain(csdr_fft *f, double *inout, int sign)
+{
+    if (!f || !inout) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(f->b->device)) return CSDR_EHIP;
+    const int N = f->b->size;
+    int rc = fft_host_buf(f, (size_t)N);
+    if (rc) return rc;
+    f->st.resize(2 * (size_t)N);
+    for (size_t i = 0; i < 2 * (size_t)N; i++) f->st[i] = (float)inout[i];
+    CSDR_HIP(hipMemcpy(f->d_buf, f->st.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+    CSDR_HIP(fft_plain_launch(log2_of(N), sign, f->d_buf, f->d_buf, f->b->d_tw1, f->b->d_tw2, nullptr));
+    CSDR_HIP(hipMemcpy(f->st.data(), f->d_buf, (size_t)N * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < 2 * (size_t)N; i++) inout[i] = (double)f->st[i];
+    return CSDR_OK;
+}
+int csdr_fft_fwd(csdr_fft *f, double *inout_iq) { return fft_plain(f, inout_iq, +1); }
+int csdr_fft_rev(csdr_fft *f, double *inout_iq) { return fft_plain(f, inout_iq, -1); }
+
+}  // extern "C"

@@ -1,0 +1,24 @@
+// spectrum_kernels.h -- launch interface of the CFft kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace csdr {
+
+struct SpectrumArgs {
+    const float *in;  long in_stride;   // complex fp32 [channels][in_stride], frames back to back
+    const float *win;                   // [N] window (Hann*2, dsp/fft.cpp:196-198)
+    const float *tw1, *tw2;             // twiddle tables as for the FastFIR kernel
+    float *sum, *pwr;                   // [channels][N] running sum / mean power (display order)
+    float *ave;                         // [channels][N] log10(mean + K_C) + K_B, in bels
+    int *counters;                      // [channels][2]: ave_count, total_count
+    int *overload;                      // [channels]
+    int channels, nframes, ave_size;
+    float kc; double kb;
+};
+hipError_t spectrum_launch(int log2n, const SpectrumArgs &a, hipStream_t stream);
+
+// plain transform of one N-point block: sign=+1 CFft::FwdFFT, -1 RevFFT; natural order in/out
+hipError_t fft_plain_launch(int log2n, int sign, const float *in, float *out, const float *tw1,
+                            const float *tw2, hipStream_t stream);
+
+}  // namespace csdr

@@ -1,0 +1,207 @@
+// spectrum_kernels.hip -- CFft display spectrum and plain N-point transforms for gfx950 (K3).
+//
+// Replaces CFft::PutInDisplayFFT (reference dsp/fft.cpp:267-288: Hann*2 window, I/Q swap, forward
+// transform) together with the tail of CFft::CpxFFT (:562-589: |X|^2, running mean over AveSize
+// frames, log10, fft-shifted into display order), and CFft::FwdFFT / RevFFT (:416-426).
+// One workgroup of N/32 threads per channel walks that channel's frames in order (the running
+// mean makes frames sequential); the transform is the same three-pass decimation-in-frequency
+// FFT as the overlap-save kernel (fft_core.hpp), its digit-reversed output is scattered straight
+// into display order.  8 B in + 4 B out per bin.
+#include "fft_core.hpp"
+#include "spectrum_kernels.h"
+
+namespace csdr {
+
+template <int LOG2N>
+struct SpecCfg {
+    static constexpr int N = 1 << LOG2N, T = N / 32, R0 = N / 1024, G = 32 / R0;
+    static constexpr int LDS_DATA = N + 2 * (N / 32);
+    static constexpr int LDS_BYTES = (LDS_DATA + 1024) * 8;
+};
+
+// forward (positive exponent) transform of the block held as x[e*R0+n1] <-> sample 1024*n1+G*t+e;
+// on return x[r] is spectrum bin  (t>>5) + R0*((t&31) + 32*bitrev5(r))
+template <int LOG2N>
+__device__ __forceinline__ void fft_fwd_passes(v2f (&x)[32], v2f *lds, const v2f *tw2, const v2f *w1)
+{
+    using Cfg = SpecCfg<LOG2N>;
+    constexpr int R0 = Cfg::R0, G = Cfg::G;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < G; e++) {
+        v2f y[R0];
+#pragma unroll
+        for (int i = 0; i < R0; i++) y[i] = x[e * R0 + i];
+        dft_dif<R0, +1>(y);
+        v2f pw[R0];
+        twiddle_powers<R0>(opaque(w1[e]), pw);
+        static_for<0, R0>([&](auto Rr) {
+            constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+            if constexpr (k0 != 0) y[r] = cmul(y[r], pw[k0]);
+        });
+#pragma unroll
+        for (int i = 0; i < R0; i++) x[e * R0 + i] = y[i];
+    }
+    __syncthreads();
+    static_for<0, R0>([&](auto Rr) {
+        constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+        const int base = lds_pad(1024 * k0 + G * t);
+#pragma unroll
+        for (int e = 0; e < G; e++) lds[base + e] = x[e * R0 + r];      // 8-byte stores
+    });
+    __syncthreads();
+    const int sb = t >> 5, sn = t & 31;
+    const int base = lds_pad(1024 * sb) + sn;
+#pragma unroll
+    for (int n1 = 0; n1 < 32; n1++) x[n1] = lds[base + 34 * n1];
+    dft_dif<32, +1>(x);
+    static_for<1, 32>([&](auto Rr) {
+        constexpr int r = Rr.value, k1 = bitrev<32>(r);
+        x[r] = cmul(x[r], tw2[k1 * 32 + sn]);
+    });
+    static_for<0, 32>([&](auto Rr) {
+        constexpr int r = Rr.value, k1 = bitrev<32>(r);
+        lds[base + 34 * k1] = x[r];
+    });
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 32; n++) x[n] = lds[34 * t + n];
+    dft_dif<32, +1>(x);
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(SpecCfg<LOG2N>::T)
+void spectrum_kernel(SpectrumArgs a)
+{
+    using Cfg = SpecCfg<LOG2N>;
+    constexpr int N = Cfg::N, T = Cfg::T, R0 = Cfg::R0, G = Cfg::G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+    v2f *tw2 = lds + Cfg::LDS_DATA;
+    const int t = threadIdx.x, ch = blockIdx.x;
+    for (int i = t; i < 1024; i += T) tw2[i] = reinterpret_cast<const v2f *>(a.tw2)[i];
+    v2f w1[G];
+#pragma unroll
+    for (int e = 0; e < G; e++) w1[e] = reinterpret_cast<const v2f *>(a.tw1)[G * t + e];
+    const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
+    float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
+    int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    int over = 0;
+    for (int f = 0; f < a.nframes; f++) {
+        const v2f *src = in + (long)f * N;
+        v2f x[32];
+#pragma unroll
+        for (int e = 0; e < G; e++)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; n1++) {
+                const int i = 1024 * n1 + G * t + e;
+                const v2f s = src[i];
+                const float w = a.win[i];
+                if (s.x > 32000.0f) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
+                x[e * R0 + n1] = v2f{w * s.y, w * s.x};           // I/Q swapped, fft.cpp:280-281
+            }
+        total++;                                                  // CpxFFT counters, fft.cpp:515-517
+        if (ave_count < a.ave_size) ave_count++;
+        __syncthreads();
+        fft_fwd_passes<LOG2N>(x, lds, tw2, w1);
+        int tt = t;
+        asm volatile("" : "+v"(tt));          // keep the 96 scattered addresses out of LICM's hands
+        const int k0 = tt >> 5, k1 = tt & 31;
+        static_for<0, 32>([&](auto Rr) {
+            constexpr int r = Rr.value, k2 = bitrev<32>(r);
+            const int k = k0 + R0 * (k1 + 32 * k2);
+            const int j = (k + N / 2) & (N - 1);                  // display order, fft.cpp:564-589
+            const float p = x[r].x * x[r].x + x[r].y * x[r].y;
+            float sm = sum[j];
+            if (total <= a.ave_size) sm = sm + p;
+            else sm = sm - pwr[j] + p;
+            sum[j] = sm;
+            const float m = sm / (float)ave_count;
+            pwr[j] = m;
+            ave[j] = (float)((double)log10f(m + a.kc) + a.kb);
+            if constexpr ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the live loads
+        });
+    }
+    if (t == 0) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }
+    if (over) a.overload[ch] = 1;
+}
+
+// plain transform: out[k] = sum_n in[n] e^{sign j 2 pi n k / N}; sign=-1 via conjugation
+template <int LOG2N>
+__global__ __launch_bounds__(SpecCfg<LOG2N>::T)
+void fft_plain_kernel(const v2f *in, v2f *out, const v2f *tw1g, const v2f *tw2g, int sign)
+{
+    using Cfg = SpecCfg<LOG2N>;
+    constexpr int T = Cfg::T, R0 = Cfg::R0, G = Cfg::G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+    v2f *tw2 = lds + Cfg::LDS_DATA;
+    const int t = threadIdx.x;
+    for (int i = t; i < 1024; i += T) tw2[i] = tw2g[i];
+    v2f w1[G];
+#pragma unroll
+    for (int e = 0; e < G; e++) w1[e] = tw1g[G * t + e];
+    const float cj = sign > 0 ? 1.0f : -1.0f;
+    v2f x[32];
+#pragma unroll
+    for (int e = 0; e < G; e++)
+#pragma unroll
+        for (int n1 = 0; n1 < R0; n1++) {
+            const v2f s = in[1024 * n1 + G * t + e];
+            x[e * R0 + n1] = v2f{s.x, cj * s.y};
+        }
+    __syncthreads();
+    fft_fwd_passes<LOG2N>(x, lds, tw2, w1);
+    const int k0 = t >> 5, k1 = t & 31;
+    __syncthreads();                       // in == out allowed: every input was read before pass 1
+    static_for<0, 32>([&](auto Rr) {
+        constexpr int r = Rr.value, k2 = bitrev<32>(r);
+        out[k0 + R0 * (k1 + 32 * k2)] = v2f{x[r].x, cj * x[r].y};
+    });
+}
+
+template <int LOG2N>
+static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
+{
+    using Cfg = SpecCfg<LOG2N>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spectrum_kernel<LOG2N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+template <int LOG2N>
+static hipError_t plain_launch_one(int sign, const float *in, float *out, const float *tw1, const float *tw2, hipStream_t s)
+{
+    using Cfg = SpecCfg<LOG2N>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_plain_kernel<LOG2N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fft_plain_kernel<LOG2N>, dim3(1), dim3(Cfg::T), Cfg::LDS_BYTES, s, (const v2f *)in, (v2f *)out,
+                       (const v2f *)tw1, (const v2f *)tw2, sign);
+    return hipGetLastError();
+}
+
+hipError_t spectrum_launch(int log2n, const SpectrumArgs &a, hipStream_t stream)
+{
+    switch (log2n) {
+    case 11: return spec_launch_one<11>(a, stream);
+    case 12: return spec_launch_one<12>(a, stream);
+    case 13: return spec_launch_one<13>(a, stream);
+    case 14: return spec_launch_one<14>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+hipError_t fft_plain_launch(int log2n, int sign, const float *in, float *out, const float *tw1,
+                            const float *tw2, hipStream_t stream)
+{
+    switch (log2n) {
+    case 11: return plain_launch_one<11>(sign, in, out, tw1, tw2, stream);
+    case 12: return plain_launch_one<12>(sign, in, out, tw1, tw2, stream);
+    case 13: return plain_launch_one<13>(sign, in, out, tw1, tw2, stream);
+    case 14: return plain_launch_one<14>(sign, in, out, tw1, tw2, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace csdr

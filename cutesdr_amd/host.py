@@ -521,3 +521,112 @@ class DemodBatch(_Obj):
         y = dout.download(np.float32, self.channels * (T + self.n)).reshape(self.channels, T + self.n)
         din.free(); dout.free()
         return [y[c, :self.out_count(c)].copy() for c in range(self.channels)]
+
+
+class CFft(_Obj):
+    """dsp/fft.h:24-85 -- display spectrum + plain transforms (device sizes 2048..16384)."""
+    _destroy = "csdr_fft_destroy"
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_fft_create(device), "csdr_fft_create")
+        self.size = 2048
+
+    def SetFFTParams(self, size, invert, dBCompensation, SampleFreq):
+        check(lib().csdr_fft_set_params(self.h, size, int(invert), dBCompensation, SampleFreq), "csdr_fft_set_params")
+        self.size = max(512, min(65536, size))
+
+    def SetFFTAve(self, ave):
+        check(lib().csdr_fft_set_ave(self.h, ave))
+
+    def ResetFFT(self):
+        check(lib().csdr_fft_reset(self.h))
+
+    def PutInDisplayFFT(self, InBuf):
+        a = _c128(InBuf)
+        return check(lib().csdr_fft_put_display(self.h, len(a), _vp(a)), "csdr_fft_put_display")
+
+    def GetScreenIntegerFFTData(self, MaxHeight, MaxWidth, MaxdB, MindB, StartFreq, StopFreq):
+        out = np.zeros(max(MaxWidth, 1), dtype=np.int32)
+        ov = check(lib().csdr_fft_get_screen(self.h, MaxHeight, MaxWidth, MaxdB, MindB, StartFreq, StopFreq, _vp(out)))
+        return bool(ov), out
+
+    def ave_buf(self):
+        out = np.zeros(self.size, dtype=np.float32)
+        check(lib().csdr_fft_get_ave(self.h, _vp(out)))
+        return out
+
+    def FwdFFT(self, x):
+        a = _c128(x).copy(); check(lib().csdr_fft_fwd(self.h, _vp(a))); return a
+
+    def RevFFT(self, x):
+        a = _c128(x).copy(); check(lib().csdr_fft_rev(self.h, _vp(a))); return a
+
+
+class FftBatch(_Obj):
+    """Batched display spectra over [channels][frames*size] fp32 I/Q on the device."""
+    _destroy = "csdr_fft_batch_destroy"
+
+    def __init__(self, channels, device=0):
+        self.channels, self.device = channels, device
+        self.h = check_ptr(lib().csdr_fft_batch_create(device, channels), "csdr_fft_batch_create")
+
+    def set_params(self, size, invert, db_comp, fs):
+        check(lib().csdr_fft_batch_set_params(self.h, size, int(invert), db_comp, fs), "fft_batch_set_params")
+
+    def set_ave(self, ave):
+        check(lib().csdr_fft_batch_set_ave(self.h, ave))
+
+    def size(self):
+        return check(lib().csdr_fft_batch_size(self.h))
+
+    def put_display_ptr(self, d_in, in_stride, nframes, stream=None):
+        check(lib().csdr_fft_batch_put_display(self.h, C.c_void_p(d_in), in_stride, nframes,
+                                               C.c_void_p(stream) if stream else None), "fft_batch_put_display")
+
+    def put_display(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        n = self.size()
+        din = DeviceBuffer(x.nbytes, self.device)
+        din.upload(x)
+        self.put_display_ptr(din.ptr, x.shape[1], x.shape[1] // n)
+        sync(self.device)
+        din.free()
+
+    def ave_buf(self, channel):
+        out = np.zeros(self.size(), dtype=np.float32)
+        check(lib().csdr_fft_batch_get_ave(self.h, channel, _vp(out)))
+        return out
+
+    def total_count(self, channel):
+        return check(lib().csdr_fft_batch_get_total_count(self.h, channel))
+
+
+class CFractResampler(_Obj):
+    """dsp/fractresampler.h:17-33"""
+    _destroy = "csdr_resampler_destroy"
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_resampler_create(device), "csdr_resampler_create")
+
+    def Init(self, MaxInputSize):
+        check(lib().csdr_resampler_init(self.h, MaxInputSize))
+
+    def Resample(self, x, Rate, gain=None):
+        cap = int(len(x) / Rate) + 8
+        if np.iscomplexobj(x):
+            a = _c128(x)
+            if gain is None:
+                out = np.zeros(cap, dtype=np.complex128)
+                k = check(lib().csdr_resampler_resample_cpx(self.h, len(a), Rate, _vp(a), _vp(out)))
+                return out[:k]
+            out = np.zeros(2 * cap, dtype=np.int16)
+            k = check(lib().csdr_resampler_resample_cpx_i16(self.h, len(a), Rate, _vp(a), _vp(out), gain))
+            return out[:2 * k].reshape(-1, 2)
+        a = _f64(x)
+        if gain is None:
+            out = np.zeros(cap)
+            k = check(lib().csdr_resampler_resample_real(self.h, len(a), Rate, _vp(a), _vp(out)))
+            return out[:k]
+        out = np.zeros(cap, dtype=np.int16)
+        k = check(lib().csdr_resampler_resample_real_i16(self.h, len(a), Rate, _vp(a), _vp(out), gain))
+        return out[:k]

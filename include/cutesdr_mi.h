@@ -247,6 +247,58 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
                              int n_per_channel, float *d_out, long long out_stride, void *stream);
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
 
+/* ----------------------------------------------------------------------------------------
+ * CFft -- display spectrum and plain transforms (dsp/fft.h:24-85).  FFT sizes 2048..16384 run on
+ * the device in this build (the reference accepts 512..65536: set_params returns CSDR_EINVAL
+ * outside that range).
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_fft csdr_fft;
+csdr_fft *csdr_fft_create(int device);                                       /* fft.cpp:41-62 */
+void csdr_fft_destroy(csdr_fft *f);
+int csdr_fft_set_params(csdr_fft *f, int size, int invert, double db_comp, double fs);  /* :118-243 */
+int csdr_fft_set_ave(csdr_fft *f, int ave);                                  /* :103-113 */
+int csdr_fft_reset(csdr_fft *f);                                             /* :248-259 */
+/* CFft::PutInDisplayFFT (:267-288): n complex doubles (n = FFT size); returns m_TotalCount */
+int csdr_fft_put_display(csdr_fft *f, int n, const double *in_iq);
+/* CFft::GetScreenIntegerFFTData (:308-410): fills out[0..max_w), returns the overload flag */
+int csdr_fft_get_screen(csdr_fft *f, int max_h, int max_w, double max_db, double min_db,
+                        int start_hz, int stop_hz, int *out);
+/* m_pFFTAveBuf (bels, display order, `size` floats) for tests; returns the size */
+int csdr_fft_get_ave(csdr_fft *f, float *out);
+/* CFft::FwdFFT / RevFFT (:416-426): in-place, unnormalised, FwdFFT has the POSITIVE exponent */
+int csdr_fft_fwd(csdr_fft *f, double *inout_iq);
+int csdr_fft_rev(csdr_fft *f, double *inout_iq);
+
+/* batched spectra: [channels][in_stride] complex fp32 on the device, nframes frames per row */
+typedef struct csdr_fft_batch csdr_fft_batch;
+csdr_fft_batch *csdr_fft_batch_create(int device, int channels);
+void csdr_fft_batch_destroy(csdr_fft_batch *f);
+int csdr_fft_batch_set_params(csdr_fft_batch *f, int size, int invert, double db_comp, double fs);
+int csdr_fft_batch_set_ave(csdr_fft_batch *f, int ave);
+int csdr_fft_batch_reset(csdr_fft_batch *f);
+int csdr_fft_batch_size(csdr_fft_batch *f);
+int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long in_stride, int nframes,
+                               void *stream);
+int csdr_fft_batch_get_ave(csdr_fft_batch *f, int channel, float *out);
+int csdr_fft_batch_get_total_count(csdr_fft_batch *f, int channel);
+int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max_w, double max_db,
+                              double min_db, int start_hz, int stop_hz, int *out);
+
+/* ----------------------------------------------------------------------------------------
+ * CFractResampler (dsp/fractresampler.h:17-33)
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_resampler csdr_resampler;
+csdr_resampler *csdr_resampler_create(int device);
+void csdr_resampler_destroy(csdr_resampler *r);
+int csdr_resampler_init(csdr_resampler *r, int max_input_size);              /* fractresampler.cpp:85-135 */
+/* Resample overloads: rate = input rate / output rate; return the output sample count */
+int csdr_resampler_resample_real(csdr_resampler *r, int n, double rate, const double *in, double *out);       /* :258-297 */
+int csdr_resampler_resample_cpx(csdr_resampler *r, int n, double rate, const double *in_iq, double *out_iq);  /* :144-184 */
+int csdr_resampler_resample_real_i16(csdr_resampler *r, int n, double rate, const double *in, short *out,
+                                     double gain);                           /* :306-352 */
+int csdr_resampler_resample_cpx_i16(csdr_resampler *r, int n, double rate, const double *in_iq, short *out_lr,
+                                    double gain);                            /* :194-249 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,118 @@
+"""GPU parity of the CFft display spectrum / plain transforms (K3) and of CFractResampler (K5)
+against the fp64 oracle, through the C ABI.  K3 tolerance: 0.01 dB on every bin within 60 dB of
+the frame's strongest bin, 0.5 dB on every other bin above -150 dBFS (an fp32 transform has its
+rounding floor ~125 dB below the strongest component, so weak bins beside a strong carrier
+cannot hold 0.01 dB); plain transforms 2e-5 * N * max|x|; resampler 1e-5 * max|x|, counts exact,
+int16 outputs within 1 LSB."""
+import numpy as np
+import pytest
+from util_signals import tones_plus_noise, FULL_SCALE
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_spectrum_close(got, want):
+    """got / want in bels (display order)."""
+    err = np.abs(got - want)
+    near = want > want.max() - 6.0                           # within 60 dB of the strongest bin
+    assert err[near].max() <= 0.001                          # 0.01 dB
+    rest = (want > -15.0) & ~near                            # everything else above -150 dBFS
+    if rest.any():
+        assert err[rest].max() <= 0.05                       # 0.5 dB
+
+
+@pytest.mark.parametrize("n,ave", [(4096, 1), (2048, 4), (16384, 3)])
+def test_display_spectrum_matches_oracle(oracle, n, ave):
+    import cutesdr_amd as ca
+    fs = 2e6
+    f, r = ca.CFft(), oracle.CFft()
+    for o in (f, r):
+        o.SetFFTParams(n, False, 0.0, fs)
+        o.SetFFTAve(ave)
+    for k in range(7):                                       # C1: -20 dBFS tone at +250 kHz, noise -70 dBFS
+        x = tones_plus_noise(k, n, fs, [250e3, -611e3 + 977.0 * k], start=k * n)
+        assert f.PutInDisplayFFT(x) == r.PutInDisplayFFT(x) == k + 1
+        got, want = f.ave_buf().astype(np.float64), r.ave_buf()
+        assert_spectrum_close(got, want)
+        assert np.argmax(got) == np.argmax(want)
+    ovg, pg = f.GetScreenIntegerFFTData(1 << 16, 700, 0.0, -160.0, -900000, 900000)
+    ovr, pr = r.GetScreenIntegerFFTData(1 << 16, 700, 0.0, -160.0, -900000, 900000)
+    assert ovg == ovr is False
+    assert np.abs(pg - pr).max() <= 8                         # 65536 px over 160 dB: 0.02 dB per 8 px
+    ovg, pg = f.GetScreenIntegerFFTData(300, n - 1, 0.0, -220.0, -1000000, 1000000)   # more pixels than bins
+    ovr, pr = r.GetScreenIntegerFFTData(300, n - 1, 0.0, -220.0, -1000000, 1000000)
+    assert np.abs(pg - pr).max() <= 1
+    big = x.copy(); big[5] = 32500.0
+    f.PutInDisplayFFT(big); r.PutInDisplayFFT(big)
+    assert f.GetScreenIntegerFFTData(100, 50, 0.0, -100.0, 0, 500000)[0] is True
+
+
+def test_display_anchor_c1():
+    # -20 dBFS tone at +250 kHz, Fs 2 MHz, N 4096 -> display index 2560, -1.3982 bels
+    import cutesdr_amd as ca
+    n, fs = 4096, 2e6
+    f = ca.CFft(); f.SetFFTParams(n, False, 0.0, fs); f.SetFFTAve(1)
+    f.PutInDisplayFFT(3276.7 * np.exp(2j * np.pi * 250e3 * np.arange(n) / fs))
+    a = f.ave_buf()
+    assert np.argmax(a) == 2560 and a[2560] == pytest.approx(-1.3982, abs=2e-4)
+
+
+def test_unsupported_sizes_fail_loudly():
+    import cutesdr_amd as ca
+    from cutesdr_amd._capi import CsdrError
+    f = ca.CFft()
+    with pytest.raises(CsdrError):
+        f.SetFFTParams(1024, False, 0.0, 48000.0)
+    with pytest.raises(CsdrError):
+        f.SetFFTParams(65536, False, 0.0, 48000.0)
+
+
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+def test_plain_transforms(oracle, n):
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(n)
+    x = 1000 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    f = ca.CFft(); f.SetFFTParams(n, False, 0.0, 1.0)
+    tol = 2e-5 * n * np.abs(x).max() / np.sqrt(n) * 4
+    assert np.abs(f.FwdFFT(x) - oracle.fft(x, +1)).max() <= tol
+    assert np.abs(f.RevFFT(x) - oracle.fft(x, -1)).max() <= tol
+    back = f.RevFFT(f.FwdFFT(x)) / n                          # Rev(Fwd(x)) = N x
+    assert np.abs(back - x).max() <= 2e-5 * np.abs(x).max() * 20
+
+
+def test_fft_batch_frames_and_channels(oracle):
+    import cutesdr_amd as ca
+    n, C, frames, fs = 4096, 3, 5, 2e6
+    b = ca.FftBatch(C)
+    b.set_params(n, False, 0.0, fs); b.set_ave(2)
+    x = np.stack([tones_plus_noise(40 + c, frames * n, fs, [100e3 * (c + 1)]) for c in range(C)])
+    b.put_display(x)
+    for c in range(C):
+        r = oracle.CFft(); r.SetFFTParams(n, False, 0.0, fs); r.SetFFTAve(2)
+        for k in range(frames):
+            r.PutInDisplayFFT(x[c, k * n:(k + 1) * n])
+        assert b.total_count(c) == frames
+        want = r.ave_buf()
+        assert_spectrum_close(b.ave_buf(c).astype(np.float64), want)
+
+
+@pytest.mark.parametrize("rate", [1.0, 1.6276041666666667, 0.7312, 2.5])
+def test_resampler_all_overloads(oracle, rate):
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(11)
+    x = 8000 * rng.standard_normal(3 * 2048)
+    xc = x + 8000j * rng.standard_normal(3 * 2048)
+    for data, gain in ((x, None), (xc, None), (x, 1.7), (xc, 0.9)):
+        g, r = ca.CFractResampler(), oracle.CFractResampler()
+        g.Init(4096); r.Init(4096)
+        for i in range(3):
+            part = data[i * 2048:(i + 1) * 2048]
+            got, want = g.Resample(part, rate, gain), r.Resample(part, rate, gain)
+            assert len(got) == len(want)
+            if gain is None:
+                assert np.abs(got - want).max() <= 1e-5 * 8000 * 6
+            else:
+                assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1
+    g = ca.CFractResampler(); g.Init(8192)
+    y = g.Resample(x[:4096], 1.6276)
+    assert len(y) == 2517                                    # App. A.9 anchor
