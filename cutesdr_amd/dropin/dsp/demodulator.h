@@ -1,0 +1,84 @@
+// dsp/demodulator.h drop-in: tDemodInfo and class CDemodulator with the reference's public surface
+// (reference dsp/demodulator.h:20-100).  The whole chain runs device-resident behind
+// csdr_demod_* of libcutesdr_mi.
+#ifndef DEMODULATOR_H
+#define DEMODULATOR_H
+#include "dsp/datatypes.h"
+#include "dsp/csdr_dropin.h"
+#if defined(QT_CORE_LIB) || defined(QT_VERSION)
+#include <QString>
+typedef QString csdr_label_t;
+#else
+#include <string>
+typedef std::string csdr_label_t;
+#endif
+
+#define DEMOD_AM 0
+#define DEMOD_SAM 1
+#define DEMOD_FM 2
+#define DEMOD_USB 3
+#define DEMOD_LSB 4
+#define DEMOD_CWU 5
+#define DEMOD_CWL 6
+#define NUM_DEMODS 7
+#define MAX_INBUFSIZE 250000
+#define MAX_MAGBUFSIZE 32000
+
+typedef struct _sdmd
+{
+    int HiCut;
+    int HiCutmin;
+    int HiCutmax;
+    int LowCut;
+    int LowCutmin;
+    int LowCutmax;
+    int FilterClickResolution;
+    int Offset;
+    int SquelchValue;
+    int AgcSlope;
+    int AgcThresh;
+    int AgcManualGain;
+    int AgcDecay;
+    bool AgcOn;
+    bool AgcHangOn;
+    bool Symetric;
+    csdr_label_t txt;
+} tDemodInfo;
+
+class CDemodulator
+{
+public:
+    CDemodulator() : m_h(csdr_dropin_handle(csdr_demod_create(CSDR_DEVICE, CSDR_FASTFIR_SIZE), "CDemodulator")) {}
+    virtual ~CDemodulator() { csdr_demod_destroy(m_h); }
+    CDemodulator(const CDemodulator &) = delete;
+    CDemodulator &operator=(const CDemodulator &) = delete;
+
+    void SetInputSampleRate(TYPEREAL InputRate)
+    { std::lock_guard<std::mutex> g(m_Mutex); csdr_dropin_count(csdr_demod_set_input_rate(m_h, InputRate), "CDemodulator::SetInputSampleRate"); }
+    double GetOutputRate() { return csdr_demod_get_output_rate(m_h); }
+    double GetSMeterPeak() { return csdr_demod_get_smeter_peak(m_h); }
+    double GetSMeterAve() { return csdr_demod_get_smeter_ave(m_h); }
+    void SetDemod(int Mode, tDemodInfo CurrentDemodInfo)
+    {
+        std::lock_guard<std::mutex> g(m_Mutex);
+        csdr_demod_info i;
+        i.HiCut = CurrentDemodInfo.HiCut; i.HiCutmin = CurrentDemodInfo.HiCutmin; i.HiCutmax = CurrentDemodInfo.HiCutmax;
+        i.LowCut = CurrentDemodInfo.LowCut; i.LowCutmin = CurrentDemodInfo.LowCutmin; i.LowCutmax = CurrentDemodInfo.LowCutmax;
+        i.FilterClickResolution = CurrentDemodInfo.FilterClickResolution; i.Offset = CurrentDemodInfo.Offset;
+        i.SquelchValue = CurrentDemodInfo.SquelchValue; i.AgcSlope = CurrentDemodInfo.AgcSlope;
+        i.AgcThresh = CurrentDemodInfo.AgcThresh; i.AgcManualGain = CurrentDemodInfo.AgcManualGain;
+        i.AgcDecay = CurrentDemodInfo.AgcDecay; i.AgcOn = CurrentDemodInfo.AgcOn; i.AgcHangOn = CurrentDemodInfo.AgcHangOn;
+        i.Symetric = CurrentDemodInfo.Symetric;
+        csdr_dropin_count(csdr_demod_set_demod(m_h, Mode, &i), "CDemodulator::SetDemod");
+    }
+    void SetDemodFreq(TYPEREAL Freq) { csdr_dropin_count(csdr_demod_set_freq(m_h, Freq), "CDemodulator::SetDemodFreq"); }
+    int ProcessData(int InLength, TYPECPX *pInData, TYPEREAL *pOutData)
+    { std::lock_guard<std::mutex> g(m_Mutex); return csdr_dropin_count(csdr_demod_process_mono(m_h, InLength, &pInData->re, pOutData), "CDemodulator::ProcessData"); }
+    int ProcessData(int InLength, TYPECPX *pInData, TYPECPX *pOutData)
+    { std::lock_guard<std::mutex> g(m_Mutex); return csdr_dropin_count(csdr_demod_process_stereo(m_h, InLength, &pInData->re, &pOutData->re), "CDemodulator::ProcessData"); }
+
+private:
+    csdr_demod *m_h;
+    std::mutex m_Mutex;
+};
+#endif  // DEMODULATOR_H
