@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: BASELINE.json config C3, 256 batched channels through the
-16384-pt CFastFIR overlap-save on one MI355X (the HBM-roofline config the metric is quoted
-on).  One "step" = one pass of 256 channels x 2^19 complex samples (64 hops each) through the
-filter, inputs and outputs resident in HBM.  With --gpus N every rank owns its own 256
-channels (channels shard with no data-path collective: weak scaling).
+16384-pt CFastFIR overlap-save on one MI355X (the HBM-roofline config the metric is quoted on).
+One "step" = one pass of 256 channels x 2^19 complex samples (64 hops each) through the filter,
+inputs and outputs resident in HBM.  With --gpus N every rank owns its own 256 channels (channels
+shard with no data-path collective: weak scaling); the only torch.distributed calls are the barrier
+and the MAX-reduce of the elapsed time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
@@ -12,6 +13,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -22,22 +24,90 @@ T_PER_CH = 1 << 19
 FS = 62500.0
 ALG_BYTES_PER_SAMPLE = 16.0       # 8 B fp32 I/Q read + 8 B written
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = "complex IQ MSamples/s through CFastFIR+demod chain; achieved HBM GB/s vs peak"
 
 
+# ---------------------------------------------------------------- distributed plumbing
+def dist_init(backend=None):
+    """One process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment."""
+    import torch.distributed as dist
+    ctx = SimpleNamespace(rank=int(os.environ.get("RANK", "0")), world=int(os.environ.get("WORLD_SIZE", "1")),
+                          local=int(os.environ.get("LOCAL_RANK", "0")), dist=dist, backend=backend)
+    if ctx.world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            import torch
+            ctx.backend = "nccl"                      # = RCCL on ROCm
+            dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.local))
+        else:
+            dist.init_process_group(backend)
+    return ctx
+
+
+def shard_channels(ctx, total_channels):
+    """Contiguous channel range of this rank: [lo, hi)."""
+    per = total_channels // ctx.world
+    return ctx.rank * per, (ctx.rank + 1) * per
+
+
+def dist_barrier(ctx):
+    if ctx.world > 1:
+        ctx.dist.barrier()
+
+
+def dist_max(ctx, value):
+    if ctx.world == 1:
+        return float(value)
+    import torch
+    dev = torch.device("cuda", ctx.local) if ctx.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dist_finish(ctx):
+    if ctx.world > 1:
+        ctx.dist.destroy_process_group()
+
+
+def result_line(ctx, channels, samples, steps, warmup, elapsed, kern_ms, traffic=None, cpu=None):
+    per_step = channels * samples                     # samples one rank filters per step
+    value = per_step * steps * ctx.world / elapsed / 1e6
+    achieved = ALG_BYTES_PER_SAMPLE * per_step / (kern_ms * 1e-3) / 1e9
+    return {
+        "metric": METRIC, "value": round(value, 2), "unit": "MSamples/s",
+        "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: %d channels/GPU x 2^%d IQ samples, 16384-pt CFastFIR overlap-save "
+                               "(8193 taps, hop 8192), shared -5..+5 kHz filter @62.5 kS/s"
+                               % (channels, samples.bit_length() - 1),
+                   "channels_per_gpu": channels, "samples_per_channel": samples, "fft_size": FFT_N,
+                   "parallelism": "channels sharded x%d, no collective" % ctx.world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "csdr::fastfir_os_kernel<14, false>", "kernel_ms": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * per_step},
+        "cpu_baseline": cpu,
+    }
+
+
+# ---------------------------------------------------------------- CPU baseline
 def cpu_baseline(budget_s=12.0):
-    """The fp64 CPU restatement (oracle, kind 'port') of the same filter, 1 thread, on a
-    bounded sample of the same workload: hops of one channel until ~budget_s has elapsed."""
+    """The fp64 CPU restatement (oracle, kind 'port') of the same filter, 1 thread, on a bounded
+    sample of the same workload: hops of one channel until ~budget_s has elapsed."""
     import numpy as np
     from oracle import oracle as orc
     rng = np.random.default_rng(1)
     chunk = 1 << 20
-    x = 3000.0 * (rng.standard_normal(chunk) + 1j * rng.standard_normal(chunk))
+    x = 3276.7 * (rng.standard_normal(chunk) + 1j * rng.standard_normal(chunk))
     res = {}
     for name, faithful in (("faithful", 1), ("lean", 0)):
         ff = orc.CFastFIR(FFT_N)
         ff.set_faithful(faithful)
         ff.SetupParameters(-5000, 5000, 0, FS)
-        ff.ProcessData(x[: FFT_N])                      # warm
+        ff.ProcessData(x[:FFT_N])                       # warm
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget_s / 2:
             ff.ProcessData(x)
@@ -46,9 +116,9 @@ def cpu_baseline(budget_s=12.0):
         res[name + "_samples"] = n
     return {
         "value": round(res["faithful"], 3), "unit": "MSamples/s", "cores": 1, "kind": "port",
-        "sample": "1 channel, %d (faithful: per-FFT power/log10 side effect of dsp/fft.cpp:564-589 kept) "
-                  "+ %d (lean) samples of the C3 stream through the fp64 16384-pt oracle FastFIR"
-                  % (res["faithful_samples"], res["lean_samples"]),
+        "sample": "1 channel of the C3 stream through the fp64 16384-pt oracle FastFIR: %d samples with the "
+                  "reference's per-FFT power/log10 side effect (dsp/fft.cpp:564-589) kept = value, %d samples "
+                  "without it = lean_value" % (res["faithful_samples"], res["lean_samples"]),
         "lean_value": round(res["lean"], 3),
     }
 
@@ -58,32 +128,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=CHANNELS)
+    ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU")
     ap.add_argument("--blocks-per-wg", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        raise SystemExit("bench.py needs a GPU (libcutesdr_mi has no CPU fallback)")
+    ctx = dist_init()
+    torch.cuda.set_device(ctx.local)
 
     import cutesdr_amd as ca
     C, T = args.channels, T_PER_CH
-    dev = torch.device("cuda", local)
+    lo, _ = shard_channels(ctx, C * ctx.world)          # this rank's channels: lo .. lo+C-1
+    dev = torch.device("cuda", ctx.local)
     g = torch.Generator(device=dev)
-    g.manual_seed(0xC0DE0000 + rank)
+    g.manual_seed(0xC0DE0000 + lo)
     # synthetic IQ resident in HBM: noise at -20 dBFS of a 16-bit full scale
     x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * 3276.7
     y = torch.empty_like(x)
-    fir = ca.FastFirBatch(C, FFT_N, device=local)
+    fir = ca.FastFirBatch(C, FFT_N, device=ctx.local)
     fir.setup(-5000, 5000, 0, FS)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -93,8 +158,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist_barrier(ctx)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -103,21 +167,12 @@ def main():
         step()
         ev[i][1].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist_barrier(ctx)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = dist_max(ctx, time.perf_counter() - t0)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
-    if rank == 0:
-        samples_per_step = C * T
-        total = samples_per_step * args.steps * world
-        value = total / elapsed / 1e6
-        achieved = ALG_BYTES_PER_SAMPLE * samples_per_step / (kern_ms * 1e-3) / 1e9
+    if ctx.rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -125,29 +180,9 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out = {
-            "metric": "complex IQ MSamples/s through CFastFIR+demod chain; achieved HBM GB/s vs peak",
-            "value": round(value, 2), "unit": "MSamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %d channels/GPU x 2^19 IQ samples, 16384-pt CFastFIR overlap-save "
-                                   "(8193 taps, hop 8192), shared -5..+5 kHz filter @62.5 kS/s" % C,
-                       "channels_per_gpu": C, "samples_per_channel": T, "fft_size": FFT_N,
-                       "parallelism": "channels sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "fastfir_os_kernel<14>", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * samples_per_step},
-        }
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        elif not args.no_cpu:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        cpu = cpu_baseline() if (ctx.world == 1 and not args.no_cpu) else None
+        print(json.dumps(result_line(ctx, C, T, args.steps, args.warmup, elapsed, kern_ms, traffic, cpu)), flush=True)
+    dist_finish(ctx)
 
 
 if __name__ == "__main__":
