@@ -160,6 +160,9 @@ void fastfir_os_kernel(FastFirArgs a)
                 x[e * R0 + HALF + n1] = nxt[e * HALF + n1];
                 carry[e * HALF + n1] = nxt[e * HALF + n1];
             }
+        // next block's new samples: issued as soon as nxt is free, in flight during the whole block
+        if (b + 1 < b1) load_half(r_in, (b + 1) * (L * 8), nxt);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < G; e++) {
             v2f y[R0];
@@ -175,7 +178,8 @@ void fastfir_os_kernel(FastFirArgs a)
 #pragma unroll
             for (int i = 0; i < R0; i++) x[e * R0 + i] = y[i];
         }
-        __syncthreads();                       // previous block's I3 reads are done
+        // no barrier here: pass F1 writes exactly the LDS cells this thread itself read in pass I3 of
+        // the previous block (same columns, all rows), so program order is enough
         {
             v4f wv[16];                        // (R0 rows) x (G/2 column pairs) = 16 float4
 #pragma unroll
@@ -277,8 +281,6 @@ void fastfir_os_kernel(FastFirArgs a)
 
         // ---------------- I3: conj twiddle, radix-R0 DIT inverse, store valid half ---------
         // next block's new samples: issued now, consumed at the top of the next iteration
-        if (b + 1 < b1) load_half(r_in, (b + 1) * (L * 8), nxt);
-        __builtin_amdgcn_sched_barrier(0);
         static_for<0, R0>([&](auto Rr) {
             constexpr int r = Rr.value, k0 = bitrev<R0>(r);
             const int base = lds_pad(1024 * k0 + G * t);

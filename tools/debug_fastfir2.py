@@ -7,7 +7,7 @@ np.set_printoptions(linewidth=200, precision=3, suppress=True)
 L_ = lib()
 L_.csdr__dbg_fastfir_stage.restype = C.c_int
 L_.csdr__dbg_fastfir_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-for n in (8192, 16384):
+for n in (16384,):
     L = n // 2
     b = ca.FastFirBatch(1, n)
     b.setup(-5000, 5000, 0, 62500.0)
