@@ -214,6 +214,7 @@ int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max
         for (i = f->bin_min; i <= f->bin_max; i++) {
             y = level(i);
             x = f->xlat[i];
+            if (x >= f->plot_w) continue;              // the reference writes OutBuf[MaxWidth] here (one past the end)
             if (x == xprev) {
                 if (y < ymax) { out[x] = y; ymax = y; }
             } else {
@@ -221,7 +222,7 @@ int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max
             }
         }
     } else {
-        for (x = 0; x < f->plot_w; x++) out[x] = level(f->xlat[x]);
+        for (x = 0; x < f->plot_w; x++) out[x] = level(f->xlat[x < n ? x : n - 1]);
     }
     return over ? 1 : 0;
 }

@@ -136,144 +136,367 @@ __device__ __forceinline__ float agc_real(PcAgc &a, float *dly, float *ring, flo
     return d * g;
 }
 
-// ---- second-order PLL step shared by SAM and FM (samdemod.cpp:83-97, fmdemod.cpp:166-184) ------
-// rotates x by sgn*phase, returns the rotated sample, advances phase/freq
-__device__ __forceinline__ void pll_step(double &phase, double &freq, double lo, double hi, double alpha,
-                                         double beta, float sgn, float xr, float xi, float &tr, float &ti,
-                                         float &err_out)
-{
-    // the reference wraps its fp64 phase once per call; wrap here every sample so that the fp32
-    // sincos sees a small argument (same value of sin/cos)
-    float s, c;
-    sincosf((float)phase, &s, &c);
-    s *= sgn;
-    tr = c * xr - s * xi;
-    ti = c * xi + s * xr;
-    const float err = -sgn * atan2f(ti, tr);
-    freq += beta * (double)err;
-    if (freq > hi) freq = hi;
-    else if (freq < lo) freq = lo;
-    phase += freq + alpha * (double)err;
-    if (phase > 3.14159265358979323846) phase -= kTwoPiD;
-    else if (phase < -3.14159265358979323846) phase += kTwoPiD;
-    err_out = err;
+// =====================================================================================================
+// One wave per channel.  Everything that does not depend on the previous output sample (log
+// magnitudes, sliding-window peak, gain law, delay line, arg(x), envelopes, FIR dot products) is
+// computed by the 64 lanes in parallel over a tile of samples staged in LDS; only the genuinely
+// recurrent scalars (S-meter and AGC averagers, PLL frequency/phase, DC blockers, squelch average,
+// biquad) are walked sample by sample by lane 0, with their transcendentals hoisted out:
+//   * the AGC peak  m_Peak  of agc.cpp:210-231 (compare, equality test, rescan) is exactly the
+//     maximum of the last WindowSamples log-magnitudes, so it is a sliding-window maximum (log-step
+//     doubling over [history | tile]);
+//   * the PLL error  -atan2(rot(x, phi))  of fmdemod.cpp:166-172 / samdemod.cpp:83-89 equals
+//     -wrap(arg(x) + sgn*phi), so arg(x) is taken for the whole tile up front and the loop carries
+//     a dozen fp64 operations per sample and no transcendental.
+// =====================================================================================================
+constexpr int PT = 1024;                 // tile length (samples)
+constexpr int PH = PC_AGC_RING;          // longest history (AGC delay / window)
+constexpr double kPiD = 3.14159265358979323846;
+
+struct PcLds {
+    float2 dl[PH + PT];                  // [last dly_n inputs | tile] : delay line, then AGC output in place
+    float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile], doubled in place
+    float pk[PT];                        // sliding peak, then gain
+    float w0[PT + PC_FIR_MAX];           // [FIR history | tile] work array (audio / envelope / I)
+    float w1[PT + PC_FIR_MAX];           // second work array (theta / Q)
+    float w2[PT];                        // third work array (S-meter dB, PLL phase)
+};
+
+__device__ __forceinline__ double wrap_pi(double a)
+{   // (-pi, pi], the range of atan2
+    if (a > kPiD) a -= kTwoPiD;
+    else if (a <= -kPiD) a += kTwoPiD;
+    return a;
 }
+
+// y[i] = sum_k h[k] * w[base + i - k], i = lane, lane+64, ...; w holds [ntaps-1 history | n samples]
+__device__ __forceinline__ void fir_tile(const float *h, int ntaps, const float *w, float *out, int n, int lane)
+{
+    for (int i = lane; i < n; i += 64) {
+        const float *p = w + (ntaps - 1) + i;
+        float acc = 0.f;
+        for (int k = 0; k < ntaps; k++) acc += h[k] * p[-k];
+        out[i] = acc;
+    }
+}
+// keep the last `hist` entries of [hist | n] in front for the next tile
+__device__ __forceinline__ void slide(float *w, int hist, int n, int lane)
+{
+    float keep[2] = {0.f, 0.f};
+    for (int j = 0; j < 2; j++) { const int i = lane + 64 * j; if (i < hist) keep[j] = w[n + i]; }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < 2; j++) { const int i = lane + 64 * j; if (i < hist) w[i] = keep[j]; }
+}
+
+#define PC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
 __global__ __launch_bounds__(64)
 void postchain_kernel(PcArgs a)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= a.channels) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+    PcLds &S = *reinterpret_cast<PcLds *>(pc_smem);
+    const int ch = blockIdx.x, lane = threadIdx.x;
     PcChannel &C = a.chan[ch];
-    float *dly = a.agc_dly + (long)ch * PC_AGC_RING * 2;
-    float *ring = a.agc_mag + (long)ch * PC_AGC_RING;
-    const float *in = a.in + 2 * (long)ch * a.in_stride;
+    float *g_dly = a.agc_dly + (long)ch * PC_AGC_RING * 2;      // linear: last dly_n inputs, oldest first
+    float *g_mag = a.agc_mag + (long)ch * PC_AGC_RING;          // linear: last win_n-1 magnitudes
+    const float2 *in = reinterpret_cast<const float2 *>(a.in) + (long)ch * a.in_stride;
     const bool stereo = a.flags & PC_STEREO;
-    float *out = a.out + (stereo ? 2 : 1) * (long)(a.out_rows ? a.out_rows[ch] : ch) * a.out_stride;
-    float *scr = a.scratch + (long)ch * a.scratch_stride;
+    const long orow = (long)(a.out_rows ? a.out_rows[ch] : ch) * a.out_stride;
+    float *outm = a.out ? a.out + orow : nullptr;                               // mono
+    float2 *outs = a.out ? reinterpret_cast<float2 *>(a.out) + orow : nullptr;  // stereo / complex
     const int mode = (a.flags & PC_DO_DEMOD) ? C.mode : PC_MODE_NONE;
+    const bool do_sm = a.flags & PC_DO_SMETER, do_agc = a.flags & PC_DO_AGC, agc_real = a.flags & PC_AGC_REAL;
+    const bool cpx_out = stereo || mode == PC_MODE_NONE;
 
-    // scalar state into registers for the duration of the call
+    // scalar state (only lane 0's copy is meaningful and written back)
     PcSMeter sm = C.sm;
     PcAgc agc = C.agc;
+    const int D = agc.dly_n > 0 ? agc.dly_n : 1, W1 = agc.win_n > 0 ? agc.win_n - 1 : 0;
+    double am_z1 = C.am.z1;
+    double sam_z1 = C.sam.z1, sam_y1 = C.sam.y1, sam_ph = C.sam.phase, sam_fr = C.sam.freq;
+    double fm_ph = C.fm.phase, fm_fr = C.fm.freq, fm_dc = C.fm.err_dc, fm_sq = C.fm.sq_ave;
+    int fm_squelched = C.fm.squelched;
+    PcIir lp = C.fm.lp;
+
+    // histories -> LDS
+    if (do_agc && agc.on) {
+        for (int i = lane; i < D; i += 64) S.dl[i] = make_float2(g_dly[2 * i], g_dly[2 * i + 1]);
+        for (int i = lane; i < W1; i += 64) S.mg[i] = g_mag[i];
+    }
+    const PcFir *fir = mode == PC_MODE_AM ? &C.am.fir : mode == PC_MODE_SAM ? &C.sam.fir : mode == PC_MODE_FM ? &C.fm.hp : nullptr;
+    const int nt = fir ? fir->ntaps : 1;
+    if (fir) {
+        for (int i = lane; i < nt - 1; i += 64) { S.w0[i] = (mode == PC_MODE_FM || mode == PC_MODE_AM && !stereo) ? fir->zreal[i] : fir->zr[i]; S.w1[i] = fir->zi[i]; }
+    }
+    PC_SYNC();
 
     for (int b = 0; b < a.nbursts; b++) {
-        const float *x = in + 2 * (long)b * a.burst;
-        float *y = out + (stereo ? 2 : 1) * (long)b * a.burst;
-        const int n = a.burst;
-        if (mode == PC_MODE_FM) {
-            PcFm &F = C.fm;
-            double phase = F.phase, freq = F.freq, dc = F.err_dc;
-            for (int i = 0; i < n; i++) {
-                float re = x[2 * i], im = x[2 * i + 1];
-                if (a.flags & PC_DO_SMETER) smeter_step(sm, re, im);
-                if (a.flags & PC_DO_AGC) agc_cpx(agc, dly, ring, re, im);
-                float tr, ti, err;
-                pll_step(phase, freq, F.lo, F.hi, F.alpha, F.beta, 1.0f, re, im, tr, ti, err);
-                dc = (1.0 - F.dc_alpha) * dc + F.dc_alpha * freq;
-                scr[i] = (float)((freq - dc) * F.out_gain);
-            }
-            F.phase = phase; F.freq = freq; F.err_dc = dc;
-            // noise squelch: HP FIR -> |.| EMA over the burst, ONE hysteresis decision (:113-152)
-            if (n <= 16384) {
-                double ave = F.sq_ave;
-                for (int i = 0; i < n; i++) {
-                    const float hp = fir_real(F.hp, scr[i]);
-                    ave = (1.0 - F.sq_alpha) * ave + F.sq_alpha * (double)fabsf(hp);
+        for (int t0 = 0; t0 < a.burst; t0 += PT) {
+            const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
+            const long gi = (long)b * a.burst + t0;
+            float2 *x = S.dl + ((do_agc && agc.on) ? D : 0);           // tile samples (AGC: behind the delay history)
+            for (int i = lane; i < n; i += 64) x[i] = in[gi + i];
+            PC_SYNC();
+            // ---------------- S-meter (smeter.cpp:62-93) ----------------
+            if (do_sm) {
+                for (int i = lane; i < n; i += 64) {
+                    const float pw = (x[i].x * x[i].x + x[i].y * x[i].y) * (1.0f / (32767.0f * 32767.0f));
+                    S.w2[i] = pw > 0.f ? 10.0f * log10f(pw) : -500.0f;
                 }
-                F.sq_ave = ave;
-                if (0 == F.sq_thresh) F.squelched = 1;
-                else if (F.squelched) { if (ave < (F.sq_thresh - 100.0)) F.squelched = 0; }
-                else { if (ave >= (F.sq_thresh + 100.0)) F.squelched = 1; }
-                if (F.squelched) for (int i = 0; i < n; i++) scr[i] = 0.f;
-                else for (int i = 0; i < n; i++) scr[i] = iir_a(F.lp, scr[i]);
+                PC_SYNC();
+                if (lane == 0) {
+                    for (int i = 0; i < n; i++) {
+                        const double mag = S.w2[i];
+                        sm.att_ave = (1.0 - sm.att_a) * sm.att_ave + sm.att_a * mag;
+                        sm.dec_ave = (1.0 - sm.dec_a) * sm.dec_ave + sm.dec_a * mag;
+                        if (sm.att_ave > sm.dec_ave) { sm.ave_mag = sm.att_ave; sm.dec_ave = sm.att_ave; }
+                        else sm.ave_mag = sm.dec_ave;
+                        if (mag > sm.peak_mag) sm.peak_mag = mag;
+                    }
+                }
             }
-            if (stereo) for (int i = 0; i < n; i++) { y[2 * i] = scr[i]; y[2 * i + 1] = scr[i]; }
-            else for (int i = 0; i < n; i++) y[i] = scr[i];
-        } else if (mode == PC_MODE_SAM) {
-            PcSam &S = C.sam;
-            double phase = S.phase, freq = S.freq, z1 = S.z1, y1 = S.y1;
-            const float sgn = stereo ? 1.0f : -1.0f;       // mono: e^{-j phi}, stereo: e^{+j phi}
-            for (int i = 0; i < n; i++) {
-                float re = x[2 * i], im = x[2 * i + 1];
-                if (a.flags & PC_DO_SMETER) smeter_step(sm, re, im);
-                if (a.flags & PC_DO_AGC) agc_cpx(agc, dly, ring, re, im);
-                float tr, ti, err;
-                pll_step(phase, freq, S.lo, S.hi, S.alpha, S.beta, sgn, re, im, tr, ti, err);
-                const double z0 = (double)tr + z1 * 0.99;
-                if (stereo) {
-                    const double y0 = (double)ti + y1 * 0.99;
-                    float orr = (float)(z0 - z1), oi = (float)(y0 - y1);
-                    y1 = y0;
-                    fir_cpx(S.fir, orr, oi);
-                    y[2 * i] = orr + oi;                    // lower sideband -> left
-                    y[2 * i + 1] = orr - oi;                // upper sideband -> right
+            // ---------------- AGC (agc.cpp:174-296 / 301-401) ----------------
+            if (do_agc) {
+                if (!agc.on) {
+                    const float g = (float)agc.manual_gain;
+                    for (int i = lane; i < n; i += 64) { x[i].x *= g; x[i].y *= g; }
                 } else {
-                    y[i] = (float)(z0 - z1);
+                    float *mg = S.mg + W1;
+                    for (int i = lane; i < n; i += 64) {
+                        float m = fabsf(x[i].x);
+                        if (!agc_real) { const float mi = fabsf(x[i].y); if (mi > m) m = mi; }
+                        mg[i] = log10f(m + 3.2767e-4f) - 4.51543987f;
+                    }
+                    PC_SYNC();
+                    // sliding maximum over the last win_n magnitudes: log-step doubling on a copy
+                    // (pk[i] = max mg[i-2^k+1 .. i]), then two overlapping windows of 2^k
+                    const int Wn = W1 + 1;
+                    int k = 0;
+                    while ((2 << k) <= Wn) k++;                       // 2^k <= Wn < 2^(k+1)
+                    float *cur = S.mg;                               // [W1 history | n], doubled in place
+                    const int len = W1 + n;
+                    // the last W1 entries are the next tile's history: save them first
+                    float keepm[32];
+#pragma unroll
+                    for (int j = 0; j < 32; j++) { const int i = lane + 64 * j; keepm[j] = (i < W1) ? cur[n + i] : 0.f; }
+                    PC_SYNC();
+                    for (int lev = 0; lev < k; lev++) {
+                        const int sft = 1 << lev;
+                        float nv[48];
+#pragma unroll
+                        for (int j = 0; j < 48; j++) {
+                            const int i = lane + 64 * j;
+                            float v = (i < len) ? cur[i] : -16.f;
+                            if (i < len && i >= sft) v = fmaxf(v, cur[i - sft]);
+                            nv[j] = v;
+                        }
+                        PC_SYNC();
+#pragma unroll
+                        for (int j = 0; j < 48; j++) { const int i = lane + 64 * j; if (i < len) cur[i] = nv[j]; }
+                        PC_SYNC();
+                    }
+                    const int span = 1 << k;
+                    for (int i = lane; i < n; i += 64) {
+                        const int e = W1 + i;                         // window = [e-Wn+1, e]
+                        float v = cur[e];
+                        const int e2 = e - Wn + span;                 // second window of length span ending at e2
+                        if (e2 >= 0) v = fmaxf(v, cur[e2]);
+                        S.pk[i] = v;
+                    }
+                    PC_SYNC();
+                    // restore the magnitude history for the next tile
+#pragma unroll
+                    for (int j = 0; j < 32; j++) { const int i = lane + 64 * j; if (i < W1) cur[i] = keepm[j]; }
+                    // attack / decay averagers: sequential (lane 0), output = log gain argument
+                    if (lane == 0) {
+                        for (int i = 0; i < n; i++) {
+                            const double pk = S.pk[i];
+                            if (pk > agc.attack_ave) agc.attack_ave = (1.0 - agc.att_rise) * agc.attack_ave + agc.att_rise * pk;
+                            else                     agc.attack_ave = (1.0 - agc.att_fall) * agc.attack_ave + agc.att_fall * pk;
+                            if (agc.hang) {
+                                if (pk > agc.decay_ave) { agc.decay_ave = (1.0 - agc.dec_rise) * agc.decay_ave + agc.dec_rise * pk; agc.hang_timer = 0; }
+                                else if (agc.hang_timer < agc.hang_time) agc.hang_timer++;
+                                else agc.decay_ave = (1.0 - agc.dec_fall) * agc.decay_ave + agc.dec_fall * pk;
+                            } else {
+                                if (pk > agc.decay_ave) agc.decay_ave = (1.0 - agc.dec_rise) * agc.decay_ave + agc.dec_rise * pk;
+                                else                    agc.decay_ave = (1.0 - agc.dec_fall) * agc.decay_ave + agc.dec_fall * pk;
+                            }
+                            const double m = agc.attack_ave > agc.decay_ave ? agc.attack_ave : agc.decay_ave;
+                            S.pk[i] = (m <= agc.knee) ? -1.0f : (float)(m * (agc.gain_slope - 1.0));   // -1: fixed gain marker
+                        }
+                    }
+                    PC_SYNC();
+                    // gain law + delay line: out[i] = in[i - D] * gain[i]; S.dl = [D old | n new]
+                    float2 outv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int i = lane + 64 * j;
+                        if (i < n) {
+                            const float e = S.pk[i];
+                            const float g = (e == -1.0f) ? (float)agc.fixed_gain : 0.7f * exp10f(e);
+                            const float2 d = S.dl[i];
+                            outv[j] = make_float2(d.x * g, d.y * g);
+                        }
+                    }
+                    float2 keepd[32];
+#pragma unroll
+                    for (int j = 0; j < 32; j++) { const int i = lane + 64 * j; if (i < D) keepd[j] = S.dl[n + i]; }
+                    PC_SYNC();
+#pragma unroll
+                    for (int j = 0; j < 32; j++) { const int i = lane + 64 * j; if (i < D) S.dl[i] = keepd[j]; }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < n) x[i] = outv[j]; }
+                    PC_SYNC();
                 }
-                z1 = z0;
             }
-            S.phase = phase; S.freq = freq; S.z1 = z1; S.y1 = y1;
-        } else if (mode == PC_MODE_AM) {
-            PcAm &A = C.am;
-            double z1 = A.z1;
-            for (int i = 0; i < n; i++) {
-                float re = x[2 * i], im = x[2 * i + 1];
-                if (a.flags & PC_DO_SMETER) smeter_step(sm, re, im);
-                if (a.flags & PC_DO_AGC) agc_cpx(agc, dly, ring, re, im);
-                const double mag = (double)sqrtf(re * re + im * im);
-                const double z0 = mag + z1 * 0.99;
-                float v = (float)(z0 - z1);
-                z1 = z0;
-                if (stereo) {
-                    float vr = v, vi = v;
-                    fir_cpx(A.fir, vr, vi);
-                    y[2 * i] = vr; y[2 * i + 1] = vi;
-                } else {
-                    y[i] = fir_real(A.fir, v);
+            // x[0..n) now holds the AGC output (or the input); x = S.dl + D
+            // ---------------- demodulators ----------------
+            if (mode == PC_MODE_NONE || mode >= PC_MODE_USB) {
+                if (a.out) {
+                    for (int i = lane; i < n; i += 64) {
+                        if (cpx_out) outs[gi + i] = x[i];
+                        else outm[gi + i] = x[i].x;                       // ssbdemod.cpp:48-53
+                    }
+                }
+            } else if (mode == PC_MODE_AM) {
+                float *w = S.w0 + (nt - 1);
+                for (int i = lane; i < n; i += 64) w[i] = sqrtf(x[i].x * x[i].x + x[i].y * x[i].y);
+                PC_SYNC();
+                if (lane == 0) {                                          // DC block, amdemod.cpp:70-80
+                    for (int i = 0; i < n; i++) { const double z0 = (double)w[i] + am_z1 * 0.99; w[i] = (float)(z0 - am_z1); am_z1 = z0; }
+                }
+                PC_SYNC();
+                const float *h = stereo ? C.am.fir.icoef : C.am.fir.coef, *hq = C.am.fir.qcoef;
+                for (int i = lane; i < n; i += 64) {
+                    const float *p = w + i;
+                    float acc = 0.f, acq = 0.f;
+                    for (int k = 0; k < nt; k++) { acc += h[k] * p[-k]; if (stereo) acq += hq[k] * p[-k]; }
+                    if (stereo) outs[gi + i] = make_float2(acc, acq); else outm[gi + i] = acc;
+                }
+                PC_SYNC();
+                slide(S.w0, nt - 1, n, lane);
+                PC_SYNC();
+            } else {
+                // PLL modes: theta = arg(x), r = |x| for the whole tile
+                float *th = S.w1 + (nt - 1), *au = S.w0 + (nt - 1);
+                for (int i = lane; i < n; i += 64) th[i] = atan2f(x[i].y, x[i].x);
+                PC_SYNC();
+                if (mode == PC_MODE_FM) {
+                    const PcFm &F = C.fm;
+                    if (lane == 0) {
+                        for (int i = 0; i < n; i++) {                     // fmdemod.cpp:166-186
+                            const double err = -wrap_pi((double)th[i] + fm_ph);
+                            fm_fr += F.beta * err;
+                            if (fm_fr > F.hi) fm_fr = F.hi; else if (fm_fr < F.lo) fm_fr = F.lo;
+                            fm_ph = wrap_pi(fm_ph + fm_fr + F.alpha * err);
+                            fm_dc = (1.0 - F.dc_alpha) * fm_dc + F.dc_alpha * fm_fr;
+                            au[i] = (float)((fm_fr - fm_dc) * F.out_gain);
+                        }
+                    }
+                    PC_SYNC();
+                    // raw audio to the output row; squelch is decided at the end of the burst
+                    for (int i = lane; i < n; i += 64) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
+                    if (a.burst <= 16384) {                               // MAX_SQBUF_SIZE
+                        fir_tile(F.hp.coef, nt, S.w0, S.w2, n, lane);
+                        PC_SYNC();
+                        if (lane == 0)
+                            for (int i = 0; i < n; i++) fm_sq = (1.0 - F.sq_alpha) * fm_sq + F.sq_alpha * (double)fabsf(S.w2[i]);
+                    }
+                    PC_SYNC();
+                    slide(S.w0, nt - 1, n, lane);
+                    PC_SYNC();
+                } else {                                                  // SAM, samdemod.cpp:78-158
+                    const PcSam &M = C.sam;
+                    const double sgn = stereo ? 1.0 : -1.0;
+                    if (lane == 0) {
+                        for (int i = 0; i < n; i++) {
+                            S.w2[i] = (float)sam_ph;                      // phase used for this sample
+                            const double err = -sgn * wrap_pi((double)th[i] + sgn * sam_ph);
+                            sam_fr += M.beta * err;
+                            if (sam_fr > M.hi) sam_fr = M.hi; else if (sam_fr < M.lo) sam_fr = M.lo;
+                            sam_ph = wrap_pi(sam_ph + sam_fr + M.alpha * err);
+                        }
+                    }
+                    PC_SYNC();
+                    // rotated sample tr + j ti = |x| e^{j(theta + sgn phi)}
+                    for (int i = lane; i < n; i += 64) {
+                        const float r = sqrtf(x[i].x * x[i].x + x[i].y * x[i].y);
+                        float s, c;
+                        sincosf(th[i] + (float)sgn * S.w2[i], &s, &c);
+                        au[i] = r * c;                                    // tr
+                        th[i] = r * s;                                    // ti
+                    }
+                    PC_SYNC();
+                    if (lane == 0) {                                      // DC blocks
+                        for (int i = 0; i < n; i++) {
+                            const double z0 = (double)au[i] + sam_z1 * 0.99; au[i] = (float)(z0 - sam_z1); sam_z1 = z0;
+                            if (stereo) { const double y0 = (double)th[i] + sam_y1 * 0.99; th[i] = (float)(y0 - sam_y1); sam_y1 = y0; }
+                        }
+                    }
+                    PC_SYNC();
+                    if (!stereo) {
+                        for (int i = lane; i < n; i += 64) outm[gi + i] = au[i];
+                    } else {
+                        const float *hi = M.fir.icoef, *hq = M.fir.qcoef;
+                        for (int i = lane; i < n; i += 64) {
+                            float ar = 0.f, ai = 0.f;
+                            for (int k = 0; k < nt; k++) { ar += hi[k] * au[i - k]; ai += hq[k] * th[i - k]; }
+                            outs[gi + i] = make_float2(ar + ai, ar - ai);    // lower sideband left, upper right
+                        }
+                        PC_SYNC();
+                        slide(S.w0, nt - 1, n, lane);
+                        slide(S.w1, nt - 1, n, lane);
+                    }
+                    PC_SYNC();
                 }
             }
-            A.z1 = z1;
-        } else {
-            // SSB / CW (real part or copy), or no demodulator (AGC / S-meter only)
-            const bool demod = mode >= PC_MODE_USB;
-            for (int i = 0; i < n; i++) {
-                float re = x[2 * i], im = x[2 * i + 1];
-                if (a.flags & PC_DO_SMETER) smeter_step(sm, re, im);
-                if (a.flags & PC_DO_AGC) {
-                    if (a.flags & PC_AGC_REAL) re = agc_real(agc, dly, ring, re);
-                    else agc_cpx(agc, dly, ring, re, im);
-                }
-                if (stereo || !demod) {
-                    if (a.out) { y[2 * i] = re; y[2 * i + 1] = im; }
-                } else {
-                    y[i] = re;
+        }
+        // ---------------- end of burst: FM squelch decision (fmdemod.cpp:128-151) ----------------
+        if (mode == PC_MODE_FM && a.burst <= 16384) {
+            const PcFm &F = C.fm;
+            if (0 == F.sq_thresh) fm_squelched = 1;
+            else if (fm_squelched) { if (fm_sq < (F.sq_thresh - 100.0)) fm_squelched = 0; }
+            else { if (fm_sq >= (F.sq_thresh + 100.0)) fm_squelched = 1; }
+            fm_squelched = __shfl(fm_squelched, 0);
+            const long g0 = (long)b * a.burst;
+            PC_SYNC();
+            for (int t0 = 0; t0 < a.burst; t0 += PT) {
+                const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
+                if (fm_squelched) {
+                    for (int i = lane; i < n; i += 64) { if (stereo) outs[g0 + t0 + i] = make_float2(0.f, 0.f); else outm[g0 + t0 + i] = 0.f; }
+                } else {                                                  // low-pass biquad over the burst
+                    for (int i = lane; i < n; i += 64) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i];
+                    PC_SYNC();
+                    if (lane == 0) for (int i = 0; i < n; i++) S.w2[i] = iir_a(lp, S.w2[i]);
+                    PC_SYNC();
+                    for (int i = lane; i < n; i += 64) { const float y = S.w2[i]; if (stereo) outs[g0 + t0 + i] = make_float2(y, y); else outm[g0 + t0 + i] = y; }
+                    PC_SYNC();
                 }
             }
         }
     }
-    C.sm = sm;
-    C.agc = agc;
+
+    // ---------------- write the state back ----------------
+    PC_SYNC();
+    if (do_agc && agc.on) {
+        for (int i = lane; i < D; i += 64) { g_dly[2 * i] = S.dl[i].x; g_dly[2 * i + 1] = S.dl[i].y; }
+        for (int i = lane; i < W1; i += 64) g_mag[i] = S.mg[i];
+    }
+    if (fir) {
+        PcFir *fw = const_cast<PcFir *>(fir);
+        for (int i = lane; i < nt - 1; i += 64) {
+            if (mode == PC_MODE_FM || (mode == PC_MODE_AM && !stereo)) fw->zreal[i] = S.w0[i];
+            else { fw->zr[i] = S.w0[i]; fw->zi[i] = mode == PC_MODE_AM ? S.w0[i] : S.w1[i]; }
+        }
+    }
+    if (lane == 0) {
+        C.sm = sm; C.agc = agc;
+        C.am.z1 = am_z1;
+        C.sam.z1 = sam_z1; C.sam.y1 = sam_y1; C.sam.phase = sam_ph; C.sam.freq = sam_fr;
+        C.fm.phase = fm_ph; C.fm.freq = fm_fr; C.fm.err_dc = fm_dc; C.fm.sq_ave = fm_sq; C.fm.squelched = fm_squelched;
+        C.fm.lp = lp;
+    }
 }
 
 // stand-alone CFir / CIir objects (one lane each): op 0 FIR real, 1 FIR complex, 2 IIR real, 3 IIR complex
@@ -303,7 +526,14 @@ hipError_t filter_leaf_launch(PcFir *fir, PcIir *iir, const float *in, float *ou
 
 hipError_t postchain_launch(const PcArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(postchain_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, stream, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&postchain_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PcLds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(postchain_kernel, dim3(a.channels), dim3(64), sizeof(PcLds), stream, a);
     return hipGetLastError();
 }
 

@@ -171,9 +171,9 @@ class CFft(_Handle):
         return lib().orc_cfft_put_display(self.h, len(a), _ptr(a))
 
     def GetScreenIntegerFFTData(self, max_h, max_w, max_db, min_db, start_hz, stop_hz):
-        out = np.zeros(max(max_w, 1), dtype=np.int32)
+        out = np.zeros(max(max_w, 1) + 1, dtype=np.int32)     # the reference's loop writes OutBuf[MaxWidth] too
         ov = lib().orc_cfft_get_screen(self.h, max_h, max_w, max_db, min_db, start_hz, stop_hz, _ptr(out))
-        return bool(ov), out
+        return bool(ov), out[:max(max_w, 1)].copy()
 
     def FwdFFT(self, x):
         a = _c128(x).copy(); lib().orc_cfft_fwd(self.h, _ptr(a)); return a

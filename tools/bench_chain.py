@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the bench.py contract): the other kernels of the path on BASELINE
+config C4's per-GPU share -- 256 channels x 2^21 samples at 2 MSPS.
+  K2  downconvert alone (FM chain 11,11,15,19,31 -> 62.5 kS/s): input MS/s, algorithmic GB/s
+  chain  full CDemodulator batch (mixed AM/FM/USB), FastFIR 2048: input MS/s
+Prints one JSON line."""
+import json, sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cutesdr_amd as ca
+
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+T = 1 << 21
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(1)
+x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * 3276.7
+y = torch.empty((C, T // 16, 2), device=dev, dtype=torch.float32)
+stream = torch.cuda.current_stream().cuda_stream
+out = {}
+
+dc = ca.DownConvertBatch(C)
+dc.set_data_rate(2e6, 15000.0)
+for c in range(C):
+    dc.set_frequency(-100e3 - 500.0 * c, channel=c)
+def k2():
+    dc.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T // 16, stream)
+for _ in range(2): k2()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): k2()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+out["k2_ms"] = round(ms, 3)
+out["k2_input_MSps"] = round(C * T / ms / 1e3, 1)
+out["k2_alg_GBps"] = round(C * T * (8 + 8 / 32) / ms / 1e6, 1)
+
+def info(**kw):
+    base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
+                AgcManualGain=30, AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+    base.update(kw); return ca.DemodInfo(**base)
+modes = [(0, dict(HiCutmin=500, HiCutmax=10000, LowCutmax=-500, LowCutmin=-10000)), (2, dict()),
+         (3, dict(HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200, LowCutmin=0, Symetric=0))]
+b = ca.DemodBatch(C, 2048)
+b.set_input_rate(2e6)
+for c in range(C):
+    m, kw = modes[c % 3]
+    b.set_demod(c, m, info(**kw))
+b.commit()
+for c in range(C):
+    b.set_freq(c, -100e3 - 500.0 * c)
+aud = torch.empty((C, T // 16 + 4096), device=dev, dtype=torch.float32)
+def chain():
+    b.process_ptr(x.data_ptr(), T, T, aud.data_ptr(), T // 16 + 4096, stream)
+chain(); torch.cuda.synchronize()
+e0.record()
+for _ in range(3): chain()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+out["chain_ms"] = round(ms, 3)
+out["chain_input_MSps"] = round(C * T / ms / 1e3, 1)
+out["chain_alg_GBps"] = round(C * T * (8 + 4 / 32) / ms / 1e6, 1)
+out["channels"] = C
+print(json.dumps(out))
