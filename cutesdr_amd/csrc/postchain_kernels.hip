@@ -149,6 +149,7 @@ __device__ __forceinline__ float agc_real(PcAgc &a, float *dly, float *ring, flo
 //     -wrap(arg(x) + sgn*phi), so arg(x) is taken for the whole tile up front and the loop carries
 //     a dozen fp64 operations per sample and no transcendental.
 // =====================================================================================================
+constexpr int PC_NCHUNK = (PC_AGC_RING + 1024) / 16, PC_RLEVELS = 8;
 constexpr int PT = 1024;                 // tile length (samples)
 constexpr int PH = PC_AGC_RING;          // longest history (AGC delay / window)
 constexpr double kPiD = 3.14159265358979323846;
@@ -156,10 +157,12 @@ constexpr double kPiD = 3.14159265358979323846;
 struct PcLds {
     float2 dl[PH + PT];                  // [last dly_n inputs | tile] : delay line, then AGC output in place
     float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile], doubled in place
-    float pk[PT];                        // sliding peak, then gain
-    float w0[PT + PC_FIR_MAX];           // [FIR history | tile] work array (audio / envelope / I)
-    float w1[PT + PC_FIR_MAX];           // second work array (theta / Q)
-    float w2[PT];                        // third work array (S-meter dB, PLL phase)
+    float pk[PT + 16];                    // sliding peak, then gain
+    float w0[PT + PC_FIR_MAX + 17];           // [FIR history | tile] work array (audio / envelope / I)
+    float w1[PT + PC_FIR_MAX + 17];           // second work array (theta / Q)
+    float h0[PC_FIR_MAX + 5], h1[PC_FIR_MAX + 5];   // FIR taps of the active demodulator
+    float w2[PT + 16];
+    float rt[PC_RLEVELS][PC_NCHUNK];     // log table over the chunk maxima of the sliding peak                    // third work array (S-meter dB, PLL phase)
 };
 
 __device__ __forceinline__ double wrap_pi(double a)
@@ -169,16 +172,24 @@ __device__ __forceinline__ double wrap_pi(double a)
     return a;
 }
 
-// y[i] = sum_k h[k] * w[base + i - k], i = lane, lane+64, ...; w holds [ntaps-1 history | n samples]
-__device__ __forceinline__ void fir_tile(const float *h, int ntaps, const float *w, float *out, int n, int lane)
+// acc[j] = sum_k h[k] * x[i_j - k] for this lane's outputs i_j = lane + 64 j; x points at the tile
+// (ntaps-1 history samples sit in front of it), h and x in LDS.  Each tap is fetched once per lane
+// and reused for the 16 outputs.
+__device__ __forceinline__ void fir16(const float *h, int ntaps, const float *x, int lane, float (&acc)[16])
 {
-    for (int i = lane; i < n; i += 64) {
-        const float *p = w + (ntaps - 1) + i;
-        float acc = 0.f;
-        for (int k = 0; k < ntaps; k++) acc += h[k] * p[-k];
-        out[i] = acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    const float *p = x + lane;
+#pragma unroll 3
+    for (int k = 0; k < ntaps; k++) {
+        const float hk = h[k];
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] += hk * p[64 * j - k];
     }
 }
+__device__ __forceinline__ void vreg(double &x) { asm volatile("" : "+v"(x)); }    // keep a loop constant in VGPRs
+__device__ __forceinline__ double wrap_turn(double a) { return a - rint(a); }    // [-0.5, 0.5]
+constexpr double kInvTwoPiD = 1.0 / (2.0 * 3.14159265358979323846);
 // keep the last `hist` entries of [hist | n] in front for the next tile
 __device__ __forceinline__ void slide(float *w, int hist, int n, int lane)
 {
@@ -188,8 +199,95 @@ __device__ __forceinline__ void slide(float *w, int hist, int n, int lane)
     for (int j = 0; j < 2; j++) { const int i = lane + 64 * j; if (i < hist) w[i] = keep[j]; }
 }
 
+// Lane 0 walks src[0..n) in order, f(value, index); the next eight values are fetched from LDS
+// while the current eight go through the recurrence, so no LDS latency sits on the dependent chain.
+// src must be readable up to n+15.
+template <class F>
+__device__ __forceinline__ void seq_walk(const float *src, int n, F f)
+{
+    float cur[8], nxt[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) cur[j] = src[j];
+    for (int i0 = 0; i0 < n; i0 += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) nxt[j] = src[i0 + 8 + j];
+        if (i0 + 8 <= n) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) f(cur[j], i0 + j);
+        } else {
+            for (int j = 0; j < 8; j++) if (i0 + j < n) f(cur[j], i0 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+    }
+}
+
 #define PC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+// pk[i] = max(E[i .. i+W1]), i < n, for E = S.mg[0 .. W1+n).  Chunks of 16: per-chunk prefix and
+// suffix maxima (registers), a log table over the <= 192 chunk maxima for the chunks strictly
+// inside a window, then window = suffix(first chunk) | inner chunks | prefix(last chunk).
+// Only prefix values at tile positions (-> S.pk) and suffix values at i < n (-> S.w2) are kept.
+constexpr float kNegBig = -1.0e30f;
+__device__ __forceinline__ void sliding_max(PcLds &S, int W1, int n, int lane)
+{
+    const int len = W1 + n;
+    if (W1 < 16) {                                      // short windows: direct
+        for (int i = lane; i < n; i += 64) {
+            float v = S.mg[i];
+            for (int k = 1; k <= W1; k++) v = fmaxf(v, S.mg[i + k]);
+            S.pk[i] = v;
+        }
+        PC_SYNC();
+        return;
+    }
+    const int nc = (len + 15) >> 4;
+    for (int c = lane; c < PC_NCHUNK; c += 64) {
+        float e[16];
+        const float4 *src = reinterpret_cast<const float4 *>(S.mg + 16 * c);
+        if (c < nc) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const float4 v = src[q]; e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int j = 0; j < 16; j++) if (16 * c + j >= len) e[j] = kNegBig;
+            float pre[16], suf[16];
+            pre[0] = e[0]; suf[15] = e[15];
+#pragma unroll
+            for (int j = 1; j < 16; j++) { pre[j] = fmaxf(pre[j - 1], e[j]); suf[15 - j] = fmaxf(suf[16 - j], e[15 - j]); }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int idx = 16 * c + j;
+                const int ip = idx - W1;                                  // prefix wanted at tile positions
+                S.pk[(ip >= 0 && ip < n) ? ip : PT + 15] = pre[j];
+                S.w2[idx < n ? idx : PT + 15] = suf[j];
+            }
+            S.rt[0][c] = pre[15];
+        } else {
+            S.rt[0][c] = kNegBig;
+        }
+    }
+    PC_SYNC();
+    for (int l = 1; l < PC_RLEVELS; l++) {
+        const int h = 1 << (l - 1);
+        for (int c = lane; c < PC_NCHUNK; c += 64) {
+            const float v0 = S.rt[l - 1][c];
+            const float v1 = (c + h < PC_NCHUNK) ? S.rt[l - 1][c + h] : kNegBig;
+            S.rt[l][c] = fmaxf(v0, v1);
+        }
+        PC_SYNC();
+    }
+    for (int i = lane; i < n; i += 64) {
+        const int ci = i >> 4, ce = (i + W1) >> 4, cnt = ce - ci - 1;     // W1 >= 16: ce > ci
+        float v = fmaxf(S.w2[i], S.pk[i]);
+        if (cnt > 0) {
+            const int l = 31 - __clz(cnt);
+            v = fmaxf(v, fmaxf(S.rt[l][ci + 1], S.rt[l][ce - (1 << l)]));
+        }
+        S.pk[i] = v;
+    }
+    PC_SYNC();
+}
 
 __global__ __launch_bounds__(64)
 void postchain_kernel(PcArgs a)
@@ -227,12 +325,23 @@ void postchain_kernel(PcArgs a)
     const PcFir *fir = mode == PC_MODE_AM ? &C.am.fir : mode == PC_MODE_SAM ? &C.sam.fir : mode == PC_MODE_FM ? &C.fm.hp : nullptr;
     const int nt = fir ? fir->ntaps : 1;
     if (fir) {
+        for (int i = lane; i < nt; i += 64) {
+            S.h0[i] = (mode == PC_MODE_FM || !stereo) ? fir->coef[i] : fir->icoef[i];
+            S.h1[i] = fir->qcoef[i];
+        }
         for (int i = lane; i < nt - 1; i += 64) { S.w0[i] = (mode == PC_MODE_FM || mode == PC_MODE_AM && !stereo) ? fir->zreal[i] : fir->zr[i]; S.w1[i] = fir->zi[i]; }
     }
     PC_SYNC();
 
+#ifdef PC_PROFILE
+    unsigned long long tk[10] = {0}, tlast = __builtin_readcyclecounter();
+#define PC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tk[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define PC_TICK(k)
+#endif
     for (int b = 0; b < a.nbursts; b++) {
         for (int t0 = 0; t0 < a.burst; t0 += PT) {
+            PC_TICK(7);
             const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
             const long gi = (long)b * a.burst + t0;
             float2 *x = S.dl + ((do_agc && agc.on) ? D : 0);           // tile samples (AGC: behind the delay history)
@@ -246,16 +355,19 @@ void postchain_kernel(PcArgs a)
                 }
                 PC_SYNC();
                 if (lane == 0) {
-                    for (int i = 0; i < n; i++) {
-                        const double mag = S.w2[i];
-                        sm.att_ave = (1.0 - sm.att_a) * sm.att_ave + sm.att_a * mag;
-                        sm.dec_ave = (1.0 - sm.dec_a) * sm.dec_ave + sm.dec_a * mag;
-                        if (sm.att_ave > sm.dec_ave) { sm.ave_mag = sm.att_ave; sm.dec_ave = sm.att_ave; }
-                        else sm.ave_mag = sm.dec_ave;
-                        if (mag > sm.peak_mag) sm.peak_mag = mag;
-                    }
+                    double att = sm.att_ave, dec = sm.dec_ave, pkm = sm.peak_mag;
+                    const double aa = sm.att_a, da = sm.dec_a, ia = 1.0 - sm.att_a, id = 1.0 - sm.dec_a;
+                    seq_walk(S.w2, n, [&](float v, int) {
+                        const double mag = v;
+                        att = ia * att + aa * mag;
+                        dec = id * dec + da * mag;
+                        dec = fmax(att, dec);                            // ave = dec afterwards in both branches
+                        pkm = fmax(mag, pkm);
+                    });
+                    sm.att_ave = att; sm.dec_ave = dec; sm.ave_mag = dec; sm.peak_mag = pkm;
                 }
             }
+            PC_TICK(0);
             // ---------------- AGC (agc.cpp:174-296 / 301-401) ----------------
             if (do_agc) {
                 if (!agc.on) {
@@ -269,72 +381,62 @@ void postchain_kernel(PcArgs a)
                         mg[i] = log10f(m + 3.2767e-4f) - 4.51543987f;
                     }
                     PC_SYNC();
-                    // sliding maximum over the last win_n magnitudes: log-step doubling on a copy
-                    // (pk[i] = max mg[i-2^k+1 .. i]), then two overlapping windows of 2^k
-                    const int Wn = W1 + 1;
-                    int k = 0;
-                    while ((2 << k) <= Wn) k++;                       // 2^k <= Wn < 2^(k+1)
-                    float *cur = S.mg;                               // [W1 history | n], doubled in place
-                    const int len = W1 + n;
-                    // the last W1 entries are the next tile's history: save them first
-                    float keepm[32];
-#pragma unroll
-                    for (int j = 0; j < 32; j++) { const int i = lane + 64 * j; keepm[j] = (i < W1) ? cur[n + i] : 0.f; }
-                    PC_SYNC();
-                    for (int lev = 0; lev < k; lev++) {
-                        const int sft = 1 << lev;
-                        float nv[48];
-#pragma unroll
-                        for (int j = 0; j < 48; j++) {
-                            const int i = lane + 64 * j;
-                            float v = (i < len) ? cur[i] : -16.f;
-                            if (i < len && i >= sft) v = fmaxf(v, cur[i - sft]);
-                            nv[j] = v;
-                        }
+            PC_TICK(1);
+                    // sliding maximum: pk[i] = max E[i .. i+W1], E = [W1 history | tile] = S.mg
+                    sliding_max(S, W1, n, lane);
+                    // the last W1 magnitudes are the next tile's history (forward move, 64 at a time)
+                    for (int i0 = 0; i0 < W1; i0 += 64) {
+                        const int i = i0 + lane;
+                        const float v = S.mg[(i < W1 ? i : 0) + n];
                         PC_SYNC();
-#pragma unroll
-                        for (int j = 0; j < 48; j++) { const int i = lane + 64 * j; if (i < len) cur[i] = nv[j]; }
+                        if (i < W1) S.mg[i] = v;
                         PC_SYNC();
                     }
-                    const int span = 1 << k;
-                    for (int i = lane; i < n; i += 64) {
-                        const int e = W1 + i;                         // window = [e-Wn+1, e]
-                        float v = cur[e];
-                        const int e2 = e - Wn + span;                 // second window of length span ending at e2
-                        if (e2 >= 0) v = fmaxf(v, cur[e2]);
-                        S.pk[i] = v;
-                    }
-                    PC_SYNC();
-                    // restore the magnitude history for the next tile
-#pragma unroll
-                    for (int j = 0; j < 32; j++) { const int i = lane + 64 * j; if (i < W1) cur[i] = keepm[j]; }
                     // attack / decay averagers: sequential (lane 0), output = log gain argument
                     if (lane == 0) {
-                        for (int i = 0; i < n; i++) {
-                            const double pk = S.pk[i];
-                            if (pk > agc.attack_ave) agc.attack_ave = (1.0 - agc.att_rise) * agc.attack_ave + agc.att_rise * pk;
-                            else                     agc.attack_ave = (1.0 - agc.att_fall) * agc.attack_ave + agc.att_fall * pk;
-                            if (agc.hang) {
-                                if (pk > agc.decay_ave) { agc.decay_ave = (1.0 - agc.dec_rise) * agc.decay_ave + agc.dec_rise * pk; agc.hang_timer = 0; }
-                                else if (agc.hang_timer < agc.hang_time) agc.hang_timer++;
-                                else agc.decay_ave = (1.0 - agc.dec_fall) * agc.decay_ave + agc.dec_fall * pk;
-                            } else {
-                                if (pk > agc.decay_ave) agc.decay_ave = (1.0 - agc.dec_rise) * agc.decay_ave + agc.dec_rise * pk;
-                                else                    agc.decay_ave = (1.0 - agc.dec_fall) * agc.decay_ave + agc.dec_fall * pk;
-                            }
-                            const double m = agc.attack_ave > agc.decay_ave ? agc.attack_ave : agc.decay_ave;
-                            S.pk[i] = (m <= agc.knee) ? -1.0f : (float)(m * (agc.gain_slope - 1.0));   // -1: fixed gain marker
+                        double att = agc.attack_ave, dec = agc.decay_ave;
+                        int timer = agc.hang_timer;
+                        // ave += alpha (pk - ave), alpha = rise when pk > ave else fall.  With rise >= fall
+                        // that increment is max(rise d, fall d); sa/sd = -1 turns the max into a min for a
+                        // setting with fall > rise.
+                        const double sa = agc.att_rise >= agc.att_fall ? 1.0 : -1.0, sd = agc.dec_rise >= agc.dec_fall ? 1.0 : -1.0;
+                        double ar = sa * agc.att_rise, af = sa * agc.att_fall, dr = sd * agc.dec_rise, df = sd * agc.dec_fall;
+                        double sav = sa, sdv = sd;
+                        vreg(ar); vreg(af); vreg(dr); vreg(df); vreg(sav); vreg(sdv);
+                        float *dst = S.pk;
+                        if (!agc.hang) {
+                            seq_walk(S.pk, n, [&](float v, int i) {
+                                const double pk = v;
+                                const double da = pk - att, dd = pk - dec;
+                                att = att + sav * fmax(ar * da, af * da);
+                                dec = dec + sdv * fmax(dr * dd, df * dd);
+                                dst[i] = (float)fmax(att, dec);
+                            });
+                        } else {
+                            const int hang_time = agc.hang_time;
+                            seq_walk(S.pk, n, [&](float v, int i) {
+                                const double pk = v;
+                                const double da = pk - att, dd = pk - dec;
+                                att = att + sav * fmax(ar * da, af * da);
+                                const bool up = dd > 0.0, hold = !up && timer < hang_time;
+                                dec = dec + sdv * (up ? dr : (hold ? 0.0 : df)) * dd;
+                                timer = up ? 0 : (hold ? timer + 1 : timer);
+                                dst[i] = (float)fmax(att, dec);
+                            });
                         }
+                        agc.attack_ave = att; agc.decay_ave = dec; agc.hang_timer = timer;
                     }
                     PC_SYNC();
+            PC_TICK(3);
                     // gain law + delay line: out[i] = in[i - D] * gain[i]; S.dl = [D old | n new]
+                    const float knee = (float)agc.knee, slm1 = (float)(agc.gain_slope - 1.0), fixed_gain = (float)agc.fixed_gain;
                     float2 outv[16];
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
                         const int i = lane + 64 * j;
                         if (i < n) {
-                            const float e = S.pk[i];
-                            const float g = (e == -1.0f) ? (float)agc.fixed_gain : 0.7f * exp10f(e);
+                            const float m = S.pk[i];
+                            const float g = (m <= knee) ? fixed_gain : 0.7f * exp10f(m * slm1);
                             const float2 d = S.dl[i];
                             outv[j] = make_float2(d.x * g, d.y * g);
                         }
@@ -351,6 +453,7 @@ void postchain_kernel(PcArgs a)
                 }
             }
             // x[0..n) now holds the AGC output (or the input); x = S.dl + D
+            PC_TICK(4);
             // ---------------- demodulators ----------------
             if (mode == PC_MODE_NONE || mode >= PC_MODE_USB) {
                 if (a.out) {
@@ -363,16 +466,18 @@ void postchain_kernel(PcArgs a)
                 float *w = S.w0 + (nt - 1);
                 for (int i = lane; i < n; i += 64) w[i] = sqrtf(x[i].x * x[i].x + x[i].y * x[i].y);
                 PC_SYNC();
-                if (lane == 0) {                                          // DC block, amdemod.cpp:70-80
-                    for (int i = 0; i < n; i++) { const double z0 = (double)w[i] + am_z1 * 0.99; w[i] = (float)(z0 - am_z1); am_z1 = z0; }
-                }
+                if (lane == 0)                                            // DC block, amdemod.cpp:70-80
+                    seq_walk(w, n, [&](float v, int i) { const double z0 = (double)v + am_z1 * 0.99; w[i] = (float)(z0 - am_z1); am_z1 = z0; });
                 PC_SYNC();
-                const float *h = stereo ? C.am.fir.icoef : C.am.fir.coef, *hq = C.am.fir.qcoef;
-                for (int i = lane; i < n; i += 64) {
-                    const float *p = w + i;
-                    float acc = 0.f, acq = 0.f;
-                    for (int k = 0; k < nt; k++) { acc += h[k] * p[-k]; if (stereo) acq += hq[k] * p[-k]; }
-                    if (stereo) outs[gi + i] = make_float2(acc, acq); else outm[gi + i] = acc;
+                float acc[16], acq[16];
+                fir16(S.h0, nt, w, lane, acc);
+                if (stereo) {
+                    fir16(S.h1, nt, w, lane, acq);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < n) outs[gi + i] = make_float2(acc[j], acq[j]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { const int i = lane + 64 * j; if (i < n) outm[gi + i] = acc[j]; }
                 }
                 PC_SYNC();
                 slide(S.w0, nt - 1, n, lane);
@@ -380,28 +485,39 @@ void postchain_kernel(PcArgs a)
             } else {
                 // PLL modes: theta = arg(x), r = |x| for the whole tile
                 float *th = S.w1 + (nt - 1), *au = S.w0 + (nt - 1);
-                for (int i = lane; i < n; i += 64) th[i] = atan2f(x[i].y, x[i].x);
+                for (int i = lane; i < n; i += 64) th[i] = atan2f(x[i].y, x[i].x) * (float)kInvTwoPiD;   // turns
                 PC_SYNC();
                 if (mode == PC_MODE_FM) {
                     const PcFm &F = C.fm;
                     if (lane == 0) {
-                        for (int i = 0; i < n; i++) {                     // fmdemod.cpp:166-186
-                            const double err = -wrap_pi((double)th[i] + fm_ph);
-                            fm_fr += F.beta * err;
-                            if (fm_fr > F.hi) fm_fr = F.hi; else if (fm_fr < F.lo) fm_fr = F.lo;
-                            fm_ph = wrap_pi(fm_ph + fm_fr + F.alpha * err);
-                            fm_dc = (1.0 - F.dc_alpha) * fm_dc + F.dc_alpha * fm_fr;
-                            au[i] = (float)((fm_fr - fm_dc) * F.out_gain);
-                        }
+                        // phase, frequency and error in turns: wrapping is a - rint(a)
+                        const double beta = F.beta, alpha = F.alpha, hi = F.hi * kInvTwoPiD, lo = F.lo * kInvTwoPiD,
+                                     dca = F.dc_alpha, idca = 1.0 - F.dc_alpha, og = F.out_gain * kTwoPiD;
+                        double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD, dc = fm_dc * kInvTwoPiD;
+                        seq_walk(th, n, [&](float v, int i) {              // fmdemod.cpp:166-186
+                            const double err = -wrap_turn((double)v + ph);
+                            fr = fmin(fmax(fr + beta * err, lo), hi);
+                            ph = wrap_turn(ph + fr + alpha * err);
+                            dc = idca * dc + dca * fr;
+                            au[i] = (float)((fr - dc) * og);
+                        });
+                        fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD; fm_dc = dc * kTwoPiD;
                     }
                     PC_SYNC();
+            PC_TICK(5);
                     // raw audio to the output row; squelch is decided at the end of the burst
                     for (int i = lane; i < n; i += 64) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
                     if (a.burst <= 16384) {                               // MAX_SQBUF_SIZE
-                        fir_tile(F.hp.coef, nt, S.w0, S.w2, n, lane);
+            PC_TICK(6);
+                        float acc[16];
+                        fir16(S.h0, nt, au, lane, acc);
+#pragma unroll
+                        for (int j = 0; j < 16; j++) S.w2[(lane + 64 * j) & (PT - 1)] = fabsf(acc[j]);
                         PC_SYNC();
-                        if (lane == 0)
-                            for (int i = 0; i < n; i++) fm_sq = (1.0 - F.sq_alpha) * fm_sq + F.sq_alpha * (double)fabsf(S.w2[i]);
+                        if (lane == 0) {
+                            const double qa = F.sq_alpha, iqa = 1.0 - F.sq_alpha;
+                            seq_walk(S.w2, n, [&](float v, int) { fm_sq = iqa * fm_sq + qa * (double)v; });
+                        }
                     }
                     PC_SYNC();
                     slide(S.w0, nt - 1, n, lane);
@@ -410,39 +526,42 @@ void postchain_kernel(PcArgs a)
                     const PcSam &M = C.sam;
                     const double sgn = stereo ? 1.0 : -1.0;
                     if (lane == 0) {
-                        for (int i = 0; i < n; i++) {
-                            S.w2[i] = (float)sam_ph;                      // phase used for this sample
-                            const double err = -sgn * wrap_pi((double)th[i] + sgn * sam_ph);
-                            sam_fr += M.beta * err;
-                            if (sam_fr > M.hi) sam_fr = M.hi; else if (sam_fr < M.lo) sam_fr = M.lo;
-                            sam_ph = wrap_pi(sam_ph + sam_fr + M.alpha * err);
-                        }
+                        const double beta = M.beta, alpha = M.alpha, hi = M.hi * kInvTwoPiD, lo = M.lo * kInvTwoPiD;
+                        double ph = sam_ph * kInvTwoPiD, fr = sam_fr * kInvTwoPiD;
+                        seq_walk(th, n, [&](float v, int i) {
+                            S.w2[i] = (float)ph;                          // phase used for this sample (turns)
+                            const double err = -sgn * wrap_turn((double)v + sgn * ph);
+                            fr = fmin(fmax(fr + beta * err, lo), hi);
+                            ph = wrap_turn(ph + fr + alpha * err);
+                        });
+                        sam_ph = ph * kTwoPiD; sam_fr = fr * kTwoPiD;
                     }
                     PC_SYNC();
                     // rotated sample tr + j ti = |x| e^{j(theta + sgn phi)}
                     for (int i = lane; i < n; i += 64) {
                         const float r = sqrtf(x[i].x * x[i].x + x[i].y * x[i].y);
                         float s, c;
-                        sincosf(th[i] + (float)sgn * S.w2[i], &s, &c);
+                        sincospif(2.0f * (th[i] + (float)sgn * S.w2[i]), &s, &c);
                         au[i] = r * c;                                    // tr
                         th[i] = r * s;                                    // ti
                     }
                     PC_SYNC();
                     if (lane == 0) {                                      // DC blocks
-                        for (int i = 0; i < n; i++) {
-                            const double z0 = (double)au[i] + sam_z1 * 0.99; au[i] = (float)(z0 - sam_z1); sam_z1 = z0;
-                            if (stereo) { const double y0 = (double)th[i] + sam_y1 * 0.99; th[i] = (float)(y0 - sam_y1); sam_y1 = y0; }
-                        }
+                        seq_walk(au, n, [&](float v, int i) { const double z0 = (double)v + sam_z1 * 0.99; au[i] = (float)(z0 - sam_z1); sam_z1 = z0; });
+                        if (stereo)
+                            seq_walk(th, n, [&](float v, int i) { const double y0 = (double)v + sam_y1 * 0.99; th[i] = (float)(y0 - sam_y1); sam_y1 = y0; });
                     }
                     PC_SYNC();
                     if (!stereo) {
                         for (int i = lane; i < n; i += 64) outm[gi + i] = au[i];
                     } else {
-                        const float *hi = M.fir.icoef, *hq = M.fir.qcoef;
-                        for (int i = lane; i < n; i += 64) {
-                            float ar = 0.f, ai = 0.f;
-                            for (int k = 0; k < nt; k++) { ar += hi[k] * au[i - k]; ai += hq[k] * th[i - k]; }
-                            outs[gi + i] = make_float2(ar + ai, ar - ai);    // lower sideband left, upper right
+                        float ar[16], ai[16];
+                        fir16(S.h0, nt, au, lane, ar);
+                        fir16(S.h1, nt, th, lane, ai);
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {                    // lower sideband left, upper right
+                            const int i = lane + 64 * j;
+                            if (i < n) outs[gi + i] = make_float2(ar[j] + ai[j], ar[j] - ai[j]);
                         }
                         PC_SYNC();
                         slide(S.w0, nt - 1, n, lane);
@@ -452,6 +571,7 @@ void postchain_kernel(PcArgs a)
                 }
             }
         }
+            PC_TICK(8);
         // ---------------- end of burst: FM squelch decision (fmdemod.cpp:128-151) ----------------
         if (mode == PC_MODE_FM && a.burst <= 16384) {
             const PcFm &F = C.fm;
@@ -468,7 +588,7 @@ void postchain_kernel(PcArgs a)
                 } else {                                                  // low-pass biquad over the burst
                     for (int i = lane; i < n; i += 64) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i];
                     PC_SYNC();
-                    if (lane == 0) for (int i = 0; i < n; i++) S.w2[i] = iir_a(lp, S.w2[i]);
+                    if (lane == 0) seq_walk(S.w2, n, [&](float v, int i) { S.w2[i] = iir_a(lp, v); });
                     PC_SYNC();
                     for (int i = lane; i < n; i += 64) { const float y = S.w2[i]; if (stereo) outs[g0 + t0 + i] = make_float2(y, y); else outm[g0 + t0 + i] = y; }
                     PC_SYNC();
@@ -477,6 +597,12 @@ void postchain_kernel(PcArgs a)
         }
     }
 
+            PC_TICK(9);
+#ifdef PC_PROFILE
+    if (lane == 0 && ch == 0)
+        printf("pcprof mode %d: load+smeter %llu mag %llu slide %llu agcseq %llu gain %llu demod-pre+pll %llu rawout %llu fir+ema+slide %llu burstend %llu (x100 cycles)\n",
+               mode, tk[0] / 100, tk[1] / 100, tk[2] / 100, tk[3] / 100, tk[4] / 100, tk[5] / 100, tk[6] / 100, tk[7] / 100, tk[8] / 100);
+#endif
     // ---------------- write the state back ----------------
     PC_SYNC();
     if (do_agc && agc.on) {
