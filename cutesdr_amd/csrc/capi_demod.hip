@@ -186,10 +186,17 @@ struct csdr_demod_batch {
     std::vector<std::vector<int>> members;            // core -> channel ids (row order)
     std::vector<int *> d_rows;                        // core -> device array of channel ids
     std::map<long long, int> core_by_bw;
+    // the groups are independent: each runs on its own stream, forked from and joined to the caller's
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> joins;
+    hipEvent_t fork = nullptr;
     ~csdr_demod_batch()
     {
         for (auto *k : cores) delete k;
         for (auto *p : d_rows) if (p) (void)hipFree(p);
+        for (auto st : streams) (void)hipStreamDestroy(st);
+        for (auto ev : joins) (void)hipEventDestroy(ev);
+        if (fork) (void)hipEventDestroy(fork);
     }
 };
 
@@ -365,6 +372,16 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
             if (rc) return rc;
         }
     }
+    if (b->cores.size() > 1) {
+        CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+        for (size_t ki = 0; ki < b->cores.size(); ki++) {
+            hipStream_t st; hipEvent_t ev;
+            CSDR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            b->streams.push_back(st);
+            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            b->joins.push_back(ev);
+        }
+    }
     return CSDR_OK;
 }
 int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq)
@@ -395,12 +412,22 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
     if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad argument");
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
     if (!device_ok(b->device)) return CSDR_EHIP;
+    hipStream_t caller = (hipStream_t)stream;
+    const bool forked = b->cores.size() > 1;
+    if (forked) CSDR_HIP(hipEventRecord(b->fork, caller));
+    int err = 0;
     for (size_t ki = 0; ki < b->cores.size(); ki++) {
-        int rc = b->cores[ki]->step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride,
-                                    b->d_rows[ki], false, (hipStream_t)stream);
-        if (rc < 0) return rc;
+        hipStream_t st = forked ? b->streams[ki] : caller;
+        if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
+        const int rc = b->cores[ki]->step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride,
+                                          b->d_rows[ki], false, st);
+        if (rc < 0 && !err) err = rc;
+        if (forked) {                                   // join even after an error: the caller's stream stays ordered
+            CSDR_HIP(hipEventRecord(b->joins[ki], st));
+            CSDR_HIP(hipStreamWaitEvent(caller, b->joins[ki], 0));
+        }
     }
-    return CSDR_OK;
+    return err ? err : CSDR_OK;
 }
 /* audio samples channel `channel` received in the last process call */
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel)

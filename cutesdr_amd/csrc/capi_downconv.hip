@@ -203,7 +203,7 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         a.hist_stride = b->hist_stride;
         a.chan = b->d_chan; a.chan_list = b->d_list + list_off; a.amp = b->d_amp; a.in_rows = d_in_rows;
         a.nchan = (int)list.size(); a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
-        for (int q = 0; q < p.nstages; q++) a.st[q] = p.st[q];
+        for (int q = 0; q < p.nstages; q++) { a.st[q] = p.st[q]; a.kind[q] = p.kind[q]; }
         // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long
         long min_seg = (long)DC_TILE_SAMPLES * 8;
         if (min_seg < (long)p.W * 8) min_seg = (long)p.W * 8;

@@ -37,6 +37,7 @@ struct DcArgs {
     const float *amp;                        // [DC_AMP_N] amplitude envelope a_n
     int nchan, n_in, nstages, W, seg_len, nseg;
     int roff[DC_MAX_STAGES + 2];
+    int kind[DC_MAX_STAGES];                 // 3 = CIC3, otherwise the half-band length (11, 15, .. 51)
     DcStage st[DC_MAX_STAGES];
 };
 

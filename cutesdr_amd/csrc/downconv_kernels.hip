@@ -37,6 +37,32 @@ __device__ __forceinline__ v2f phasor_of(unsigned long long phase)
     return v2f{c, s};
 }
 
+// One decimate-by-2 stage with the tap geometry fixed at compile time: L = 3 is the CIC-3
+// (downconvert.cpp:444-460), otherwise an L-tap half band whose non-zero taps are the even ones
+// (symmetric pairs 2q / L-1-2q) and the centre (downconvert.cpp:286-320, 348-423).  The pair
+// coefficients are wave-uniform and stay in scalar registers.
+template <int L>
+__device__ __forceinline__ void dc_stage(const v2f *xe, v2f *y, int nout, const DcStage &st, int t)
+{
+    constexpr int NP = (L == 3) ? 2 : (L + 1) / 4;
+    float c[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) c[q] = st.c[q];
+    const float cc = st.ccoef;
+    for (int j = t; j < nout; j += DC_T) {
+        const v2f *p = xe + 2 * j;
+        v2f acc;
+        if (L == 3) {
+            acc = (p[0] + p[3]) * c[0] + (p[1] + p[2]) * c[1];
+        } else {
+            acc = p[(L - 1) / 2] * cc;
+#pragma unroll
+            for (int q = 0; q < NP; q++) acc += (p[2 * q] + p[L - 1 - 2 * q]) * c[q];
+        }
+        y[j] = acc;
+    }
+}
+
 __global__ __launch_bounds__(DC_T)
 void downconv_kernel(DcArgs a)
 {
@@ -111,13 +137,20 @@ void downconv_kernel(DcArgs a)
             const v2f *xe = lds + roff[s];
             const int hnext = (s + 1 < ns) ? a.st[s + 1].hist : 0;
             v2f *y = lds + roff[s + 1] + hnext;
-            const int nout = len >> 1, np = a.st[s].npairs, cen = a.st[s].center;
-            const float cc = a.st[s].ccoef;
-            for (int j = t; j < nout; j += DC_T) {
-                const v2f *p = xe + 2 * j;
-                v2f acc = cen >= 0 ? p[cen] * cc : v2f{0.f, 0.f};
-                for (int q = 0; q < np; q++) acc += (p[a.st[s].a[q]] + p[a.st[s].b[q]]) * a.st[s].c[q];
-                y[j] = acc;
+            const int nout = len >> 1;
+            switch (a.kind[s]) {
+            case 3:  dc_stage<3>(xe, y, nout, a.st[s], t); break;
+            case 11: dc_stage<11>(xe, y, nout, a.st[s], t); break;
+            case 15: dc_stage<15>(xe, y, nout, a.st[s], t); break;
+            case 19: dc_stage<19>(xe, y, nout, a.st[s], t); break;
+            case 23: dc_stage<23>(xe, y, nout, a.st[s], t); break;
+            case 27: dc_stage<27>(xe, y, nout, a.st[s], t); break;
+            case 31: dc_stage<31>(xe, y, nout, a.st[s], t); break;
+            case 35: dc_stage<35>(xe, y, nout, a.st[s], t); break;
+            case 39: dc_stage<39>(xe, y, nout, a.st[s], t); break;
+            case 43: dc_stage<43>(xe, y, nout, a.st[s], t); break;
+            case 47: dc_stage<47>(xe, y, nout, a.st[s], t); break;
+            default: dc_stage<51>(xe, y, nout, a.st[s], t); break;
             }
             __syncthreads();
             // slide the history: last hist_s inputs of this stage move to the front
