@@ -36,7 +36,8 @@ struct DcArgs {
     const int *in_rows;                      // optional [channels]: input row of each channel id
     const float *amp;                        // [DC_AMP_N] amplitude envelope a_n
     int nchan, n_in, nstages, W, seg_len, nseg;
-    int roff[DC_MAX_STAGES + 2];
+    int roff[DC_MAX_STAGES + 2];             // LDS region of each stage's input (the last one: tile outputs)
+    int ooff[DC_MAX_STAGES + 1];             // offset of the odd-sample half inside region s
     int kind[DC_MAX_STAGES];                 // 3 = CIC3, otherwise the half-band length (11, 15, .. 51)
     DcStage st[DC_MAX_STAGES];
 };

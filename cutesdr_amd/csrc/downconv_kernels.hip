@@ -23,10 +23,14 @@
 
 namespace csdr {
 
-constexpr int DC_T = 256;                  // threads per workgroup
+constexpr int DC_T = 512;                  // threads per workgroup
 constexpr int DC_ROW = 2 * DC_T;           // samples per row (16 B per lane)
 constexpr int DC_TILE = 4096;              // input samples per tile
 constexpr int DC_ANCHOR_ROWS = 16;
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would make
+// every barrier of the cascade wait for the global loads prefetched for the next tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // e^{j * 2*pi * phase/2^64}
 __device__ __forceinline__ v2f phasor_of(unsigned long long phase)
@@ -41,25 +45,51 @@ __device__ __forceinline__ v2f phasor_of(unsigned long long phase)
 // (downconvert.cpp:444-460), otherwise an L-tap half band whose non-zero taps are the even ones
 // (symmetric pairs 2q / L-1-2q) and the centre (downconvert.cpp:286-320, 348-423).  The pair
 // coefficients are wave-uniform and stay in scalar registers.
+//
+// The stage input xe = [history | input] is kept split by sample parity, E[m] = xe[2m] and
+// O[m] = xe[2m+1], so that output j reads E[j+q] / O[j+q]: consecutive lanes touch consecutive
+// LDS words (the interleaved layout made every tap read a 16-byte-stride access).  Outputs go to
+// the next stage's halves (its history is even, so output j has parity j&1) or, after the last
+// stage, to the linear tile-output region.
+// per-stage parameters: staged through LDS once per workgroup, then held in registers with stage s
+// in lane s and fetched with v_readlane (no memory access on the per-tile path)
+enum { DP_KIND = 0, DP_HIST2, DP_ROFF, DP_OOFF, DP_CC, DP_C0, DP_WORDS = DP_C0 + DC_MAX_PAIRS + 1 };
+
 template <int L>
-__device__ __forceinline__ void dc_stage(const v2f *xe, v2f *y, int nout, const DcStage &st, int t)
+__device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2f *yO, v2f *ylin, int nout,
+                                         const int (&pv)[DP_WORDS], int s, int t)
 {
     constexpr int NP = (L == 3) ? 2 : (L + 1) / 4;
+    constexpr int H = (L - 1) / 2;              // centre tap (odd index for every L = 4k+3)
+    constexpr int UN = 1;                       // outputs per thread and pass: all reads before any write
     float c[NP];
 #pragma unroll
-    for (int q = 0; q < NP; q++) c[q] = st.c[q];
-    const float cc = st.ccoef;
-    for (int j = t; j < nout; j += DC_T) {
-        const v2f *p = xe + 2 * j;
-        v2f acc;
-        if (L == 3) {
-            acc = (p[0] + p[3]) * c[0] + (p[1] + p[2]) * c[1];
-        } else {
-            acc = p[(L - 1) / 2] * cc;
+    for (int q = 0; q < NP; q++) c[q] = __int_as_float(__builtin_amdgcn_readlane(pv[DP_C0 + q], s));
+    const float cc = __int_as_float(__builtin_amdgcn_readlane(pv[DP_CC], s));
+    for (int j0 = t; j0 < nout; j0 += UN * DC_T) {
+        v2f acc[UN];
 #pragma unroll
-            for (int q = 0; q < NP; q++) acc += (p[2 * q] + p[L - 1 - 2 * q]) * c[q];
+        for (int u = 0; u < UN; u++) {
+            const int j = j0 + u * DC_T;
+            if (j < nout) {
+                if (L == 3) {
+                    acc[u] = (E[j] + O[j + 1]) * c[0] + (O[j] + E[j + 1]) * c[1];
+                } else {
+                    acc[u] = O[j + (H - 1) / 2] * cc;
+#pragma unroll
+                    for (int q = 0; q < NP; q++) acc[u] += (E[j + q] + E[j + H - q]) * c[q];
+                }
+            }
         }
-        y[j] = acc;
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int j = j0 + u * DC_T;
+            if (j < nout) {
+                if (ylin) ylin[j] = acc[u];
+                else if (j & 1) yO[j >> 1] = acc[u];
+                else yE[j >> 1] = acc[u];
+            }
+        }
     }
 }
 
@@ -78,8 +108,27 @@ void downconv_kernel(DcArgs a)
 
     // LDS regions R_s = [hist_s | stage-s input] at a.roff[s] (host computed); R_ns = tile outputs
     const int *roff = a.roff;
+    __shared__ int ptab[DC_MAX_STAGES + 1][DP_WORDS];
+    for (int i = t; i < (ns + 1) * DP_WORDS; i += DC_T) {
+        const int s = i / DP_WORDS, k = i % DP_WORDS;
+        int v = 0;
+        if (k == DP_ROFF) v = roff[s];
+        else if (k == DP_OOFF) v = a.ooff[s];
+        else if (s < ns) {
+            if (k == DP_KIND) v = a.kind[s];
+            else if (k == DP_HIST2) v = a.st[s].hist / 2;
+            else if (k == DP_CC) v = __float_as_int(a.st[s].ccoef);
+            else if (k - DP_C0 < DC_MAX_PAIRS) v = __float_as_int(a.st[s].c[k - DP_C0]);
+        }
+        ptab[s][k] = v;
+    }
     for (int s = 0; s < ns; s++)
-        for (int i = t; i < a.st[s].hist; i += DC_T) lds[roff[s] + i] = v2f{0.f, 0.f};
+        for (int i = t; i < a.st[s].hist; i += DC_T)
+            lds[roff[s] + ((i & 1) ? a.ooff[s] : 0) + (i >> 1)] = v2f{0.f, 0.f};
+    lds_barrier();
+    int pv[DP_WORDS];
+#pragma unroll
+    for (int k = 0; k < DP_WORDS; k++) pv[k] = ptab[(t & 63) <= ns ? (t & 63) : ns][k];
 
     const v2f *in = a.in + (long)(a.in_rows ? a.in_rows[ch] : ch) * a.in_stride;
     v2f *out = a.out + (long)ch * a.out_stride;
@@ -91,28 +140,59 @@ void downconv_kernel(DcArgs a)
     const v2f rowstep = phasor_of(cs.inc * (unsigned long long)DC_ROW);
     const float a_inf = a.amp[DC_AMP_N - 1];
 
+    // The raw input of a tile is fetched into registers one tile ahead, while the previous tile goes
+    // through the cascade: nothing waits on HBM latency except the very first tile.
+    constexpr int NR = DC_TILE / DC_ROW;
+    v4f raw[NR];
+    auto tile_len = [&](long p) {
+        const long lim = ((p < seg_start) ? seg_start : seg_end) - p;
+        return (int)(lim < DC_TILE ? lim : DC_TILE);
+    };
+    auto fetch = [&](long p) {
+        if (p >= seg_end || (p < seg_start && seg == 0)) return;      // past the end / history-fed warm-up
+        const int m = tile_len(p);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = r * DC_ROW + 2 * t;
+            if (i < m) raw[r] = *reinterpret_cast<const v4f *>(in + p + i);
+        }
+    };
+
     // pos: index of the tile's first sample in this call's input (negative inside the warm-up)
     long pos = seg_start - a.W;
+#ifdef DC_PROFILE
+    unsigned long long tk[20] = {0}, tlast = __builtin_readcyclecounter();
+#define DC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tk[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define DC_TICK(k)
+#endif
+    fetch(pos);
     while (pos < seg_end) {
         const bool warm = pos < seg_start;
-        const long lim = (warm ? seg_start : seg_end) - pos;
-        const int n = (int)(lim < DC_TILE ? lim : DC_TILE);
-        v2f *r0 = lds + roff[0] + (ns > 0 ? a.st[0].hist : 0);
+        const int n = tile_len(pos);
+        // stage-0 input: parity halves behind their histories (no decimation: the linear output region)
+        const int h0 = ns > 0 ? a.st[0].hist / 2 : 0;
+        v2f *r0 = lds + roff[0] + h0, *r0o = lds + roff[0] + (ns > 0 ? a.ooff[0] : 0) + h0;
         // ---------------- stage-0 input: mix with the NCO (or take the mixed history) -----------
         if (warm && seg == 0) {
-            for (int i = t; i < n; i += DC_T) r0[i] = hist[pos + a.W + i];
+            for (int i = t; i < n; i += DC_T) {
+                const v2f v = hist[pos + a.W + i];
+                if (ns == 0) r0[i] = v;
+                else if (i & 1) r0o[i >> 1] = v;
+                else r0[i >> 1] = v;
+            }
         } else {
             v2f p0 = {1.f, 0.f}, p1 = {1.f, 0.f};
-            int row = 0;
-            for (int i0 = 0; i0 < n; i0 += DC_ROW, row++) {
-                const int i = i0 + 2 * t;
+#pragma unroll
+            for (int row = 0; row < NR; row++) {
+                const int i = row * DC_ROW + 2 * t;
                 const long gi = pos + i;                       // sample index within the call
                 if ((row & (DC_ANCHOR_ROWS - 1)) == 0) {
                     p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(gi + 1));
                     p1 = phasor_of(cs.phase + cs.inc * (unsigned long long)(gi + 2));
                 }
                 if (i < n) {
-                    const v4f v = *reinterpret_cast<const v4f *>(in + gi);
+                    const v4f v = raw[row];
                     v2f x0 = cmul(v2f{v.x, v.y}, p0), x1 = cmul(v2f{v.z, v.w}, p1);
                     const unsigned long long age = cs.age + (unsigned long long)gi;
                     if (age + 1 >= DC_AMP_N) {                  // wave-uniform except at the seam
@@ -120,7 +200,11 @@ void downconv_kernel(DcArgs a)
                     } else {
                         x0 *= a.amp[age]; x1 *= a.amp[age + 1];
                     }
-                    *reinterpret_cast<v4f *>(&r0[i]) = v4f{x0.x, x0.y, x1.x, x1.y};
+                    if (ns == 0) {
+                        *reinterpret_cast<v4f *>(&r0[i]) = v4f{x0.x, x0.y, x1.x, x1.y};
+                    } else {
+                        r0[i >> 1] = x0; r0o[i >> 1] = x1;
+                    }
                     // the last W mixed samples of the call are the next call's warm-up
                     const long hj = gi - (a.n_in - a.W);
                     if (!warm && hj >= 0 && a.W > 0)
@@ -130,48 +214,72 @@ void downconv_kernel(DcArgs a)
                 p1 = cmul(p1, rowstep);
             }
         }
-        __syncthreads();
+        DC_TICK(0);
+        lds_barrier();
+        DC_TICK(1);
+        fetch(pos + n);                                       // next tile's input, in flight during the cascade
         // ---------------- the cascade, LDS -> LDS ---------------------------------------------
         int len = n;
         for (int s = 0; s < ns; s++) {
-            const v2f *xe = lds + roff[s];
-            const int hnext = (s + 1 < ns) ? a.st[s + 1].hist : 0;
-            v2f *y = lds + roff[s + 1] + hnext;
+            const v2f *E = lds + __builtin_amdgcn_readlane(pv[DP_ROFF], s), *O = E + __builtin_amdgcn_readlane(pv[DP_OOFF], s);
+            const bool last = s + 1 == ns;
+            const int hn2 = __builtin_amdgcn_readlane(pv[DP_HIST2], s + 1);      // 0 behind the last stage
+            v2f *yE = lds + __builtin_amdgcn_readlane(pv[DP_ROFF], s + 1) + hn2;
+            v2f *yO = yE + __builtin_amdgcn_readlane(pv[DP_OOFF], s + 1);
+            v2f *ylin = last ? yE : nullptr;
             const int nout = len >> 1;
-            switch (a.kind[s]) {
-            case 3:  dc_stage<3>(xe, y, nout, a.st[s], t); break;
-            case 11: dc_stage<11>(xe, y, nout, a.st[s], t); break;
-            case 15: dc_stage<15>(xe, y, nout, a.st[s], t); break;
-            case 19: dc_stage<19>(xe, y, nout, a.st[s], t); break;
-            case 23: dc_stage<23>(xe, y, nout, a.st[s], t); break;
-            case 27: dc_stage<27>(xe, y, nout, a.st[s], t); break;
-            case 31: dc_stage<31>(xe, y, nout, a.st[s], t); break;
-            case 35: dc_stage<35>(xe, y, nout, a.st[s], t); break;
-            case 39: dc_stage<39>(xe, y, nout, a.st[s], t); break;
-            case 43: dc_stage<43>(xe, y, nout, a.st[s], t); break;
-            case 47: dc_stage<47>(xe, y, nout, a.st[s], t); break;
-            default: dc_stage<51>(xe, y, nout, a.st[s], t); break;
+#define DC_CASE(LL) case LL: dc_stage<LL>(E, O, yE, yO, ylin, nout, pv, s, t); break;
+            switch (__builtin_amdgcn_readlane(pv[DP_KIND], s)) {
+            DC_CASE(3) DC_CASE(11) DC_CASE(15) DC_CASE(19) DC_CASE(23) DC_CASE(27) DC_CASE(31)
+            DC_CASE(35) DC_CASE(39) DC_CASE(43) DC_CASE(47)
+            default: dc_stage<51>(E, O, yE, yO, ylin, nout, pv, s, t); break;
             }
-            __syncthreads();
-            // slide the history: last hist_s inputs of this stage move to the front
-            const int h = a.st[s].hist;
-            v2f keep = {0.f, 0.f};
-            if (t < h) keep = xe[len + t];
-            __syncthreads();
-            if (t < h) lds[roff[s] + t] = keep;
+#undef DC_CASE
+            DC_TICK(8 + s);
+            lds_barrier();
+            DC_TICK(3);
             len = nout;
         }
-        if (ns > 0) __syncthreads();
+        // slide every stage's history at once: the last hist_s inputs of stage s (hist_s/2 per parity
+        // half) move to the front; 64 lanes per stage, 32 per half; read, barrier, write because a
+        // short tile overlaps source and target
+        {
+            constexpr int R = (DC_MAX_STAGES * 64 + DC_T - 1) / DC_T;
+            v2f keep[R];
+            int dst[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int u = t + r * DC_T, odd = (u >> 5) & 1, i = u & 31;
+                const int sg = __builtin_amdgcn_readfirstlane(u >> 6);       // one wave per stage
+                keep[r] = v2f{0.f, 0.f};
+                dst[r] = -1;
+                if (sg < ns && i < __builtin_amdgcn_readlane(pv[DP_HIST2], sg)) {
+                    dst[r] = __builtin_amdgcn_readlane(pv[DP_ROFF], sg) + (odd ? __builtin_amdgcn_readlane(pv[DP_OOFF], sg) : 0) + i;
+                    keep[r] = lds[dst[r] + (n >> (sg + 1))];
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < R; r++) if (dst[r] >= 0) lds[dst[r]] = keep[r];
+        }
+        DC_TICK(4);
         // ---------------- tile outputs -> HBM ------------------------------------------------------
         if (!warm) {
             const v2f *y = lds + roff[ns];
             const long obase = pos >> ns;
             for (int j = t; j < len; j += DC_T) out[obase + j] = y[j];
         }
-        __syncthreads();
+        DC_TICK(5);
+        lds_barrier();
+        DC_TICK(6);
         pos += n;
     }
 
+#ifdef DC_PROFILE
+    if (wg == 0 && (t == 0 || t == 256))
+        printf("dcprof t%d: mix %llu bar %llu stages %llu bar %llu hist %llu out %llu bar %llu\n", t, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
+    if (wg == 0 && (t == 0 || t == 256)) printf("dcstages t%d: %llu %llu %llu %llu %llu %llu\n", t, tk[8], tk[9], tk[10], tk[11], tk[12], tk[13]);
+#endif
     // calls shorter than the warm-up length keep the tail of the old history in front
     if (seg == a.nseg - 1 && a.n_in < a.W)
         for (int j = t; j < a.W - a.n_in; j += DC_T) hist_next[j] = hist[j + a.n_in];
@@ -182,7 +290,14 @@ int downconv_layout(DcArgs &a)
     int o = 0;
     for (int s = 0; s <= a.nstages; s++) {
         a.roff[s] = o;
-        o += ((s < a.nstages ? a.st[s].hist : 0) + (DC_TILE >> s) + 1) & ~1;
+        if (s < a.nstages) {
+            const int half = (a.st[s].hist / 2 + (DC_TILE >> (s + 1)) + 2) & ~1;    // + slack for the CIC's O[j+1]
+            a.ooff[s] = half;
+            o += 2 * half;
+        } else {
+            a.ooff[s] = 0;
+            o += ((DC_TILE >> s) + 1) & ~1;
+        }
     }
     return o * 8 + 64;
 }
