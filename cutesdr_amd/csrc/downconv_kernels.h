@@ -7,7 +7,7 @@ namespace csdr {
 constexpr int DC_MAX_STAGES = 9;     // MAX_DECSTAGES-1, reference dsp/downconvert.h:18
 constexpr int DC_MAX_PAIRS = 13;     // 51-tap half band: 13 symmetric even-tap pairs + centre
 constexpr int DC_AMP_N = 512;        // NCO amplitude envelope table length
-constexpr int DC_TILE_SAMPLES = 4096;
+constexpr int DC_TILE_SAMPLES = 512;
 
 typedef float dc_v2f __attribute__((ext_vector_type(2)));
 

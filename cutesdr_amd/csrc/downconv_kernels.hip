@@ -23,9 +23,9 @@
 
 namespace csdr {
 
-constexpr int DC_T = 512;                  // threads per workgroup
+constexpr int DC_T = 64;                  // threads per workgroup
 constexpr int DC_ROW = 2 * DC_T;           // samples per row (16 B per lane)
-constexpr int DC_TILE = 4096;              // input samples per tile
+constexpr int DC_TILE = 512;              // input samples per tile
 constexpr int DC_ANCHOR_ROWS = 16;
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would make
@@ -51,21 +51,27 @@ __device__ __forceinline__ v2f phasor_of(unsigned long long phase)
 // LDS words (the interleaved layout made every tap read a 16-byte-stride access).  Outputs go to
 // the next stage's halves (its history is even, so output j has parity j&1) or, after the last
 // stage, to the linear tile-output region.
-// per-stage parameters: staged through LDS once per workgroup, then held in registers with stage s
-// in lane s and fetched with v_readlane (no memory access on the per-tile path)
-enum { DP_KIND = 0, DP_HIST2, DP_ROFF, DP_OOFF, DP_CC, DP_C0, DP_WORDS = DP_C0 + DC_MAX_PAIRS + 1 };
+// per-stage parameters, staged in LDS once per workgroup: the tap values are read from there (wide
+// uniform reads), the layout words sit packed in two registers with stage s in lane s (v_readlane)
+enum { DP_KIND = 0, DP_HIST2, DP_ROFF, DP_OOFF, DP_CC, DP_C0 = 8, DP_WORDS = 24 };   // rows of 96 B, taps 16-B aligned
 
 template <int L>
 __device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2f *yO, v2f *ylin, int nout,
-                                         const int (&pv)[DP_WORDS], int s, int t)
+                                         const int *prm, int t)
 {
     constexpr int NP = (L == 3) ? 2 : (L + 1) / 4;
     constexpr int H = (L - 1) / 2;              // centre tap (odd index for every L = 4k+3)
     constexpr int UN = 1;                       // outputs per thread and pass: all reads before any write
     float c[NP];
 #pragma unroll
-    for (int q = 0; q < NP; q++) c[q] = __int_as_float(__builtin_amdgcn_readlane(pv[DP_C0 + q], s));
-    const float cc = __int_as_float(__builtin_amdgcn_readlane(pv[DP_CC], s));
+    for (int q = 0; q < NP; q += 4) {
+        const v4f v = *reinterpret_cast<const v4f *>(prm + DP_C0 + q);
+        c[q] = v.x;
+        if (q + 1 < NP) c[q + 1] = v.y;
+        if (q + 2 < NP) c[q + 2] = v.z;
+        if (q + 3 < NP) c[q + 3] = v.w;
+    }
+    const float cc = __int_as_float(prm[DP_CC]);
     for (int j0 = t; j0 < nout; j0 += UN * DC_T) {
         v2f acc[UN];
 #pragma unroll
@@ -93,7 +99,7 @@ __device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2
     }
 }
 
-__global__ __launch_bounds__(DC_T)
+__global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void downconv_kernel(DcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -108,7 +114,7 @@ void downconv_kernel(DcArgs a)
 
     // LDS regions R_s = [hist_s | stage-s input] at a.roff[s] (host computed); R_ns = tile outputs
     const int *roff = a.roff;
-    __shared__ int ptab[DC_MAX_STAGES + 1][DP_WORDS];
+    __shared__ __attribute__((aligned(16))) int ptab[DC_MAX_STAGES + 1][DP_WORDS];
     for (int i = t; i < (ns + 1) * DP_WORDS; i += DC_T) {
         const int s = i / DP_WORDS, k = i % DP_WORDS;
         int v = 0;
@@ -118,7 +124,7 @@ void downconv_kernel(DcArgs a)
             if (k == DP_KIND) v = a.kind[s];
             else if (k == DP_HIST2) v = a.st[s].hist / 2;
             else if (k == DP_CC) v = __float_as_int(a.st[s].ccoef);
-            else if (k - DP_C0 < DC_MAX_PAIRS) v = __float_as_int(a.st[s].c[k - DP_C0]);
+            else if (k >= DP_C0 && k - DP_C0 < DC_MAX_PAIRS) v = __float_as_int(a.st[s].c[k - DP_C0]);
         }
         ptab[s][k] = v;
     }
@@ -126,9 +132,16 @@ void downconv_kernel(DcArgs a)
         for (int i = t; i < a.st[s].hist; i += DC_T)
             lds[roff[s] + ((i & 1) ? a.ooff[s] : 0) + (i >> 1)] = v2f{0.f, 0.f};
     lds_barrier();
-    int pv[DP_WORDS];
-#pragma unroll
-    for (int k = 0; k < DP_WORDS; k++) pv[k] = ptab[(t & 63) <= ns ? (t & 63) : ns][k];
+    // lane s: kind | hist/2 << 8 | odd-half offset << 16, and the region offset, of stage s
+    int pv0, pv1;
+    {
+        const int *row = ptab[(t & 63) <= ns ? (t & 63) : ns];
+        pv0 = row[DP_KIND] | (row[DP_HIST2] << 8) | (row[DP_OOFF] << 16);
+        pv1 = row[DP_ROFF];
+    }
+    const v2f step1 = phasor_of(cs.inc);                 // one sample of NCO rotation
+    v2f p0 = {1.f, 0.f}, p1 = {1.f, 0.f};
+    int anchor_rows = 0;                                 // rows until the phasors are re-anchored
 
     const v2f *in = a.in + (long)(a.in_rows ? a.in_rows[ch] : ch) * a.in_stride;
     v2f *out = a.out + (long)ch * a.out_stride;
@@ -138,7 +151,7 @@ void downconv_kernel(DcArgs a)
     long seg_end = seg_start + a.seg_len;
     if (seg_end > a.n_in) seg_end = a.n_in;
     const v2f rowstep = phasor_of(cs.inc * (unsigned long long)DC_ROW);
-    const float a_inf = a.amp[DC_AMP_N - 1];
+    const float a_inf = a.amp[DC_AMP_N - 1], inv_a_inf = 1.0f / a_inf;
 
     // The raw input of a tile is fetched into registers one tile ahead, while the previous tile goes
     // through the cascade: nothing waits on HBM latency except the very first tile.
@@ -182,23 +195,39 @@ void downconv_kernel(DcArgs a)
                 else r0[i >> 1] = v;
             }
         } else {
-            v2f p0 = {1.f, 0.f}, p1 = {1.f, 0.f};
+            // the phasors run on from tile to tile and are re-anchored every DC_ANCHOR_ROWS rows
+            // (and after a short tile, which breaks the row cadence)
+            // p0/p1 carry the steady-state amplitude a_inf
+            if (anchor_rows <= 0 || n != DC_TILE) {
+                p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(pos + 2 * t + 1)) * a_inf;
+                p1 = cmul(p0, step1);
+                anchor_rows = (n == DC_TILE) ? DC_ANCHOR_ROWS : 0;
+            }
+            anchor_rows -= NR;
+            // full tile, amplitude settled, no history to save: the lean path
+            const bool lean = ns > 0 && n == DC_TILE && cs.age + (unsigned long long)pos >= DC_AMP_N &&
+                              (warm || a.W == 0 || pos + n <= a.n_in - a.W);
+            if (lean) {
+                v2f *e = r0 + t, *o = r0o + t;
+#pragma unroll
+                for (int row = 0; row < NR; row++) {
+                    const v4f v = raw[row];
+                    e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
+                    o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
+                    p0 = cmul(p0, rowstep);
+                    p1 = cmul(p1, rowstep);
+                }
+            } else
 #pragma unroll
             for (int row = 0; row < NR; row++) {
                 const int i = row * DC_ROW + 2 * t;
                 const long gi = pos + i;                       // sample index within the call
-                if ((row & (DC_ANCHOR_ROWS - 1)) == 0) {
-                    p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(gi + 1));
-                    p1 = phasor_of(cs.phase + cs.inc * (unsigned long long)(gi + 2));
-                }
                 if (i < n) {
                     const v4f v = raw[row];
                     v2f x0 = cmul(v2f{v.x, v.y}, p0), x1 = cmul(v2f{v.z, v.w}, p1);
                     const unsigned long long age = cs.age + (unsigned long long)gi;
-                    if (age + 1 >= DC_AMP_N) {                  // wave-uniform except at the seam
-                        x0 *= a_inf; x1 *= a_inf;
-                    } else {
-                        x0 *= a.amp[age]; x1 *= a.amp[age + 1];
+                    if (age + 1 < DC_AMP_N) {                   // start-up envelope (the phasors carry a_inf)
+                        x0 *= a.amp[age] * inv_a_inf; x1 *= a.amp[age + 1] * inv_a_inf;
                     }
                     if (ns == 0) {
                         *reinterpret_cast<v4f *>(&r0[i]) = v4f{x0.x, x0.y, x1.x, x1.y};
@@ -221,18 +250,19 @@ void downconv_kernel(DcArgs a)
         // ---------------- the cascade, LDS -> LDS ---------------------------------------------
         int len = n;
         for (int s = 0; s < ns; s++) {
-            const v2f *E = lds + __builtin_amdgcn_readlane(pv[DP_ROFF], s), *O = E + __builtin_amdgcn_readlane(pv[DP_OOFF], s);
+            const int d0 = __builtin_amdgcn_readlane(pv0, s), dn = __builtin_amdgcn_readlane(pv0, s + 1);
+            const v2f *E = lds + __builtin_amdgcn_readlane(pv1, s), *O = E + (d0 >> 16);
             const bool last = s + 1 == ns;
-            const int hn2 = __builtin_amdgcn_readlane(pv[DP_HIST2], s + 1);      // 0 behind the last stage
-            v2f *yE = lds + __builtin_amdgcn_readlane(pv[DP_ROFF], s + 1) + hn2;
-            v2f *yO = yE + __builtin_amdgcn_readlane(pv[DP_OOFF], s + 1);
+            const int hn2 = (dn >> 8) & 0xff;                   // 0 behind the last stage
+            v2f *yE = lds + __builtin_amdgcn_readlane(pv1, s + 1) + hn2;
+            v2f *yO = yE + (dn >> 16);
             v2f *ylin = last ? yE : nullptr;
             const int nout = len >> 1;
-#define DC_CASE(LL) case LL: dc_stage<LL>(E, O, yE, yO, ylin, nout, pv, s, t); break;
-            switch (__builtin_amdgcn_readlane(pv[DP_KIND], s)) {
+#define DC_CASE(LL) case LL: dc_stage<LL>(E, O, yE, yO, ylin, nout, ptab[s], t); break;
+            switch (d0 & 0xff) {
             DC_CASE(3) DC_CASE(11) DC_CASE(15) DC_CASE(19) DC_CASE(23) DC_CASE(27) DC_CASE(31)
             DC_CASE(35) DC_CASE(39) DC_CASE(43) DC_CASE(47)
-            default: dc_stage<51>(E, O, yE, yO, ylin, nout, pv, s, t); break;
+            default: dc_stage<51>(E, O, yE, yO, ylin, nout, ptab[s], t); break;
             }
 #undef DC_CASE
             DC_TICK(8 + s);
@@ -241,8 +271,8 @@ void downconv_kernel(DcArgs a)
             len = nout;
         }
         // slide every stage's history at once: the last hist_s inputs of stage s (hist_s/2 per parity
-        // half) move to the front; 64 lanes per stage, 32 per half; read, barrier, write because a
-        // short tile overlaps source and target
+        // half) move to the front; one wave per stage (lanes 0-31 even half, 32-63 odd half); read,
+        // barrier, write because a short tile overlaps source and target
         {
             constexpr int R = (DC_MAX_STAGES * 64 + DC_T - 1) / DC_T;
             v2f keep[R];
@@ -250,12 +280,14 @@ void downconv_kernel(DcArgs a)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int u = t + r * DC_T, odd = (u >> 5) & 1, i = u & 31;
-                const int sg = __builtin_amdgcn_readfirstlane(u >> 6);       // one wave per stage
-                keep[r] = v2f{0.f, 0.f};
+                const int sg = __builtin_amdgcn_readfirstlane(u >> 6);
                 dst[r] = -1;
-                if (sg < ns && i < __builtin_amdgcn_readlane(pv[DP_HIST2], sg)) {
-                    dst[r] = __builtin_amdgcn_readlane(pv[DP_ROFF], sg) + (odd ? __builtin_amdgcn_readlane(pv[DP_OOFF], sg) : 0) + i;
-                    keep[r] = lds[dst[r] + (n >> (sg + 1))];
+                if (sg < ns) {
+                    const int d = __builtin_amdgcn_readlane(pv0, sg);
+                    if (i < ((d >> 8) & 0xff)) {
+                        dst[r] = __builtin_amdgcn_readlane(pv1, sg) + (odd ? (d >> 16) : 0) + i;
+                        keep[r] = lds[dst[r] + (n >> (sg + 1))];
+                    }
                 }
             }
             lds_barrier();

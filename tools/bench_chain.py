@@ -35,6 +35,9 @@ out["k2_ms"] = round(ms, 3)
 out["k2_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["k2_alg_GBps"] = round(C * T * (8 + 8 / 32) / ms / 1e6, 1)
 
+if os.environ.get('K2_ONLY'):
+    print(json.dumps(out)); sys.exit(0)
+
 def info(**kw):
     base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
                 FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
