@@ -430,6 +430,14 @@ class DemodInfo(C.Structure):
 DEMOD_AM, DEMOD_SAM, DEMOD_FM, DEMOD_USB, DEMOD_LSB, DEMOD_CWU, DEMOD_CWL = range(7)
 
 
+def fm_defaults():
+    """The GUI's FM demodulator settings (gui/mainwindow.cpp:442-452, 1019-1023)."""
+    return DemodInfo(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000,
+                     LowCutmax=-5000, FilterClickResolution=100, Offset=0, SquelchValue=0,
+                     AgcSlope=0, AgcThresh=-100, AgcManualGain=30, AgcDecay=200,
+                     AgcOn=1, AgcHangOn=0, Symetric=1)
+
+
 class CDemodulator(_Obj):
     """dsp/demodulator.h:56-100 -- the whole chain, host double buffers, reference call semantics."""
     _destroy = "csdr_demod_destroy"
