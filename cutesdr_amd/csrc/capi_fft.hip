@@ -22,6 +22,7 @@ struct csdr_fft_batch {
     int start_hz, stop_hz, bin_min, bin_max, plot_w;
     std::vector<int> xlat;
     float *d_win, *d_tw1, *d_tw2, *d_sum, *d_pwr, *d_ave;
+    float *d_work;                               // transform work space of the multi-launch sizes
     int *d_cnt, *d_over;
     std::vector<float> h_ave;
     std::vector<int> h_over;
@@ -29,7 +30,7 @@ struct csdr_fft_batch {
 
 static void fft_free_dev(csdr_fft_batch *f)
 {
-    float **ps[] = {&f->d_win, &f->d_tw1, &f->d_tw2, &f->d_sum, &f->d_pwr, &f->d_ave};
+    float **ps[] = {&f->d_win, &f->d_tw1, &f->d_tw2, &f->d_sum, &f->d_pwr, &f->d_ave, &f->d_work};
     for (auto p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
 }
 
@@ -50,9 +51,7 @@ static int fft_set_params(csdr_fft_batch *f, int size, int invert, double db_com
     if (f->db_comp != db_comp) { f->last_size = 0; f->db_comp = db_comp; }
     int n = size < 512 ? 512 : (size > 65536 ? 65536 : size);
     const int l2 = log2_of(n);
-    if (l2 < 11 || l2 > 14)
-        return fail(CSDR_EINVAL, "FFT size %d: this build transforms 2048..16384 points on the device "
-                    "(the reference accepts 512..65536)", n);
+    if (l2 < 0) return fail(CSDR_EINVAL, "FFT size %d is not a power of two", n);
     f->size = n;
     if (f->last_size != n) {
         f->last_size = n;
@@ -64,6 +63,7 @@ static int fft_set_params(csdr_fft_batch *f, int size, int invert, double db_com
         CSDR_HIP(hipMalloc((void **)&f->d_sum, nb));
         CSDR_HIP(hipMalloc((void **)&f->d_pwr, nb));
         CSDR_HIP(hipMalloc((void **)&f->d_ave, nb));
+        if (l2 < 11 || l2 > 14) CSDR_HIP(hipMalloc((void **)&f->d_work, nb * 4));   // [2][channels][N] complex
         CSDR_HIP(hipMemset(f->d_pwr, 0, nb));
         f->kb = f->db_comp - 20 * std::log10((double)n * 32767.0 / 2.0);
         f->kc = std::pow(10.0, (-220.0 - f->kb) / 10.0);
@@ -96,7 +96,7 @@ csdr_fft_batch *csdr_fft_batch_create(int device, int channels)
     csdr_fft_batch *f = new csdr_fft_batch();
     f->device = device; f->channels = channels;
     f->size = 1024; f->last_size = 0; f->ave_size = 1; f->invert = 0; f->db_comp = 0.0; f->fs = 1000;
-    f->d_win = f->d_tw1 = f->d_tw2 = f->d_sum = f->d_pwr = f->d_ave = nullptr;
+    f->d_win = f->d_tw1 = f->d_tw2 = f->d_sum = f->d_pwr = f->d_ave = f->d_work = nullptr;
     f->d_cnt = nullptr; f->d_over = nullptr;
     if (hipMalloc((void **)&f->d_cnt, sizeof(int) * 2 * channels) != hipSuccess ||
         hipMalloc((void **)&f->d_over, sizeof(int) * channels) != hipSuccess ||
@@ -148,7 +148,9 @@ int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long i
     a.sum = f->d_sum; a.pwr = f->d_pwr; a.ave = f->d_ave; a.counters = f->d_cnt; a.overload = f->d_over;
     a.channels = f->channels; a.nframes = nframes; a.ave_size = f->ave_size;
     a.kc = (float)f->kc; a.kb = f->kb;
-    CSDR_HIP(spectrum_launch(log2_of(f->size), a, (hipStream_t)stream));
+    const int l2 = log2_of(f->size);
+    if (l2 >= 11 && l2 <= 14) CSDR_HIP(spectrum_launch(l2, a, (hipStream_t)stream));
+    else CSDR_HIP(spectrum_generic_launch(l2, a, f->d_work, (hipStream_t)stream));
     return CSDR_OK;
 }
 /* copy of m_pFFTAveBuf of one channel (bels, display order), synchronises */
@@ -307,7 +309,9 @@ static int fft_plain(csdr_fft *f, double *inout, int sign)
     f->st.resize(2 * (size_t)N);
     for (size_t i = 0; i < 2 * (size_t)N; i++) f->st[i] = (float)inout[i];
     CSDR_HIP(hipMemcpy(f->d_buf, f->st.data(), (size_t)N * 8, hipMemcpyHostToDevice));
-    CSDR_HIP(fft_plain_launch(log2_of(N), sign, f->d_buf, f->d_buf, f->b->d_tw1, f->b->d_tw2, nullptr));
+    const int l2 = log2_of(N);
+    if (l2 >= 11 && l2 <= 14) CSDR_HIP(fft_plain_launch(l2, sign, f->d_buf, f->d_buf, f->b->d_tw1, f->b->d_tw2, nullptr));
+    else CSDR_HIP(fft_generic_plain_launch(l2, sign, f->d_buf, f->d_buf, f->b->d_work, nullptr));
     CSDR_HIP(hipMemcpy(f->st.data(), f->d_buf, (size_t)N * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < 2 * (size_t)N; i++) inout[i] = (double)f->st[i];
     return CSDR_OK;

@@ -1,0 +1,105 @@
+// fft_generic_kernels.hip -- CFft for the sizes outside the single-pass kernels' range
+// (512, 1024, 32768, 65536; the reference accepts 512..65536, dsp/fft.h:21-22, fft.cpp:140-145).
+//
+// These sizes are display-rate only (no FastFIR uses them), so the transform is a plain Stockham
+// autosort radix-2 through HBM: log2 N launches ping-ponging between two work buffers, natural
+// order in and out, twiddles from sincospi of an exact dyadic argument.  Window/swap, the running
+// power mean and the log10 of CFft::PutInDisplayFFT / CpxFFT (fft.cpp:267-288, 562-589) are two
+// element-wise kernels around it with exactly the arithmetic of spectrum_kernel.
+#include "fft_core.hpp"
+#include "spectrum_kernels.h"
+
+namespace csdr {
+
+// one radix-2 DIF Stockham pass over `batch` transforms of n0 points: the current sub-transform
+// length is n (m = n/2), the stride s = n0/n.  y[q + s(2p)] = a + b, y[q + s(2p+1)] = (a - b) w^p
+__global__ void stockham_pass_kernel(const v2f *x, v2f *y, int n0, int n, int s, float sign, long stride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;              // < n0/2
+    if (i >= n0 / 2) return;
+    x += (long)blockIdx.y * stride; y += (long)blockIdx.y * stride;
+    const int m = n >> 1, q = i & (s - 1), p = i / s;
+    const v2f a = x[q + s * p], b = x[q + s * (p + m)];
+    float sn, cs;
+    sincospif(2.0f * (float)p / (float)n, &sn, &cs);                   // p/n is dyadic: exact argument
+    const v2f w = {cs, sign * sn};
+    y[q + s * (2 * p)] = a + b;
+    y[q + s * (2 * p + 1)] = cmul(a - b, w);
+}
+
+// frame f of every channel: window, I/Q swap (fft.cpp:280-281), overload flag (fft.cpp:275-276)
+__global__ void spec_prep_kernel(SpectrumArgs a, int n, int frame, v2f *work, long wstride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (i >= n) return;
+    const v2f s = reinterpret_cast<const v2f *>(a.in)[(long)ch * a.in_stride + (long)frame * n + i];
+    const float w = a.win[i];
+    if (s.x > 32000.0f) a.overload[ch] = 1;
+    work[(long)ch * wstride + i] = v2f{w * s.y, w * s.x};
+}
+__global__ void spec_count_kernel(SpectrumArgs a)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.channels) return;
+    a.counters[2 * ch + 1]++;                                        // CpxFFT counters, fft.cpp:515-517
+    if (a.counters[2 * ch] < a.ave_size) a.counters[2 * ch]++;
+}
+// power, running mean, log10, display order (fft.cpp:564-589)
+__global__ void spec_finish_kernel(SpectrumArgs a, int n, const v2f *X, long wstride)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (k >= n) return;
+    const int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    const v2f v = X[(long)ch * wstride + k];
+    const int j = (k + n / 2) & (n - 1);
+    const long o = (long)ch * n + j;
+    const float p = v.x * v.x + v.y * v.y;
+    float sm = a.sum[o];
+    if (total <= a.ave_size) sm = sm + p;
+    else sm = sm - a.pwr[o] + p;
+    a.sum[o] = sm;
+    const float m = sm / (float)ave_count;
+    a.pwr[o] = m;
+    a.ave[o] = (float)((double)log10f(m + a.kc) + a.kb);
+}
+
+// transforms `batch` rows of work buffer A (stride wstride, B = A + half) ; returns where the result is
+static const v2f *stockham_run(int log2n, float sign, v2f *A, v2f *B, long wstride, int batch, hipStream_t st)
+{
+    const int n0 = 1 << log2n;
+    v2f *x = A, *y = B;
+    for (int n = n0, s = 1; n > 1; n >>= 1, s <<= 1) {
+        hipLaunchKernelGGL(stockham_pass_kernel, dim3(n0 / 2 / 256, batch), dim3(256), 0, st, x, y, n0, n, s, sign, wstride);
+        v2f *t = x; x = y; y = t;
+    }
+    return x;
+}
+
+// work: [2][channels][N] complex
+hipError_t spectrum_generic_launch(int log2n, const SpectrumArgs &a, float *work, hipStream_t st)
+{
+    const int n = 1 << log2n;
+    v2f *A = reinterpret_cast<v2f *>(work), *B = A + (long)a.channels * n;
+    for (int f = 0; f < a.nframes; f++) {
+        hipLaunchKernelGGL(spec_prep_kernel, dim3(n / 256, a.channels), dim3(256), 0, st, a, n, f, A, (long)n);
+        hipLaunchKernelGGL(spec_count_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, st, a);
+        const v2f *X = stockham_run(log2n, +1.0f, A, B, n, a.channels, st);
+        hipLaunchKernelGGL(spec_finish_kernel, dim3(n / 256, a.channels), dim3(256), 0, st, a, n, X, (long)n);
+    }
+    return hipGetLastError();
+}
+
+// plain N-point transform, natural order; `in` may equal `out`; work: [2][N] complex
+hipError_t fft_generic_plain_launch(int log2n, int sign, const float *in, float *out, float *work, hipStream_t st)
+{
+    const int n = 1 << log2n;
+    v2f *A = reinterpret_cast<v2f *>(work), *B = A + n;
+    hipError_t e = hipMemcpyAsync(A, in, (size_t)n * 8, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+    const v2f *X = stockham_run(log2n, sign > 0 ? 1.0f : -1.0f, A, B, n, 1, st);
+    e = hipMemcpyAsync(out, X, (size_t)n * 8, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace csdr

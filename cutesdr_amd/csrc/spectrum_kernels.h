@@ -21,4 +21,9 @@ hipError_t spectrum_launch(int log2n, const SpectrumArgs &a, hipStream_t stream)
 hipError_t fft_plain_launch(int log2n, int sign, const float *in, float *out, const float *tw1,
                             const float *tw2, hipStream_t stream);
 
+// sizes outside 2048..16384 (512, 1024, 32768, 65536): multi-launch transform through HBM.
+// work: [2][channels][N] complex for the spectrum, [2][N] for the plain transform
+hipError_t spectrum_generic_launch(int log2n, const SpectrumArgs &a, float *work, hipStream_t stream);
+hipError_t fft_generic_plain_launch(int log2n, int sign, const float *in, float *out, float *work, hipStream_t stream);
+
 }  // namespace csdr

@@ -532,7 +532,7 @@ class DemodBatch(_Obj):
 
 
 class CFft(_Obj):
-    """dsp/fft.h:24-85 -- display spectrum + plain transforms (device sizes 2048..16384)."""
+    """dsp/fft.h:24-85 -- display spectrum + plain transforms, 512..65536 points."""
     _destroy = "csdr_fft_destroy"
 
     def __init__(self, device=0):

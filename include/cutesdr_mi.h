@@ -248,9 +248,9 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
 
 /* ----------------------------------------------------------------------------------------
- * CFft -- display spectrum and plain transforms (dsp/fft.h:24-85).  FFT sizes 2048..16384 run on
- * the device in this build (the reference accepts 512..65536: set_params returns CSDR_EINVAL
- * outside that range).
+ * CFft -- display spectrum and plain transforms (dsp/fft.h:24-85).  FFT sizes 512..65536 as in
+ * the reference (clamped to that range, fft.cpp:140-145); a size that is not a power of two
+ * returns CSDR_EINVAL.
  * -------------------------------------------------------------------------------------- */
 typedef struct csdr_fft csdr_fft;
 csdr_fft *csdr_fft_create(int device);                                       /* fft.cpp:41-62 */

@@ -21,7 +21,7 @@ def assert_spectrum_close(got, want):
         assert err[rest].max() <= 0.05                       # 0.5 dB
 
 
-@pytest.mark.parametrize("n,ave", [(4096, 1), (2048, 4), (16384, 3)])
+@pytest.mark.parametrize("n,ave", [(4096, 1), (2048, 4), (16384, 3), (512, 2), (1024, 1), (32768, 2), (65536, 1)])
 def test_display_spectrum_matches_oracle(oracle, n, ave):
     import cutesdr_amd as ca
     fs = 2e6
@@ -35,12 +35,14 @@ def test_display_spectrum_matches_oracle(oracle, n, ave):
         got, want = f.ave_buf().astype(np.float64), r.ave_buf()
         assert_spectrum_close(got, want)
         assert np.argmax(got) == np.argmax(want)
-    ovg, pg = f.GetScreenIntegerFFTData(1 << 16, 700, 0.0, -160.0, -900000, 900000)
-    ovr, pr = r.GetScreenIntegerFFTData(1 << 16, 700, 0.0, -160.0, -900000, 900000)
+    w = min(700, n // 2)                                     # never more pixels than table entries (fft.cpp:165)
+    ovg, pg = f.GetScreenIntegerFFTData(1 << 16, w, 0.0, -160.0, -900000, 900000)
+    ovr, pr = r.GetScreenIntegerFFTData(1 << 16, w, 0.0, -160.0, -900000, 900000)
     assert ovg == ovr is False
     assert np.abs(pg - pr).max() <= 8                         # 65536 px over 160 dB: 0.02 dB per 8 px
-    ovg, pg = f.GetScreenIntegerFFTData(300, n - 1, 0.0, -220.0, -1000000, 1000000)   # more pixels than bins
-    ovr, pr = r.GetScreenIntegerFFTData(300, n - 1, 0.0, -220.0, -1000000, 1000000)
+    w = min(n - 1, 30000)             # pixel*bins stays inside the reference's 32-bit arithmetic (fft.cpp:355)
+    ovg, pg = f.GetScreenIntegerFFTData(300, w, 0.0, -220.0, -1000000, 1000000)   # more pixels than bins
+    ovr, pr = r.GetScreenIntegerFFTData(300, w, 0.0, -220.0, -1000000, 1000000)
     assert np.abs(pg - pr).max() <= 1
     big = x.copy(); big[5] = 32500.0
     f.PutInDisplayFFT(big); r.PutInDisplayFFT(big)
@@ -57,17 +59,20 @@ def test_display_anchor_c1():
     assert np.argmax(a) == 2560 and a[2560] == pytest.approx(-1.3982, abs=2e-4)
 
 
-def test_unsupported_sizes_fail_loudly():
+def test_size_clamp_and_bad_sizes():
+    # fft.cpp:140-145 clamps the size to 512..65536; a size that is not a power of two is refused
     import cutesdr_amd as ca
     from cutesdr_amd._capi import CsdrError
     f = ca.CFft()
+    f.SetFFTParams(64, False, 0.0, 48000.0)
+    assert f.size == 512
+    f.SetFFTParams(1 << 20, False, 0.0, 48000.0)
+    assert f.size == 65536
     with pytest.raises(CsdrError):
-        f.SetFFTParams(1024, False, 0.0, 48000.0)
-    with pytest.raises(CsdrError):
-        f.SetFFTParams(65536, False, 0.0, 48000.0)
+        f.SetFFTParams(3000, False, 0.0, 48000.0)
 
 
-@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
 def test_plain_transforms(oracle, n):
     import cutesdr_amd as ca
     rng = np.random.default_rng(n)
