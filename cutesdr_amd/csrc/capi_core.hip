@@ -1,5 +1,6 @@
 // capi_core.hip -- version, error text and device-memory helpers of the C ABI.
 #include "capi_common.hpp"
+#include <cstdlib>
 
 using namespace csdr;
 

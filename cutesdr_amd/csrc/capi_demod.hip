@@ -5,6 +5,7 @@
 #include "capi_common.hpp"
 #include "pc_unit.hpp"
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -30,8 +31,11 @@ struct ChainCore {
     csdr_downconvert_batch *dc = nullptr;
     csdr_fastfir_batch *ff = nullptr;
     PcUnit pc;
-    float *d_stage = nullptr, *d_filt = nullptr;
-    long cap = 0;                       // staging capacity per row (complex samples)
+    float *d_stage = nullptr, *d_filt = nullptr, *d_agc = nullptr;
+    long cap = 0;
+    // long calls run S-meter | AGC | demodulator as a pipeline of launches over burst groups
+    hipStream_t s_dem = nullptr, s_sm = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_dem = nullptr, ev_sm = nullptr, ev_agc[8] = {};                       // staging capacity per row (complex samples)
     int pending = 0;                    // decimated samples waiting for a full hop (same in every row)
     int last_out = 0;
 
@@ -41,6 +45,54 @@ struct ChainCore {
         if (ff) csdr_fastfir_batch_destroy(ff);
         if (d_stage) (void)hipFree(d_stage);
         if (d_filt) (void)hipFree(d_filt);
+        if (d_agc) (void)hipFree(d_agc);
+        if (s_dem) (void)hipStreamDestroy(s_dem);
+        if (s_sm) (void)hipStreamDestroy(s_sm);
+        for (hipEvent_t e : {ev_fork, ev_dem, ev_sm}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_agc) if (e) (void)hipEventDestroy(e);
+    }
+    int pipeline_init()
+    {
+        if (s_dem) return CSDR_OK;
+        CSDR_HIP(hipStreamCreateWithFlags(&s_dem, hipStreamNonBlocking));
+        CSDR_HIP(hipStreamCreateWithFlags(&s_sm, hipStreamNonBlocking));
+        CSDR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        CSDR_HIP(hipEventCreateWithFlags(&ev_dem, hipEventDisableTiming));
+        CSDR_HIP(hipEventCreateWithFlags(&ev_sm, hipEventDisableTiming));
+        for (auto &e : ev_agc) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return CSDR_OK;
+    }
+    // S-meter, AGC and demodulator of nb bursts.  Short calls: one fused launch.  Long calls: the
+    // S-meter on its own stream, AGC -> demodulator pipelined over burst groups through d_agc, so the
+    // three sequential recurrences of a channel overlap instead of adding up.
+    int post(const float *filt, float *d_out, long out_stride, const int *d_out_rows, bool stereo, int nb, hipStream_t s)
+    {
+        const int st = stereo ? PC_STEREO : 0;
+        static const bool pipelined = !(getenv("CSDR_CHAIN_PIPELINE") && atoi(getenv("CSDR_CHAIN_PIPELINE")) == 0);
+        if (nb < 16 || !pipelined)
+            return pc.run(PC_DO_SMETER | PC_DO_AGC | PC_DO_DEMOD | st, filt, cap, d_out, out_stride, nb, L, s, d_out_rows);
+        int rc = pipeline_init();
+        if (rc) return rc;
+        const int G = 8;
+        CSDR_HIP(hipEventRecord(ev_fork, s));
+        CSDR_HIP(hipStreamWaitEvent(s_sm, ev_fork, 0));
+        CSDR_HIP(hipStreamWaitEvent(s_dem, ev_fork, 0));
+        if ((rc = pc.run(PC_DO_SMETER, filt, cap, nullptr, 0, nb, L, s_sm, nullptr))) return rc;
+        for (int g = 0; g < G; g++) {
+            const int b0 = (int)((long)nb * g / G), b1 = (int)((long)nb * (g + 1) / G);
+            if (b1 == b0) continue;
+            const size_t off = (size_t)b0 * L;
+            if ((rc = pc.run(PC_DO_AGC, filt + 2 * off, cap, d_agc + 2 * off, cap, b1 - b0, L, s, nullptr))) return rc;
+            CSDR_HIP(hipEventRecord(ev_agc[g], s));
+            CSDR_HIP(hipStreamWaitEvent(s_dem, ev_agc[g], 0));
+            if ((rc = pc.run(PC_DO_DEMOD | st, d_agc + 2 * off, cap, d_out + (stereo ? 2 : 1) * off, out_stride,
+                             b1 - b0, L, s_dem, d_out_rows))) return rc;
+        }
+        CSDR_HIP(hipEventRecord(ev_dem, s_dem));
+        CSDR_HIP(hipEventRecord(ev_sm, s_sm));
+        CSDR_HIP(hipStreamWaitEvent(s, ev_dem, 0));
+        CSDR_HIP(hipStreamWaitEvent(s, ev_sm, 0));
+        return CSDR_OK;
     }
     int init(int dev, int nrows, int n)
     {
@@ -54,15 +106,17 @@ struct ChainCore {
     {
         if (need <= cap) return CSDR_OK;
         need = (need + L + 1023) / 1024 * 1024;
-        float *ns = nullptr, *nf = nullptr;
+        float *ns = nullptr, *nf = nullptr, *na = nullptr;
         CSDR_HIP(hipMalloc((void **)&ns, (size_t)rows * need * 8));
         CSDR_HIP(hipMalloc((void **)&nf, (size_t)rows * need * 8));
+        CSDR_HIP(hipMalloc((void **)&na, (size_t)rows * need * 8));
         if (d_stage && pending > 0)
             CSDR_HIP(hipMemcpy2D(ns, (size_t)need * 8, d_stage, (size_t)cap * 8, (size_t)pending * 8, rows,
                                  hipMemcpyDeviceToDevice));
         if (d_stage) (void)hipFree(d_stage);
         if (d_filt) (void)hipFree(d_filt);
-        d_stage = ns; d_filt = nf; cap = need;
+        if (d_agc) (void)hipFree(d_agc);
+        d_stage = ns; d_filt = nf; d_agc = na; cap = need;
         return CSDR_OK;
     }
     // one pass of the chain over n input samples per row (demodulator.cpp:172-207); returns the
@@ -82,8 +136,7 @@ struct ChainCore {
         if (nb > 0) {
             rc = csdr_fastfir_batch_process(ff, d_stage, cap, nb * L, d_filt, cap, s, 0);
             if (rc) return rc;
-            rc = pc.run(PC_DO_SMETER | PC_DO_AGC | PC_DO_DEMOD | (stereo ? PC_STEREO : 0), d_filt, cap, d_out,
-                        out_stride, nb, L, s, d_out_rows);
+            rc = post(d_filt, d_out, out_stride, d_out_rows, stereo, nb, s);
             if (rc) return rc;
             const int rest = total - nb * L;
             if (rest > 0) {

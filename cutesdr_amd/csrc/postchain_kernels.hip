@@ -616,12 +616,17 @@ void postchain_kernel(PcArgs a)
             else { fw->zr[i] = S.w0[i]; fw->zi[i] = mode == PC_MODE_AM ? S.w0[i] : S.w1[i]; }
         }
     }
+    // each stage writes only its own state: the stages of one channel may run as separate,
+    // concurrent launches (S-meter | AGC | demodulator pipeline of the batch chain)
     if (lane == 0) {
-        C.sm = sm; C.agc = agc;
-        C.am.z1 = am_z1;
-        C.sam.z1 = sam_z1; C.sam.y1 = sam_y1; C.sam.phase = sam_ph; C.sam.freq = sam_fr;
-        C.fm.phase = fm_ph; C.fm.freq = fm_fr; C.fm.err_dc = fm_dc; C.fm.sq_ave = fm_sq; C.fm.squelched = fm_squelched;
-        C.fm.lp = lp;
+        if (do_sm) C.sm = sm;
+        if (do_agc) C.agc = agc;
+        if (mode == PC_MODE_AM) C.am.z1 = am_z1;
+        if (mode == PC_MODE_SAM) { C.sam.z1 = sam_z1; C.sam.y1 = sam_y1; C.sam.phase = sam_ph; C.sam.freq = sam_fr; }
+        if (mode == PC_MODE_FM) {
+            C.fm.phase = fm_ph; C.fm.freq = fm_fr; C.fm.err_dc = fm_dc; C.fm.sq_ave = fm_sq; C.fm.squelched = fm_squelched;
+            C.fm.lp = lp;
+        }
     }
 }
 

@@ -219,3 +219,35 @@ def test_demod_batch_mixed_modes(oracle):
                 assert np.abs(got[c][-k:] - want[-k:]).max() <= 1e-3 * FULL_SCALE, (c, names[c])
     for c in range(C):
         assert b.smeter_ave(c) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02)
+
+
+def test_batch_long_calls_use_the_stage_pipeline(oracle):
+    """Calls of >= 16 FastFIR hops run S-meter | AGC | demodulator as concurrent launches over burst
+    groups (capi_demod.hip ChainCore::post): same results as the fused launch / the oracle, whole
+    second call compared (the first one holds the lock-in transient)."""
+    import cutesdr_amd as ca
+    fs, C = 2e6, 4
+    names = ["FM", "USB", "SAM", "AM"]
+    b = ca.DemodBatch(C, 2048)
+    b.set_input_rate(fs)
+    refs = []
+    for c, name in enumerate(names):
+        m, kw = MODES[name]
+        b.set_demod(c, m, info(ca, **kw))
+        r = oracle.CDemodulator(2048)
+        r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-100e3 - 1000.0 * c)
+        refs.append(r)
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -100e3 - 1000.0 * c)
+    n = 19968 * 64                                            # FM/USB: 39 hops per call, AM/SAM: 19
+    x = np.stack([make_input(names[c], 2 * n, fs) * np.exp(2j * np.pi * 1000.0 * c * np.arange(2 * n) / fs) for c in range(C)])
+    for call, part in enumerate((x[:, :n], x[:, n:])):
+        got = b.process(part)
+        for c in range(C):
+            want = refs[c].process_append(part[c])
+            assert len(got[c]) == len(want) >= 16 * 1024, (c, names[c])
+            if call == 1:
+                assert np.abs(got[c] - want).max() <= 1e-3 * FULL_SCALE, (c, names[c])
+    for c in range(C):
+        assert b.smeter_ave(c) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02)

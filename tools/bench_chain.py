@@ -5,6 +5,8 @@ config C4's per-GPU share -- 256 channels x 2^21 samples at 2 MSPS.
   chain  full CDemodulator batch (mixed AM/FM/USB), FastFIR 2048: input MS/s
 Prints one JSON line."""
 import json, sys, time, os
+# the chain overlaps launches on several streams; HIP's default of 4 hardware queues serialises some of them
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cutesdr_amd as ca
@@ -65,4 +67,5 @@ out["chain_ms"] = round(ms, 3)
 out["chain_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["chain_alg_GBps"] = round(C * T * (8 + 4 / 32) / ms / 1e6, 1)
 out["channels"] = C
+out["hw_queues"] = os.environ["GPU_MAX_HW_QUEUES"]
 print(json.dumps(out))
