@@ -1,0 +1,34 @@
+// frontend_kernels.h -- launch interface of the input-rate stages in front of the down-converter
+// (SURVEY 8(f) rows f1, f2): noise blanker, wire-format unpack, DC (NCO spur) estimate.  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace csdr {
+
+constexpr int NB_HIST = 32768;          // raw samples kept per channel between calls (>= MAX_AVE, noiseproc.cpp:51)
+constexpr int NB_MAX_WIDTH = 4096;      // noiseproc.cpp:49
+
+struct NbChan {                         // CNoiseProc state (dsp/noiseproc.h:36-52), stream form
+    int on, delay_n, mag_n, width_n;    // m_On, m_DelaySamples, m_MagSamples, m_WidthSamples
+    double ratio;                       // m_Ratio
+    double sum;                         // m_MagAveSum
+    long long since_trig;               // samples since the last trigger (>= width_n: not blanking)
+};
+
+struct NbArgs {
+    NbChan *chan;                       // [channels]
+    const float *in;  long in_stride;   // complex fp32 [channels][in_stride]
+    float *out;       long out_stride;  // complex fp32 [channels][out_stride]; may alias `in` only if hist is kept
+    const float *hist; float *hist_next;    // [channels][NB_HIST] complex: the last NB_HIST inputs, ping-pong
+    int channels, n;
+};
+hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream);
+
+// packets: [channels][npackets][pkt_len] bytes, pkt_len 1028 (16 bit, 256 samples) or 1444 (24 bit, 240);
+// out complex fp32 [channels][out_stride]; dc: optional [channels][2] doubles subtracted (I, Q)
+hipError_t unpack_launch(const unsigned char *pk, long chan_stride_bytes, int channels, int npackets, int pkt_len,
+                         float *out, long out_stride, const double *dc, hipStream_t stream);
+// dc[ch] <- running means of I and Q over n more samples, alpha = 1e-5 (sdrinterface.cpp:829-848)
+hipError_t spurcal_launch(const float *iq, long in_stride, int channels, int n, double *dc, hipStream_t stream);
+
+}  // namespace csdr

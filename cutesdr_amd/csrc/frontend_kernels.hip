@@ -1,0 +1,202 @@
+// frontend_kernels.hip -- the input-rate stages in front of the down-converter.
+//
+// noiseblank_kernel replaces CNoiseProc::ProcessBlanker (dsp/noiseproc.cpp:121-176).  The reference
+// loop looks sequential (running sum, blank counter) but carries no true recurrence:
+//   mag_i   = max(|re_i|, |im_i|)
+//   S_i     = sum of the last mag_n+1 magnitudes           (moving sum, :143-147)
+//   trig_i  = mag_i * ratio > S_i                          (:155-158)
+//   blank_i = a trigger among the last width_n samples     (the counter reloaded by each trigger, :160-166)
+//   out_i   = blank_i ? 0 : x_{i-delay_n-1}                (delay ring of delay_n+1 entries, :150-153)
+// so S is S_start + prefix-sum(mag_i - mag_{i-mag_n-1}) in fp64 and the blank window is a prefix-max
+// of trigger positions: one workgroup per channel walks the call in 1024-sample tiles with two block
+// scans per tile.  Samples older than the call come from a per-channel history of the last NB_HIST
+// raw inputs.
+//
+// unpack_kernel replaces the datagram conversion loops of CUdpThread::OnreadyRead
+// (interface/netiobase.cpp:497-503, 521-526); spurcal_kernel the running I/Q means of
+// CSdrInterface::NcoSpurCalibrate (interface/sdrinterface.cpp:829-848).
+#include "frontend_kernels.h"
+
+namespace csdr {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int NB_T = 256, NB_PER = 4, NB_TILE = NB_T * NB_PER;
+
+__device__ __forceinline__ double wave_incl_scan_add(double v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
+__device__ __forceinline__ long long wave_incl_scan_max(long long v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(v, d); if (lane >= d && o > v) v = o; }
+    return v;
+}
+
+__global__ __launch_bounds__(NB_T)
+void noiseblank_kernel(NbArgs a)
+{
+    __shared__ double wsum[NB_T / 64];
+    __shared__ long long wmax[NB_T / 64];
+    const int ch = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    NbChan &C = a.chan[ch];
+    const f2 *in = reinterpret_cast<const f2 *>(a.in) + (long)ch * a.in_stride;
+    f2 *out = reinterpret_cast<f2 *>(a.out) + (long)ch * a.out_stride;
+    const f2 *hist = reinterpret_cast<const f2 *>(a.hist) + (long)ch * NB_HIST;
+    f2 *hist_next = reinterpret_cast<f2 *>(a.hist_next) + (long)ch * NB_HIST;
+    const int n = a.n;
+    auto X = [&](long i) -> f2 { return i >= 0 ? in[i] : hist[NB_HIST + i]; };   // i >= -NB_HIST
+
+    if (C.on) {
+        const int M1 = C.mag_n + 1, D1 = C.delay_n + 1, W = C.width_n;
+        const double ratio = C.ratio;
+        double S0 = C.sum;
+        long long last = -C.since_trig;                    // index of the last trigger, relative to this call
+        for (int base = 0; base < n; base += NB_TILE) {
+            f2 xd[NB_PER];
+            float mag[NB_PER];
+            double d[NB_PER], run = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB_PER; k++) {
+                const long i = base + t * NB_PER + k;
+                mag[k] = 0.f; d[k] = 0.0; xd[k] = f2{0.f, 0.f};
+                if (i < n) {
+                    const f2 x = in[i], xo = X(i - M1);
+                    xd[k] = X(i - D1);
+                    mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
+                    d[k] = (double)mag[k] - (double)fmaxf(fabsf(xo.x), fabsf(xo.y));
+                }
+                run += d[k];
+                d[k] = run;                                // thread-local inclusive prefix
+            }
+            const double incl = wave_incl_scan_add(run, lane);
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            double off = S0 + (incl - run);
+            for (int q = 0; q < w; q++) off += wsum[q];
+            double total = 0.0;
+            for (int q = 0; q < NB_T / 64; q++) total += wsum[q];
+            // triggers and the position of the latest one at or before each sample
+            long long lt[NB_PER], runmax = -(1LL << 60);
+#pragma unroll
+            for (int k = 0; k < NB_PER; k++) {
+                const long i = base + t * NB_PER + k;
+                const bool trig = i < n && (double)mag[k] * ratio > off + d[k];
+                if (trig) runmax = i;
+                lt[k] = runmax;
+            }
+            const long long inclm = wave_incl_scan_max(runmax, lane);
+            if (lane == 63) wmax[w] = inclm;
+            __syncthreads();
+            long long before = last;                       // latest trigger before this thread's samples
+            for (int q = 0; q < w; q++) before = wmax[q] > before ? wmax[q] : before;
+            const long long upto = __shfl_up(inclm, 1);
+            if (lane > 0 && upto > before) before = upto;
+            long long tile_last = last;
+            for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
+#pragma unroll
+            for (int k = 0; k < NB_PER; k++) {
+                const long i = base + t * NB_PER + k;
+                if (i < n) {
+                    const long long l = lt[k] > before ? lt[k] : before;
+                    out[i] = (i - l < W) ? f2{0.f, 0.f} : xd[k];
+                }
+            }
+            S0 += total;
+            last = tile_last;
+            __syncthreads();                               // wsum / wmax reused by the next tile
+        }
+        if (t == 0) {
+            C.sum = S0;
+            long long age = (long long)n - last;
+            if (age > (1LL << 40)) age = 1LL << 40;
+            C.since_trig = age;
+        }
+    } else if (a.out != a.in) {
+        for (long i = t; i < n; i += NB_T) out[i] = in[i];  // off: the data passes through (:125-129)
+    }
+    // the last NB_HIST inputs of [history | this call] are the next call's history
+    for (long j = t; j < NB_HIST; j += NB_T) hist_next[j] = X((long)n - NB_HIST + j);
+}
+
+hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(noiseblank_kernel, dim3(a.channels), dim3(NB_T), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------- wire format -> complex fp32 ----------------
+__global__ void unpack_kernel(const unsigned char *pk, long chan_stride, int npackets, int pkt_len, int per,
+                              float *out, long out_stride, const double *dc)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // complex sample within the channel
+    const int ch = blockIdx.y;
+    if (i >= (long)npackets * per) return;
+    const long p = i / per;
+    const int j = (int)(i - p * per);
+    const unsigned char *b = pk + (long)ch * chan_stride + p * pkt_len + 4;
+    float re, im;
+    if (pkt_len == 1444) {                                            // 24 bit: << 8 into an int32, / 65536
+        b += 6 * j;
+        const int vi = (int)(((unsigned)b[0] << 8) | ((unsigned)b[1] << 16) | ((unsigned)b[2] << 24));
+        const int vq = (int)(((unsigned)b[3] << 8) | ((unsigned)b[4] << 16) | ((unsigned)b[5] << 24));
+        re = (float)vi * (1.0f / 65536.0f); im = (float)vq * (1.0f / 65536.0f);   // exact: 24 significant bits
+    } else {                                                          // 16 bit
+        b += 4 * j;
+        re = (float)(short)((unsigned short)b[0] | ((unsigned short)b[1] << 8));
+        im = (float)(short)((unsigned short)b[2] | ((unsigned short)b[3] << 8));
+    }
+    if (dc) { re = (float)((double)re - dc[2 * ch]); im = (float)((double)im - dc[2 * ch + 1]); }
+    float *o = out + 2 * ((long)ch * out_stride + i);
+    o[0] = re; o[1] = im;
+}
+
+hipError_t unpack_launch(const unsigned char *pk, long chan_stride_bytes, int channels, int npackets, int pkt_len,
+                         float *out, long out_stride, const double *dc, hipStream_t stream)
+{
+    const int per = pkt_len == 1444 ? 240 : 256;
+    const long tot = (long)npackets * per;
+    if (tot == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((tot + 255) / 256), channels), dim3(256), 0, stream,
+                       pk, chan_stride_bytes, npackets, pkt_len, per, out, out_stride, dc);
+    return hipGetLastError();
+}
+
+// ---------------- NCO spur (DC) estimate ----------------
+// y_n = (1-a)^n y_0 + a * sum_k (1-a)^(n-1-k) x_k : a weighted reduction, one workgroup per channel
+__global__ __launch_bounds__(256)
+void spurcal_kernel(const float *iq, long in_stride, int n, double *dc)
+{
+    __shared__ double red[2][256];
+    const int ch = blockIdx.x, t = threadIdx.x;
+    const f2 *x = reinterpret_cast<const f2 *>(iq) + (long)ch * in_stride;
+    const double a = 1.0 / 100000.0, l1 = log1p(-a);
+    double si = 0.0, sq = 0.0;
+    for (long k = t; k < n; k += 256) {
+        const double wgt = exp(l1 * (double)(n - 1 - k));
+        const f2 v = x[k];
+        si += wgt * (double)v.x; sq += wgt * (double)v.y;
+    }
+    red[0][t] = si; red[1][t] = sq;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double decay = exp(l1 * (double)n);
+        dc[2 * ch] = decay * dc[2 * ch] + a * red[0][0];
+        dc[2 * ch + 1] = decay * dc[2 * ch + 1] + a * red[1][0];
+    }
+}
+
+hipError_t spurcal_launch(const float *iq, long in_stride, int channels, int n, double *dc, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(spurcal_kernel, dim3(channels), dim3(256), 0, stream, iq, in_stride, n, dc);
+    return hipGetLastError();
+}
+
+}  // namespace csdr

@@ -275,6 +275,81 @@ class CAgc(_Obj):
         return out
 
 
+class CNoiseProc(_Obj):
+    """dsp/noiseproc.h:23-58 -- impulse blanker in front of the down-converter"""
+    _destroy = "csdr_noiseproc_destroy"
+
+    def __init__(self, device=0):
+        self.h = check_ptr(lib().csdr_noiseproc_create(device), "csdr_noiseproc_create")
+
+    def SetupBlanker(self, On, Threshold, Width, SampleRate):
+        check(lib().csdr_noiseproc_setup(self.h, int(On), Threshold, Width, SampleRate), "csdr_noiseproc_setup")
+
+    def ProcessBlanker(self, x):
+        a = _c128(x); out = np.empty_like(a)
+        check(lib().csdr_noiseproc_process(self.h, len(a), _vp(a), _vp(out)), "csdr_noiseproc_process")
+        return out
+
+
+class NoiseProcBatch(_Obj):
+    """device-resident blanker over [channels][n] complex fp32"""
+    _destroy = "csdr_noiseproc_batch_destroy"
+
+    def __init__(self, channels, device=0):
+        self.device, self.channels = device, channels
+        self.h = check_ptr(lib().csdr_noiseproc_batch_create(device, channels), "csdr_noiseproc_batch_create")
+
+    def setup(self, On, Threshold, Width, SampleRate, channel=-1):
+        check(lib().csdr_noiseproc_batch_setup(self.h, channel, int(On), Threshold, Width, SampleRate))
+
+    def process_ptr(self, d_in, in_stride, n, d_out, out_stride, stream=0):
+        check(lib().csdr_noiseproc_batch_process(self.h, C.c_void_p(d_in), in_stride, n, C.c_void_p(d_out), out_stride,
+                                                 C.c_void_p(stream)), "csdr_noiseproc_batch_process")
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        assert x.shape[0] == self.channels
+        n = x.shape[1]
+        din, dout = DeviceBuffer(x.nbytes, self.device), DeviceBuffer(x.nbytes, self.device)
+        din.upload(x)
+        self.process_ptr(din.ptr, n, n, dout.ptr, n)
+        sync(self.device)
+        return dout.download(np.complex64, x.size).reshape(x.shape)
+
+
+def unpack_packets(raw, pkt_len, device=0):
+    """UDP datagrams (uint8 [npackets, pkt_len], 1028 = 16 bit / 1444 = 24 bit) -> complex128 samples
+    (interface/netiobase.cpp:479-527)"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1, pkt_len)
+    per = 240 if pkt_len == 1444 else 256
+    out = np.empty(raw.shape[0] * per, dtype=np.complex128)
+    k = check(lib().csdr_ingest_unpack_host(device, _vp(raw), raw.shape[0], pkt_len, _vp(out)), "csdr_ingest_unpack_host")
+    return out[:k]
+
+
+def unpack_packets_batch(raw, pkt_len, dc=None, device=0):
+    """raw uint8 [channels, npackets, pkt_len] -> complex64 [channels, samples]; dc: optional [channels, 2] offsets"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    ch, npk = raw.shape[0], raw.shape[1]
+    per = 240 if pkt_len == 1444 else 256
+    dp, do = DeviceBuffer(raw.nbytes, device), DeviceBuffer(ch * npk * per * 8, device)
+    dp.upload(raw)
+    ddc = None
+    if dc is not None:
+        ddc = DeviceBuffer(ch * 16, device); ddc.upload(np.ascontiguousarray(dc, dtype=np.float64))
+    check(lib().csdr_ingest_unpack(device, C.c_void_p(dp.ptr), ch, npk, pkt_len, C.c_void_p(do.ptr), npk * per,
+                                   C.c_void_p(ddc.ptr if ddc else 0), C.c_void_p(0)), "csdr_ingest_unpack")
+    sync(device)
+    return do.download(np.complex64, ch * npk * per).reshape(ch, npk * per)
+
+
+def spurcal(dc, x, device=0):
+    """NcoSpurCalibrate running I/Q means (interface/sdrinterface.cpp:829-848); returns the new [I, Q]"""
+    a = _c128(x); d = np.ascontiguousarray(dc, dtype=np.float64).copy()
+    check(lib().csdr_ingest_spurcal_host(device, len(a), _vp(a), _vp(d)), "csdr_ingest_spurcal_host")
+    return d
+
+
 class CSMeter(_Obj):
     """dsp/smeter.h:13-28"""
     _destroy = "csdr_smeter_destroy"

@@ -299,6 +299,47 @@ int csdr_resampler_resample_real_i16(csdr_resampler *r, int n, double rate, cons
 int csdr_resampler_resample_cpx_i16(csdr_resampler *r, int n, double rate, const double *in_iq, short *out_lr,
                                     double gain);                            /* :194-249 */
 
+/* ----------------------------------------------------------------------------------------
+ * Input-rate stages in front of the down-converter
+ *
+ * CNoiseProc (dsp/noiseproc.h:23-58): impulse blanker.  setup = SetupBlanker (noiseproc.cpp:78-119,
+ * including its quirk that a change of the sample rate alone is ignored); process =
+ * ProcessBlanker (:121-176).  Returns CSDR_EINVAL for sample rates whose 5 ms magnitude window
+ * does not fit the reference's 32768-entry buffer (the reference overruns it).
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_noiseproc csdr_noiseproc;
+csdr_noiseproc *csdr_noiseproc_create(int device);                           /* noiseproc.cpp:59-65 */
+void csdr_noiseproc_destroy(csdr_noiseproc *p);
+int csdr_noiseproc_setup(csdr_noiseproc *p, int on, double threshold, double width_us, double sample_rate);
+/* n complex doubles in, n out (in == out allowed, as the host calls it: sdrinterface.cpp:884) */
+int csdr_noiseproc_process(csdr_noiseproc *p, int n, const double *in_iq, double *out_iq);
+
+/* device-resident batch form: [channels][stride] complex fp32; d_out must not alias d_in */
+typedef struct csdr_noiseproc_batch csdr_noiseproc_batch;
+csdr_noiseproc_batch *csdr_noiseproc_batch_create(int device, int channels);
+void csdr_noiseproc_batch_destroy(csdr_noiseproc_batch *b);
+/* channel < 0: every channel */
+int csdr_noiseproc_batch_setup(csdr_noiseproc_batch *b, int channel, int on, double threshold, double width_us,
+                               double sample_rate);
+int csdr_noiseproc_batch_process(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                                 float *d_out, long long out_stride, void *stream);
+
+/* IQ wire format (interface/netiobase.cpp:479-527): whole UDP datagrams, 4 header bytes then
+ * little-endian I,Q pairs; pkt_len 1028 = 256 samples of 16 bit, 1444 = 240 samples of 24 bit
+ * (scaled onto the 16-bit range).  d_packets: [channels][npackets][pkt_len] bytes on the device;
+ * d_out: [channels][out_stride] complex fp32; d_dc: optional [channels][2] doubles (I, Q offsets,
+ * subtracted as CSdrInterface::ProcessIQData does for the display path, sdrinterface.cpp:889-894).
+ * Returns the complex samples written per channel. */
+int csdr_ingest_unpack(int device, const void *d_packets, int channels, int npackets, int pkt_len, float *d_out,
+                       long long out_stride, const double *d_dc, void *stream);
+/* host form of the same conversion: packets in host memory, complex doubles out */
+int csdr_ingest_unpack_host(int device, const void *packets, int npackets, int pkt_len, double *out_iq);
+/* CSdrInterface::NcoSpurCalibrate (sdrinterface.cpp:829-848): d_dc[ch][0..1] <- running I/Q means
+ * (alpha 1e-5) advanced over n more samples of each row of d_iq */
+int csdr_ingest_spurcal(int device, const float *d_iq, long long in_stride, int channels, int n, double *d_dc,
+                        void *stream);
+int csdr_ingest_spurcal_host(int device, int n, const double *in_iq, double *dc_iq);
+
 #ifdef __cplusplus
 }
 #endif

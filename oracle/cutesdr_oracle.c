@@ -8,6 +8,7 @@
 #include "cutesdr_oracle.h"
 #include "../include/csdr_hb_taps.h"
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1279,4 +1280,97 @@ int orc_demod_process_mono_append(orc_demod *d, int n, const orc_cpx *in, double
         if (d->pos >= d->limit) ret += demod_chain(d, 0, out + ret, NULL);
     }
     return ret;
+}
+
+/* ==================================================================================== */
+/* CNoiseProc::ProcessBlanker  (dsp/noiseproc.cpp:78-176)  -- SURVEY 8(f) row f1           */
+/* ==================================================================================== */
+#define NB_MAX_WIDTH 4096      /* noiseproc.cpp:49-51 */
+#define NB_MAX_DELAY 4096
+#define NB_MAX_AVE 32768
+struct orc_noiseproc {
+    int on, dptr, mptr, blank, delay_n, mag_n, width_n, configured;
+    double thresh, width, fs, ratio, sum;
+    double dly[2 * NB_MAX_DELAY], mag[NB_MAX_AVE];
+};
+orc_noiseproc *orc_noiseproc_new(void)
+{
+    orc_noiseproc *p = (orc_noiseproc *)zalloc(sizeof(*p));
+    p->thresh = -1;                                      /* ctor: SetupBlanker(false, 50, 2, 1000), :66 */
+    orc_noiseproc_setup(p, 0, 50.0, 2.0, 1000.0);
+    return p;
+}
+void orc_noiseproc_free(orc_noiseproc *p) { free(p); }
+int orc_noiseproc_setup(orc_noiseproc *p, int on, double thresh, double width, double fs)
+{
+    /* :80-86: returns early when threshold, width and on are unchanged -- the sample-rate term of
+     * the test is `SampleRate==SampleRate`, always true, so a rate-only change is ignored */
+    if (p->configured && thresh == p->thresh && width == p->width && p->on == on) return 0;
+    p->configured = 1;
+    p->on = on; p->thresh = thresh; p->width = width; p->fs = fs;
+    p->width_n = (int)(width * 1e-6 * fs);               /* :92-96 */
+    if (p->width_n < 1) p->width_n = 1;
+    else if (p->width_n > NB_MAX_WIDTH) p->width_n = NB_MAX_WIDTH;
+    p->mag_n = (int)(0.005 * fs);                        /* MAGAVE_TIME, :98 */
+    if (p->mag_n > NB_MAX_AVE - 1) return -1;            /* the reference would overrun m_MagBuf here */
+    p->ratio = .005 * thresh * (double)p->mag_n;         /* :100 */
+    p->delay_n = p->width_n / 2;                         /* :102 */
+    p->dptr = p->mptr = p->blank = 0; p->sum = 0.0;
+    memset(p->dly, 0, sizeof(p->dly)); memset(p->mag, 0, sizeof(p->mag));
+    return 1;
+}
+/* in place allowed (the host calls it in place, sdrinterface.cpp:884); off: output untouched (:125-129) */
+void orc_noiseproc_process(orc_noiseproc *p, int n, const double *in, double *out)
+{
+    int i;
+    if (!p->on) return;
+    for (i = 0; i < n; i++) {
+        const double re = in[2 * i], im = in[2 * i + 1];
+        const double mre = fabs(re), mim = fabs(im), mag = (mre > mim) ? mre : mim;   /* :137-139 */
+        double ore, oim;
+        p->sum -= p->mag[p->mptr];                       /* :143-147: moving sum over mag_n+1 entries */
+        p->sum += mag;
+        p->mag[p->mptr++] = mag;
+        if (p->mptr > p->mag_n) p->mptr = 0;
+        ore = p->dly[2 * p->dptr]; oim = p->dly[2 * p->dptr + 1];      /* :150-153: delay of delay_n+1 */
+        p->dly[2 * p->dptr] = re; p->dly[2 * p->dptr + 1] = im;
+        if (++p->dptr > p->delay_n) p->dptr = 0;
+        if (mag * p->ratio > p->sum) p->blank = p->width_n;            /* :155-158 */
+        if (p->blank) { p->blank--; out[2 * i] = 0.0; out[2 * i + 1] = 0.0; }   /* :160-166 */
+        else { out[2 * i] = ore; out[2 * i + 1] = oim; }
+    }
+}
+
+/* ==================================================================================== */
+/* IQ wire format -> samples  (interface/netiobase.cpp:479-527)  -- SURVEY 8(f) row f2      */
+/* ==================================================================================== */
+/* one UDP packet: 4 header bytes, then little-endian I,Q,I,Q...; 1028 bytes = 256 samples of
+ * 16 bit, 1444 bytes = 240 samples of 24 bit scaled by 1/256 onto the 16-bit range.
+ * Returns the number of complex samples written, -1 for any other packet length. */
+int orc_unpack_packet(const unsigned char *pkt, int len, double *out)
+{
+    int i, j;
+    if (len == 1444) {
+        for (i = 4, j = 0; i < len; i += 3, j++) {
+            const uint32_t u = ((uint32_t)pkt[i] << 8) | ((uint32_t)pkt[i + 1] << 16) | ((uint32_t)pkt[i + 2] << 24);
+            out[j] = (double)(int32_t)u / 65536.0;       /* :497-503 */
+        }
+        return j / 2;
+    }
+    if (len == 1028) {
+        for (i = 4, j = 0; i < len; i += 2, j++)
+            out[j] = (double)(int16_t)((uint16_t)pkt[i] | ((uint16_t)pkt[i + 1] << 8));   /* :521-526 */
+        return j / 2;
+    }
+    return -1;
+}
+/* CSdrInterface::NcoSpurCalibrate (interface/sdrinterface.cpp:829-848): running I/Q means,
+ * alpha = 1e-5, over interleaved doubles; dc[0] = I offset, dc[1] = Q offset */
+void orc_spurcal(double *dc, int n_doubles, const double *data)
+{
+    int i;
+    for (i = 0; i < n_doubles; i++) {
+        if (i & 1) dc[1] = (1.0 - 1.0 / 100000.0) * dc[1] + (1.0 / 100000.0) * data[i];
+        else       dc[0] = (1.0 - 1.0 / 100000.0) * dc[0] + (1.0 / 100000.0) * data[i];
+    }
 }

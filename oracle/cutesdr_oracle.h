@@ -173,6 +173,16 @@ int  orc_demod_tap_len(const orc_demod *d, int tap);
 const double *orc_demod_tap_data(const orc_demod *d, int tap); /* cpx interleaved for 1-3; real for 4 */
 void orc_demod_clear_taps(orc_demod *d);
 
+/* CNoiseProc (dsp/noiseproc.h:23-58) */
+typedef struct orc_noiseproc orc_noiseproc;
+orc_noiseproc *orc_noiseproc_new(void);
+void orc_noiseproc_free(orc_noiseproc *p);
+int orc_noiseproc_setup(orc_noiseproc *p, int on, double thresh, double width, double fs);
+void orc_noiseproc_process(orc_noiseproc *p, int n, const double *in, double *out);
+/* wire format (interface/netiobase.cpp:479-527) and NCO-spur DC estimate (sdrinterface.cpp:829-848) */
+int orc_unpack_packet(const unsigned char *pkt, int len, double *out);
+void orc_spurcal(double *dc, int n_doubles, const double *data);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ def _declare(L):
     f("orc_agc_set", None, P, I, I, I, I, I, I, D)
     f("orc_agc_process_cpx", None, P, I, P, P)
     f("orc_agc_process_real", None, P, I, P, P)
+    f("orc_noiseproc_new", P); f("orc_noiseproc_free", None, P)
+    f("orc_noiseproc_setup", I, P, I, D, D, D); f("orc_noiseproc_process", None, P, I, P, P)
+    f("orc_unpack_packet", I, P, I, P); f("orc_spurcal", None, P, I, P)
     f("orc_smeter_new", P); f("orc_smeter_free", None, P)
     f("orc_smeter_process", None, P, I, P, D)
     f("orc_smeter_peak", D, P); f("orc_smeter_ave", D, P)
@@ -331,6 +334,43 @@ class CSMeter(_Handle):
 
     def GetAve(self):
         return lib().orc_smeter_ave(self.h)
+
+
+class CNoiseProc(_Handle):
+    """dsp/noiseproc.h:23-58"""
+    _free = "orc_noiseproc_free"
+
+    def __init__(self):
+        self.h = lib().orc_noiseproc_new()
+
+    def SetupBlanker(self, On, Threshold, Width, SampleRate):
+        if lib().orc_noiseproc_setup(self.h, int(On), Threshold, Width, SampleRate) < 0:
+            raise ValueError("sample rate too high for the reference's 32768-entry average buffer")
+
+    def ProcessBlanker(self, x):
+        a = _c128(x)
+        out = a.copy()                                   # off: the data passes untouched (in-place call)
+        lib().orc_noiseproc_process(self.h, len(a), _ptr(a), _ptr(out))
+        return out
+
+
+def unpack_packets(raw, pkt_len):
+    """raw: uint8 [npackets, pkt_len] -> complex128 samples (interface/netiobase.cpp:479-527)"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1, pkt_len)
+    per = {1028: 256, 1444: 240}[pkt_len]
+    out = np.empty(raw.shape[0] * per, dtype=np.complex128)
+    for k in range(raw.shape[0]):
+        row = np.ascontiguousarray(raw[k])
+        n = lib().orc_unpack_packet(_ptr(row), pkt_len, C.c_void_p(out.ctypes.data + 16 * per * k))
+        assert n == per
+    return out
+
+
+def spurcal(dc, x):
+    """NcoSpurCalibrate running means (interface/sdrinterface.cpp:829-848); dc = [I, Q] updated in place"""
+    a = _c128(x); d = np.ascontiguousarray(dc, dtype=np.float64)
+    lib().orc_spurcal(_ptr(d), 2 * len(a), _ptr(a))
+    return d
 
 
 class CAmDemod(_Handle):

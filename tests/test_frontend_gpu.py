@@ -1,0 +1,99 @@
+"""GPU parity of the input-rate stages in front of the down-converter
+against the fp64 oracle, through the C ABI: CNoiseProc blanker (sample-exact: zeros and delayed
+copies of fp32 inputs, identical trigger decisions), wire-format unpack (bit-exact: every 16/24-bit
+value is exactly representable in fp32) and the NCO-spur DC estimate (1e-9 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def impulsive(seed, n, fs, rate=2e-4):
+    rng = np.random.default_rng(seed)
+    x = 300.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x += 3000.0 * np.exp(2j * np.pi * 123e3 * np.arange(n) / fs)
+    hits = rng.random(n) < rate
+    x[hits] += 25000.0 * np.exp(2j * np.pi * rng.random(hits.sum()))
+    return x.astype(np.complex64).astype(np.complex128)     # fp32-representable: both sides see the same values
+
+
+@pytest.mark.parametrize("fs,thresh,width", [(2e6, 50.0, 2.0), (2e6, 20.0, 100.0), (500e3, 80.0, 3000.0), (6e6, 35.0, 10.0)])
+def test_blanker_matches_oracle_across_calls(oracle, fs, thresh, width):
+    import cutesdr_amd as ca
+    g, r = ca.CNoiseProc(), oracle.CNoiseProc()
+    g.SetupBlanker(True, thresh, width, fs); r.SetupBlanker(True, thresh, width, fs)
+    x = impulsive(int(fs) % 1000 + int(width), 200000, fs)
+    blanked = 0
+    for a, b in ((0, 240), (240, 5000), (5000, 70000), (70000, 70001), (70001, 200000)):   # ragged calls, history across calls
+        got, want = g.ProcessBlanker(x[a:b]), r.ProcessBlanker(x[a:b])
+        assert np.array_equal(got, want), (a, b, np.nonzero(got != want)[0][:5])
+        blanked += int((want == 0).sum())
+    assert 0 < blanked < 150000                               # the case actually blanks, and not everything
+
+
+def test_blanker_off_passes_data_and_setup_quirk(oracle):
+    import cutesdr_amd as ca
+    g, r = ca.CNoiseProc(), oracle.CNoiseProc()
+    x = impulsive(3, 5000, 2e6)
+    assert np.array_equal(g.ProcessBlanker(x), x)             # constructed off (noiseproc.cpp:64)
+    for o in (g, r):
+        o.SetupBlanker(True, 50.0, 2.0, 2e6)
+    y1g, y1r = g.ProcessBlanker(x), r.ProcessBlanker(x)
+    assert np.array_equal(y1g, y1r)
+    for o in (g, r):
+        o.SetupBlanker(True, 50.0, 2.0, 1e6)                  # rate-only change: ignored (noiseproc.cpp:80-86), state kept
+    assert np.array_equal(g.ProcessBlanker(x), r.ProcessBlanker(x))
+    from cutesdr_amd._capi import CsdrError
+    with pytest.raises(CsdrError):
+        g.SetupBlanker(True, 51.0, 2.0, 10e6)                 # 5 ms window > 32768 entries: the reference overruns
+
+
+def test_blanker_batch_channels_independent(oracle):
+    import cutesdr_amd as ca
+    C, n, fs = 5, 40000, 2e6
+    b = ca.NoiseProcBatch(C)
+    b.setup(True, 50.0, 2.0, fs)
+    b.setup(True, 25.0, 50.0, fs, channel=3)
+    b.setup(False, 50.0, 2.0, fs, channel=4)
+    x = np.stack([impulsive(10 + c, 2 * n, fs) for c in range(C)])
+    refs = [oracle.CNoiseProc() for _ in range(C)]
+    for c, r in enumerate(refs):
+        r.SetupBlanker(c != 4, 25.0 if c == 3 else 50.0, 50.0 if c == 3 else 2.0, fs)
+    for part in (x[:, :n], x[:, n:]):
+        got = b.process(part)
+        for c in range(C):
+            assert np.array_equal(got[c].astype(np.complex128), refs[c].ProcessBlanker(part[c])), c
+
+
+@pytest.mark.parametrize("pkt_len", [1028, 1444])
+def test_unpack_bit_exact(oracle, pkt_len):
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(pkt_len)
+    raw = rng.integers(0, 256, (7, pkt_len), dtype=np.uint8)
+    raw[0, 4:10] = [0x00, 0x80, 0xFF, 0x7F, 0x00, 0x00]      # extreme values at the front
+    want = oracle.unpack_packets(raw, pkt_len)
+    got = ca.unpack_packets(raw, pkt_len)
+    assert len(got) == len(want) == 7 * (240 if pkt_len == 1444 else 256)
+    assert np.array_equal(got, want)
+    # batch form with DC offsets (sdrinterface.cpp:889-894)
+    raw3 = rng.integers(0, 256, (3, 4, pkt_len), dtype=np.uint8)
+    dc = np.array([[1.5, -2.25], [0.0, 0.0], [-100.0, 37.0]])
+    got3 = ca.unpack_packets_batch(raw3, pkt_len, dc)
+    for c in range(3):
+        w = oracle.unpack_packets(raw3[c], pkt_len) - (dc[c, 0] + 1j * dc[c, 1])
+        assert np.abs(got3[c] - w).max() <= 4e-3               # fp32 result of an fp64 subtraction near +-32768
+    from cutesdr_amd._capi import CsdrError
+    with pytest.raises(CsdrError):
+        ca.unpack_packets(np.zeros((1, 1000), dtype=np.uint8), 1000)
+
+
+def test_spurcal_matches_oracle(oracle):
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(9)
+    x = (50.0 * (rng.standard_normal(300000) + 1j * rng.standard_normal(300000)) + (12.5 - 7.75j))
+    x = x.astype(np.complex64).astype(np.complex128)
+    dg, dr = np.zeros(2), np.zeros(2)
+    for a, b in ((0, 1000), (1000, 120000), (120000, 300000)):
+        dg = ca.spurcal(dg, x[a:b]); dr = oracle.spurcal(dr, x[a:b])
+        assert np.abs(dg - dr).max() <= 1e-9 * 50.0
+    assert dg[0] == pytest.approx(12.5 * (1 - (1 - 1e-5) ** 300000), abs=0.6)     # + the noise the mean has not averaged out
