@@ -149,6 +149,8 @@ __device__ __forceinline__ float agc_real(PcAgc &a, float *dly, float *ring, flo
 //     -wrap(arg(x) + sgn*phi), so arg(x) is taken for the whole tile up front and the loop carries
 //     a dozen fp64 operations per sample and no transcendental.
 // =====================================================================================================
+constexpr int LC = 16;                   // samples per lane in the linear-recurrence scans
+constexpr int BQ_TAB = 17 * 4 + 16 * 2;  // biquad chunk tables: M^k (k <= 16), c M^k (k < 16)
 constexpr int PC_NCHUNK = (PC_AGC_RING + 1024) / 16, PC_RLEVELS = 8;
 constexpr int PT = 1024;                 // tile length (samples)
 constexpr int PH = PC_AGC_RING;          // longest history (AGC delay / window)
@@ -162,7 +164,9 @@ struct PcLds {
     float w1[PT + PC_FIR_MAX + 17];           // second work array (theta / Q)
     float h0[PC_FIR_MAX + 5], h1[PC_FIR_MAX + 5];   // FIR taps of the active demodulator
     float w2[PT + 16];
-    float rt[PC_RLEVELS][PC_NCHUNK];     // log table over the chunk maxima of the sliding peak                    // third work array (S-meter dB, PLL phase)
+    float rt[PC_RLEVELS][PC_NCHUNK];
+    double pw_sm[LC + 1], pw_dc[LC + 1], pw_sq[LC + 1], pw_fd[LC + 1];   // powers of the averager coefficients
+    double bq[BQ_TAB];                   // biquad chunk tables     // log table over the chunk maxima of the sliding peak                    // third work array (S-meter dB, PLL phase)
 };
 
 __device__ __forceinline__ double wrap_pi(double a)
@@ -220,6 +224,159 @@ __device__ __forceinline__ void seq_walk(const float *src, int n, F f)
 #pragma unroll
         for (int j = 0; j < 8; j++) cur[j] = nxt[j];
     }
+}
+
+
+// =====================================================================================================
+// Constant-coefficient LINEAR recurrences (averagers, DC blockers, the biquad) are not walked sample
+// by sample: lane l takes the 16 consecutive samples [16 l, 16 l + 16), runs them from a zero state,
+// the chunk-start states follow from a 64-lane scan over the affine chunk maps (a^cnt, p_last), and
+// the homogeneous part a^(j+1) * S_start is added back.  ~100 instructions per lane and 1024-sample
+// tile instead of 3-9 per sample on one lane.  Results differ from the sequential fp64 loop by
+// rounding only.
+// =====================================================================================================
+
+__device__ __forceinline__ void pow_table(double *tab, double a, int lane)    // tab[k] = a^k, k = 0..16
+{
+    if (lane <= LC) { double p = 1.0; for (int k = 0; k < lane; k++) p *= a; tab[lane] = p; }
+}
+
+// s_i = a s_{i-1} + g x_i  over x[0..n), n <= 1024, s_{-1} = s0.  emit(i, x_i, s_i, s_{i-1}) for every
+// sample (skipped when EMIT is false).  Returns s_{n-1} on every lane.
+template <bool EMIT, class F>
+__device__ __forceinline__ double lin1_scan(const float *x, int n, double a, double g, double s0,
+                                            const double *apw, int lane, F emit)
+{
+    const int base = LC * lane;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    float xv[LC];
+    double loc[LC], p = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        xv[j] = j < cnt ? x[base + j] : 0.f;
+        p = j < cnt ? a * p + g * (double)xv[j] : p;
+        loc[j] = p;
+    }
+    double A = apw[cnt], B = p;          // chunk map s -> A s + B; inclusive scan over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double A1 = __shfl_up(A, d), B1 = __shfl_up(B, d);
+        if (lane >= d) { B = A * B1 + B; A = A * A1; }
+    }
+    const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
+    const double S = lane == 0 ? s0 : Ae * s0 + Be;                  // state entering this lane's chunk
+    if (EMIT) {
+        double prev = S;
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            if (j < cnt) {
+                const double sj = loc[j] + apw[j + 1] * S;
+                emit(base + j, xv[j], sj, prev);
+                prev = sj;
+            }
+        }
+    }
+    return __shfl(A, 63) * s0 + __shfl(B, 63);
+}
+
+// CSMeter (smeter.cpp:62-93) over one tile, final state only.  att is a plain averager; dec obeys
+// dec' = max(att', (1-da) dec + da mag), and maps x -> max(A x + B, C) are closed under composition.
+__device__ __forceinline__ void smeter_tile(PcSMeter &sm, const float *db, int n, const double *apw_att, int lane)
+{
+    const double aa = sm.att_a, ia = 1.0 - sm.att_a, da = sm.dec_a, id = 1.0 - sm.dec_a;
+    const int base = LC * lane;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    float xv[LC];
+    double loc[LC], p = 0.0, pk = -1.0e300;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        xv[j] = j < cnt ? db[base + j] : 0.f;
+        p = j < cnt ? ia * p + aa * (double)xv[j] : p;
+        loc[j] = p;
+        if (j < cnt) pk = fmax(pk, (double)xv[j]);
+    }
+    double A = apw_att[cnt], B = p;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double A1 = __shfl_up(A, d), B1 = __shfl_up(B, d);
+        if (lane >= d) { B = A * B1 + B; A = A * A1; }
+    }
+    const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
+    const double S = lane == 0 ? sm.att_ave : Ae * sm.att_ave + Be;
+    const double att_end = __shfl(A, 63) * sm.att_ave + __shfl(B, 63);
+    // chunk map of the decay average: x -> max(MA x + MB, MC)
+    double MA = 1.0, MB = 0.0, MC = -1.0e300;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        if (j < cnt) {
+            const double att = loc[j] + apw_att[j + 1] * S;          // updated attack average at this sample
+            MA = id * MA; MB = id * MB + da * (double)xv[j]; MC = fmax(id * MC + da * (double)xv[j], att);
+        }
+    }
+    // ordered reduction (lane 0 first): compose (earlier) then (later)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double A1 = __shfl_up(MA, d), B1 = __shfl_up(MB, d), C1 = __shfl_up(MC, d);
+        if (lane >= d) { MC = fmax(MA * C1 + MB, MC); MB = MA * B1 + MB; MA = MA * A1; }
+    }
+    const double dec_end = fmax(__shfl(MA, 63) * sm.dec_ave + __shfl(MB, 63), __shfl(MC, 63));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pk = fmax(pk, __shfl_xor(pk, d));
+    sm.att_ave = att_end; sm.dec_ave = dec_end; sm.ave_mag = dec_end; sm.peak_mag = fmax(sm.peak_mag, pk);
+}
+
+// CIir direct form II (iir.cpp:171-186) over x[0..n) in place.  State s = (w1, w2):
+// s' = M s + (x, 0), y = b0 x + c . s, M = [[-a1, -a2], [1, 0]], c = (b1 - b0 a1, b2 - b0 a2).
+// tab: M^k (4 doubles each, k = 0..16) then r_k = c M^k (2 doubles each, k = 0..15)
+__device__ __forceinline__ void biquad_table(double *tab, const PcIir &f, int lane)
+{
+    if (lane == 0) {
+        double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
+        const double c0 = f.b1 - f.b0 * f.a1, c1 = f.b2 - f.b0 * f.a2;
+        for (int k = 0; k <= LC; k++) {
+            tab[4 * k] = m00; tab[4 * k + 1] = m01; tab[4 * k + 2] = m10; tab[4 * k + 3] = m11;
+            if (k < LC) { tab[68 + 2 * k] = c0 * m00 + c1 * m10; tab[68 + 2 * k + 1] = c0 * m01 + c1 * m11; }
+            const double n00 = -f.a1 * m00 - f.a2 * m10, n01 = -f.a1 * m01 - f.a2 * m11;     // M * M^k
+            m10 = m00; m11 = m01; m00 = n00; m01 = n01;
+        }
+    }
+}
+__device__ __forceinline__ void biquad_scan(float *x, int n, PcIir &f, const double *tab, int lane)
+{
+    const int base = LC * lane;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    double y[LC], w1 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        const double xv = j < cnt ? (double)x[base + j] : 0.0;
+        const double w0 = xv - f.a1 * w1 - f.a2 * w2;
+        y[j] = f.b0 * w0 + f.b1 * w1 + f.b2 * w2;
+        if (j < cnt) { w2 = w1; w1 = w0; }
+    }
+    // chunk map s -> M^cnt s + v
+    double m00 = tab[4 * cnt], m01 = tab[4 * cnt + 1], m10 = tab[4 * cnt + 2], m11 = tab[4 * cnt + 3], v0 = w1, v1 = w2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double p00 = __shfl_up(m00, d), p01 = __shfl_up(m01, d), p10 = __shfl_up(m10, d), p11 = __shfl_up(m11, d);
+        const double q0 = __shfl_up(v0, d), q1 = __shfl_up(v1, d);
+        if (lane >= d) {
+            const double nv0 = m00 * q0 + m01 * q1 + v0, nv1 = m10 * q0 + m11 * q1 + v1;
+            const double n00 = m00 * p00 + m01 * p10, n01 = m00 * p01 + m01 * p11;
+            const double n10 = m10 * p00 + m11 * p10, n11 = m10 * p01 + m11 * p11;
+            m00 = n00; m01 = n01; m10 = n10; m11 = n11; v0 = nv0; v1 = nv1;
+        }
+    }
+    const double e00 = __shfl_up(m00, 1), e01 = __shfl_up(m01, 1), e10 = __shfl_up(m10, 1), e11 = __shfl_up(m11, 1);
+    const double ev0 = __shfl_up(v0, 1), ev1 = __shfl_up(v1, 1);
+    const double S1 = lane == 0 ? f.w1a : e00 * f.w1a + e01 * f.w2a + ev0;
+    const double S2 = lane == 0 ? f.w2a : e10 * f.w1a + e11 * f.w2a + ev1;
+#pragma unroll
+    for (int j = 0; j < LC; j++)
+        if (j < cnt) x[base + j] = (float)(y[j] + tab[68 + 2 * j] * S1 + tab[68 + 2 * j + 1] * S2);
+    const double f00 = __shfl(m00, 63), f01 = __shfl(m01, 63), f10 = __shfl(m10, 63), f11 = __shfl(m11, 63);
+    const double fv0 = __shfl(v0, 63), fv1 = __shfl(v1, 63);
+    const double nw1 = f00 * f.w1a + f01 * f.w2a + fv0, nw2 = f10 * f.w1a + f11 * f.w2a + fv1;
+    f.w1a = nw1; f.w2a = nw2;
 }
 
 #define PC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
@@ -331,6 +488,11 @@ void postchain_kernel(PcArgs a)
         }
         for (int i = lane; i < nt - 1; i += 64) { S.w0[i] = (mode == PC_MODE_FM || mode == PC_MODE_AM && !stereo) ? fir->zreal[i] : fir->zr[i]; S.w1[i] = fir->zi[i]; }
     }
+    pow_table(S.pw_sm, 1.0 - sm.att_a, lane);
+    pow_table(S.pw_dc, 0.99, lane);
+    pow_table(S.pw_sq, 1.0 - C.fm.sq_alpha, lane);
+    pow_table(S.pw_fd, 1.0 - C.fm.dc_alpha, lane);
+    biquad_table(S.bq, lp, lane);
     PC_SYNC();
 
 #ifdef PC_PROFILE
@@ -354,20 +516,8 @@ void postchain_kernel(PcArgs a)
                     S.w2[i] = pw > 0.f ? 10.0f * log10f(pw) : -500.0f;
                 }
                 PC_SYNC();
-                if (lane == 0) {
-                    double att = sm.att_ave, dec = sm.dec_ave, pkm = sm.peak_mag;
-                    const double aa = sm.att_a, da = sm.dec_a, ia = 1.0 - sm.att_a, id = 1.0 - sm.dec_a;
-                    seq_walk(S.w2, n, [&](float v, int) {
-                        const double mag = v;
-                        att = ia * att + aa * mag;
-                        dec = id * dec + da * mag;
-                        dec = fmax(att, dec);                            // ave = dec afterwards in both branches
-                        pkm = fmax(mag, pkm);
-                    });
-                    sm.att_ave = att; sm.dec_ave = dec; sm.ave_mag = dec; sm.peak_mag = pkm;
-                }
+                smeter_tile(sm, S.w2, n, S.pw_sm, lane);
             }
-            PC_TICK(0);
             // ---------------- AGC (agc.cpp:174-296 / 301-401) ----------------
             if (do_agc) {
                 if (!agc.on) {
@@ -466,8 +616,9 @@ void postchain_kernel(PcArgs a)
                 float *w = S.w0 + (nt - 1);
                 for (int i = lane; i < n; i += 64) w[i] = sqrtf(x[i].x * x[i].x + x[i].y * x[i].y);
                 PC_SYNC();
-                if (lane == 0)                                            // DC block, amdemod.cpp:70-80
-                    seq_walk(w, n, [&](float v, int i) { const double z0 = (double)v + am_z1 * 0.99; w[i] = (float)(z0 - am_z1); am_z1 = z0; });
+                // DC block z0 = x + 0.99 z1, out = z0 - z1 (amdemod.cpp:70-80)
+                am_z1 = lin1_scan<true>(w, n, 0.99, 1.0, am_z1, S.pw_dc, lane,
+                                        [&](int i, float, double z0, double z1) { w[i] = (float)(z0 - z1); });
                 PC_SYNC();
                 float acc[16], acq[16];
                 fir16(S.h0, nt, w, lane, acc);
@@ -491,17 +642,21 @@ void postchain_kernel(PcArgs a)
                     const PcFm &F = C.fm;
                     if (lane == 0) {
                         // phase, frequency and error in turns: wrapping is a - rint(a)
-                        const double beta = F.beta, alpha = F.alpha, hi = F.hi * kInvTwoPiD, lo = F.lo * kInvTwoPiD,
-                                     dca = F.dc_alpha, idca = 1.0 - F.dc_alpha, og = F.out_gain * kTwoPiD;
-                        double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD, dc = fm_dc * kInvTwoPiD;
-                        seq_walk(th, n, [&](float v, int i) {              // fmdemod.cpp:166-186
+                        const double beta = F.beta, alpha = F.alpha, hi = F.hi * kInvTwoPiD, lo = F.lo * kInvTwoPiD;
+                        double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD;
+                        seq_walk(th, n, [&](float v, int i) {              // fmdemod.cpp:166-177
                             const double err = -wrap_turn((double)v + ph);
                             fr = fmin(fmax(fr + beta * err, lo), hi);
                             ph = wrap_turn(ph + fr + alpha * err);
-                            dc = idca * dc + dca * fr;
-                            au[i] = (float)((fr - dc) * og);
+                            au[i] = (float)fr;                             // NCO frequency, turns per sample
                         });
-                        fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD; fm_dc = dc * kTwoPiD;
+                        fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD;
+                    }
+                    PC_SYNC();
+                    {   // audio = (freq - its running mean) * gain  (fmdemod.cpp:178-186): the mean is linear
+                        const double og = F.out_gain * kTwoPiD;
+                        fm_dc = kTwoPiD * lin1_scan<true>(au, n, 1.0 - F.dc_alpha, F.dc_alpha, fm_dc * kInvTwoPiD, S.pw_fd, lane,
+                                    [&](int i, float f, double dc, double) { au[i] = (float)(((double)f - dc) * og); });
                     }
                     PC_SYNC();
             PC_TICK(5);
@@ -514,10 +669,8 @@ void postchain_kernel(PcArgs a)
 #pragma unroll
                         for (int j = 0; j < 16; j++) S.w2[(lane + 64 * j) & (PT - 1)] = fabsf(acc[j]);
                         PC_SYNC();
-                        if (lane == 0) {
-                            const double qa = F.sq_alpha, iqa = 1.0 - F.sq_alpha;
-                            seq_walk(S.w2, n, [&](float v, int) { fm_sq = iqa * fm_sq + qa * (double)v; });
-                        }
+                        fm_sq = lin1_scan<false>(S.w2, n, 1.0 - F.sq_alpha, F.sq_alpha, fm_sq, S.pw_sq, lane,
+                                                 [](int, float, double, double) {});
                     }
                     PC_SYNC();
                     slide(S.w0, nt - 1, n, lane);
@@ -546,11 +699,12 @@ void postchain_kernel(PcArgs a)
                         th[i] = r * s;                                    // ti
                     }
                     PC_SYNC();
-                    if (lane == 0) {                                      // DC blocks
-                        seq_walk(au, n, [&](float v, int i) { const double z0 = (double)v + sam_z1 * 0.99; au[i] = (float)(z0 - sam_z1); sam_z1 = z0; });
-                        if (stereo)
-                            seq_walk(th, n, [&](float v, int i) { const double y0 = (double)v + sam_y1 * 0.99; th[i] = (float)(y0 - sam_y1); sam_y1 = y0; });
-                    }
+                    // DC blocks
+                    sam_z1 = lin1_scan<true>(au, n, 0.99, 1.0, sam_z1, S.pw_dc, lane,
+                                             [&](int i, float, double z0, double z1) { au[i] = (float)(z0 - z1); });
+                    if (stereo)
+                        sam_y1 = lin1_scan<true>(th, n, 0.99, 1.0, sam_y1, S.pw_dc, lane,
+                                                 [&](int i, float, double y0, double y1) { th[i] = (float)(y0 - y1); });
                     PC_SYNC();
                     if (!stereo) {
                         for (int i = lane; i < n; i += 64) outm[gi + i] = au[i];
@@ -588,7 +742,7 @@ void postchain_kernel(PcArgs a)
                 } else {                                                  // low-pass biquad over the burst
                     for (int i = lane; i < n; i += 64) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i];
                     PC_SYNC();
-                    if (lane == 0) seq_walk(S.w2, n, [&](float v, int i) { S.w2[i] = iir_a(lp, v); });
+                    biquad_scan(S.w2, n, lp, S.bq, lane);
                     PC_SYNC();
                     for (int i = lane; i < n; i += 64) { const float y = S.w2[i]; if (stereo) outs[g0 + t0 + i] = make_float2(y, y); else outm[g0 + t0 + i] = y; }
                     PC_SYNC();
