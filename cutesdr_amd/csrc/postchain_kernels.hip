@@ -166,7 +166,8 @@ struct PcLds {
     float w2[PT + 16];
     float rt[PC_RLEVELS][PC_NCHUNK];
     double pw_sm[LC + 1], pw_dc[LC + 1], pw_sq[LC + 1], pw_fd[LC + 1];   // powers of the averager coefficients
-    double bq[BQ_TAB];                   // biquad chunk tables     // log table over the chunk maxima of the sliding peak                    // third work array (S-meter dB, PLL phase)
+    double bq[BQ_TAB];                   // biquad chunk tables
+    double pm[(LC + 1) * 4];             // PLL transition-matrix powers     // log table over the chunk maxima of the sliding peak                    // third work array (S-meter dB, PLL phase)
 };
 
 __device__ __forceinline__ double wrap_pi(double a)
@@ -379,6 +380,168 @@ __device__ __forceinline__ void biquad_scan(float *x, int n, PcIir &f, const dou
     f.w1a = nw1; f.w2a = nw2;
 }
 
+// CAgc's attack / decay averagers (agc.cpp:233-262):  ave += alpha (pk - ave),  alpha = rise when
+// pk > ave else fall.  Piecewise linear, so: guess the selector bits, solve the then-linear
+// recurrence with a lane scan, recompute the selectors from the solution, repeat until they
+// reproduce themselves -- at that point the sequence IS the sequential one (each selector was
+// taken against the true previous average).  The correct prefix grows every round; the peak moves
+// slowly, so two or three rounds are typical.  Returns false after PC_AGC_ROUNDS without a fixed
+// point (the caller then walks the tile sample by sample).
+constexpr int PC_AGC_ROUNDS = 8;
+template <class F>
+__device__ __forceinline__ bool agc_ave_scan(const float *pk, int n, double rise, double fall, double &ave,
+                                             int lane, F emit)
+{
+    const int base = LC * lane;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    const double ave0 = ave;
+    float pv[LC];
+    unsigned sel = 0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        pv[j] = j < cnt ? pk[base + j] : 0.f;
+        if (j < cnt && (double)pv[j] > ave0) sel |= 1u << j;
+    }
+    for (int round = 0; round < PC_AGC_ROUNDS; round++) {
+        double A = 1.0, B = 0.0;
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            if (j < cnt) {
+                const double al = (sel >> j & 1) ? rise : fall;
+                A = A - al * A;
+                B = B + al * ((double)pv[j] - B);
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double A1 = __shfl_up(A, d), B1 = __shfl_up(B, d);
+            if (lane >= d) { B = A * B1 + B; A = A * A1; }
+        }
+        const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
+        double x = lane == 0 ? ave0 : Ae * ave0 + Be;
+        double val[LC];
+        unsigned nsel = 0;
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            if (j < cnt) {
+                if ((double)pv[j] > x) nsel |= 1u << j;
+                const double al = (sel >> j & 1) ? rise : fall;
+                x = x + al * ((double)pv[j] - x);
+            }
+            val[j] = x;
+        }
+        if (!__any(nsel != sel)) {
+#pragma unroll
+            for (int j = 0; j < LC; j++) if (j < cnt) emit(base + j, val[j]);
+            ave = __shfl(A, 63) * ave0 + __shfl(B, 63);
+            return true;
+        }
+        sel = nsel;
+    }
+    return false;
+}
+
+// The second-order PLL of CFmDemod / CSamDemod (fmdemod.cpp:166-177, samdemod.cpp:83-97), in turns:
+//   e = -wrap(theta_i + phi),  f += beta e (clamped to [lo, hi]),  phi += f + alpha e.
+// With the input phase unwrapped (Theta_i, a prefix sum of wrapped differences) a locked loop keeps
+// Theta_i + phi next to ONE integer K for a whole tile and never touches the clamp; under that
+// guess e = (K - Theta_i) - phi and the loop is the constant-coefficient linear system
+//   [phi; f] <- [[1-alpha-beta, 1], [-beta, 1]] [phi; f] + (alpha+beta, beta) (K - Theta_i),
+// solved by a lane scan like the biquad.  The guess is then checked sample by sample (|e| < 1/2, f
+// inside the clamp); if it holds everywhere the result is the sequential one, otherwise (cycle slip,
+// acquisition, noise) the caller walks the tile.  emit(i, phi_before, f_after).
+// tab: M^k, k = 0..16 (4 doubles each)
+__device__ __forceinline__ void pll_table(double *tab, double alpha, double beta, int lane)
+{
+    if (lane == 0) {
+        const double a00 = 1.0 - alpha - beta, a01 = 1.0, a10 = -beta, a11 = 1.0;
+        double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
+        for (int k = 0; k <= LC; k++) {
+            tab[4 * k] = m00; tab[4 * k + 1] = m01; tab[4 * k + 2] = m10; tab[4 * k + 3] = m11;
+            const double n00 = a00 * m00 + a01 * m10, n01 = a00 * m01 + a01 * m11;
+            const double n10 = a10 * m00 + a11 * m10, n11 = a10 * m01 + a11 * m11;
+            m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+        }
+    }
+}
+template <class F>
+__device__ __forceinline__ bool pll_scan(const float *th, int n, double alpha, double beta, double lo, double hi,
+                                         double &ph, double &fr, const double *tab, int lane, F emit)
+{
+    const int base = LC * lane;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    float tv[LC];
+#pragma unroll
+    for (int j = 0; j < LC; j++) tv[j] = j < cnt ? th[base + j] : 0.f;
+    // unwrapped input phase relative to the first sample of the tile
+    float last = tv[0];
+#pragma unroll
+    for (int j = 1; j < LC; j++) if (j < cnt) last = tv[j];
+    const float before = __shfl_up(last, 1);
+    double c[LC], run = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        const float pv = j == 0 ? (lane == 0 ? tv[0] : before) : tv[j - 1];
+        const float d = tv[j] - pv;
+        if (j < cnt) run += (double)(d - rintf(d));
+        c[j] = run;
+    }
+    double incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const double first = (double)__shfl(tv[0], 0);
+    const double K = rint(first + ph);
+    const double off = K - first - (incl - run);
+#pragma unroll
+    for (int j = 0; j < LC; j++) c[j] = off - c[j];                  // K - Theta_i
+    // zero-state chunk response
+    const double ab = alpha + beta;
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        if (j < cnt) {
+            const double e = c[j] - v0;
+            v1 = v1 + beta * e;
+            v0 = v0 + v1 + alpha * e;
+        }
+    }
+    double m00 = tab[4 * cnt], m01 = tab[4 * cnt + 1], m10 = tab[4 * cnt + 2], m11 = tab[4 * cnt + 3];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double p00 = __shfl_up(m00, d), p01 = __shfl_up(m01, d), p10 = __shfl_up(m10, d), p11 = __shfl_up(m11, d);
+        const double q0 = __shfl_up(v0, d), q1 = __shfl_up(v1, d);
+        if (lane >= d) {
+            const double nv0 = m00 * q0 + m01 * q1 + v0, nv1 = m10 * q0 + m11 * q1 + v1;
+            const double n00 = m00 * p00 + m01 * p10, n01 = m00 * p01 + m01 * p11;
+            const double n10 = m10 * p00 + m11 * p10, n11 = m10 * p01 + m11 * p11;
+            m00 = n00; m01 = n01; m10 = n10; m11 = n11; v0 = nv0; v1 = nv1;
+        }
+    }
+    (void)ab;
+    const double e00 = __shfl_up(m00, 1), e01 = __shfl_up(m01, 1), e10 = __shfl_up(m10, 1), e11 = __shfl_up(m11, 1);
+    const double ev0 = __shfl_up(v0, 1), ev1 = __shfl_up(v1, 1);
+    double x0 = lane == 0 ? ph : e00 * ph + e01 * fr + ev0;           // state entering this lane's chunk
+    double x1 = lane == 0 ? fr : e10 * ph + e11 * fr + ev1;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        if (j < cnt) {
+            const double e = c[j] - x0;
+            const double f = x1 + beta * e;
+            bad = bad || !(fabs(e) < 0.4999) || !(f >= lo && f <= hi);
+            emit(base + j, x0, f);
+            x1 = f;
+            x0 = x0 + f + alpha * e;
+        }
+    }
+    if (__any(bad)) return false;
+    const double f00 = __shfl(m00, 63), f01 = __shfl(m01, 63), f10 = __shfl(m10, 63), f11 = __shfl(m11, 63);
+    const double fv0 = __shfl(v0, 63), fv1 = __shfl(v1, 63);
+    const double nph = f00 * ph + f01 * fr + fv0, nfr = f10 * ph + f11 * fr + fv1;
+    ph = nph - rint(nph); fr = nfr;
+    return true;
+}
+
 #define PC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
@@ -493,6 +656,8 @@ void postchain_kernel(PcArgs a)
     pow_table(S.pw_sq, 1.0 - C.fm.sq_alpha, lane);
     pow_table(S.pw_fd, 1.0 - C.fm.dc_alpha, lane);
     biquad_table(S.bq, lp, lane);
+    if (mode == PC_MODE_FM) pll_table(S.pm, C.fm.alpha, C.fm.beta, lane);
+    if (mode == PC_MODE_SAM) pll_table(S.pm, C.sam.alpha, C.sam.beta, lane);
     PC_SYNC();
 
 #ifdef PC_PROFILE
@@ -542,39 +707,36 @@ void postchain_kernel(PcArgs a)
                         if (i < W1) S.mg[i] = v;
                         PC_SYNC();
                     }
-                    // attack / decay averagers: sequential (lane 0), output = log gain argument
-                    if (lane == 0) {
+                    // attack / decay averagers -> log gain argument max(att, dec) per sample in S.pk
+                    {
                         double att = agc.attack_ave, dec = agc.decay_ave;
-                        int timer = agc.hang_timer;
-                        // ave += alpha (pk - ave), alpha = rise when pk > ave else fall.  With rise >= fall
-                        // that increment is max(rise d, fall d); sa/sd = -1 turns the max into a min for a
-                        // setting with fall > rise.
-                        const double sa = agc.att_rise >= agc.att_fall ? 1.0 : -1.0, sd = agc.dec_rise >= agc.dec_fall ? 1.0 : -1.0;
-                        double ar = sa * agc.att_rise, af = sa * agc.att_fall, dr = sd * agc.dec_rise, df = sd * agc.dec_fall;
-                        double sav = sa, sdv = sd;
-                        vreg(ar); vreg(af); vreg(dr); vreg(df); vreg(sav); vreg(sdv);
-                        float *dst = S.pk;
-                        if (!agc.hang) {
-                            seq_walk(S.pk, n, [&](float v, int i) {
-                                const double pk = v;
-                                const double da = pk - att, dd = pk - dec;
-                                att = att + sav * fmax(ar * da, af * da);
-                                dec = dec + sdv * fmax(dr * dd, df * dd);
-                                dst[i] = (float)fmax(att, dec);
-                            });
-                        } else {
-                            const int hang_time = agc.hang_time;
-                            seq_walk(S.pk, n, [&](float v, int i) {
-                                const double pk = v;
-                                const double da = pk - att, dd = pk - dec;
-                                att = att + sav * fmax(ar * da, af * da);
-                                const bool up = dd > 0.0, hold = !up && timer < hang_time;
-                                dec = dec + sdv * (up ? dr : (hold ? 0.0 : df)) * dd;
-                                timer = up ? 0 : (hold ? timer + 1 : timer);
-                                dst[i] = (float)fmax(att, dec);
-                            });
+                        bool ok = !agc.hang;                              // the hang timer is a counter: walked
+                        if (ok) ok = agc_ave_scan(S.pk, n, agc.att_rise, agc.att_fall, att, lane,
+                                                  [&](int i, double v) { S.w2[i] = (float)v; });
+                        if (ok) ok = agc_ave_scan(S.pk, n, agc.dec_rise, agc.dec_fall, dec, lane,
+                                                  [&](int i, double v) { S.pk[i] = fmaxf(S.w2[i], (float)v); });
+                        if (ok) { agc.attack_ave = att; agc.decay_ave = dec; }
+                        else {
+                            PC_SYNC();
+                            att = agc.attack_ave; dec = agc.decay_ave;
+                            int timer = agc.hang_timer;
+                            if (lane == 0) {
+                                const double ar = agc.att_rise, af = agc.att_fall, dr = agc.dec_rise, df = agc.dec_fall;
+                                const bool hang = agc.hang;
+                                const int hang_time = agc.hang_time;
+                                float *dst = S.pk;
+                                seq_walk(S.pk, n, [&](float v, int i) {
+                                    const double pk = v;
+                                    const double da = pk - att, dd = pk - dec;
+                                    att = att + (da > 0.0 ? ar : af) * da;
+                                    const bool up = dd > 0.0, hold = hang && !up && timer < hang_time;
+                                    dec = dec + (up ? dr : (hold ? 0.0 : df)) * dd;
+                                    if (hang) timer = up ? 0 : (hold ? timer + 1 : timer);
+                                    dst[i] = (float)fmax(att, dec);
+                                });
+                            }
+                            agc.attack_ave = __shfl(att, 0); agc.decay_ave = __shfl(dec, 0); agc.hang_timer = __shfl(timer, 0);
                         }
-                        agc.attack_ave = att; agc.decay_ave = dec; agc.hang_timer = timer;
                     }
                     PC_SYNC();
             PC_TICK(3);
@@ -640,7 +802,15 @@ void postchain_kernel(PcArgs a)
                 PC_SYNC();
                 if (mode == PC_MODE_FM) {
                     const PcFm &F = C.fm;
-                    if (lane == 0) {
+                    bool scanned;
+                    {
+                        double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD;
+                        scanned = pll_scan(th, n, F.alpha, F.beta, F.lo * kInvTwoPiD, F.hi * kInvTwoPiD, ph, fr, S.pm, lane,
+                                           [&](int i, double, double f) { au[i] = (float)f; });
+                        if (scanned) { fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD; }
+                    }
+                    if (!scanned) PC_SYNC();
+                    if (!scanned && lane == 0) {
                         // phase, frequency and error in turns: wrapping is a - rint(a)
                         const double beta = F.beta, alpha = F.alpha, hi = F.hi * kInvTwoPiD, lo = F.lo * kInvTwoPiD;
                         double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD;
@@ -652,6 +822,7 @@ void postchain_kernel(PcArgs a)
                         });
                         fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD;
                     }
+                    if (!scanned) { fm_ph = __shfl(fm_ph, 0); fm_fr = __shfl(fm_fr, 0); }
                     PC_SYNC();
                     {   // audio = (freq - its running mean) * gain  (fmdemod.cpp:178-186): the mean is linear
                         const double og = F.out_gain * kTwoPiD;
@@ -678,7 +849,16 @@ void postchain_kernel(PcArgs a)
                 } else {                                                  // SAM, samdemod.cpp:78-158
                     const PcSam &M = C.sam;
                     const double sgn = stereo ? 1.0 : -1.0;
-                    if (lane == 0) {
+                    bool scanned;
+                    {   // in psi = sgn phi, g = sgn f the loop has the FM form with theta as is
+                        double ps = sgn * sam_ph * kInvTwoPiD, g = sgn * sam_fr * kInvTwoPiD;
+                        const double l0 = M.lo * kInvTwoPiD, h0 = M.hi * kInvTwoPiD;
+                        scanned = pll_scan(th, n, M.alpha, M.beta, sgn > 0 ? l0 : -h0, sgn > 0 ? h0 : -l0, ps, g, S.pm, lane,
+                                           [&](int i, double p, double) { S.w2[i] = (float)(sgn * (p - rint(p))); });
+                        if (scanned) { sam_ph = sgn * ps * kTwoPiD; sam_fr = sgn * g * kTwoPiD; }
+                    }
+                    if (!scanned) PC_SYNC();
+                    if (!scanned && lane == 0) {
                         const double beta = M.beta, alpha = M.alpha, hi = M.hi * kInvTwoPiD, lo = M.lo * kInvTwoPiD;
                         double ph = sam_ph * kInvTwoPiD, fr = sam_fr * kInvTwoPiD;
                         seq_walk(th, n, [&](float v, int i) {
@@ -689,6 +869,7 @@ void postchain_kernel(PcArgs a)
                         });
                         sam_ph = ph * kTwoPiD; sam_fr = fr * kTwoPiD;
                     }
+                    if (!scanned) { sam_ph = __shfl(sam_ph, 0); sam_fr = __shfl(sam_fr, 0); }
                     PC_SYNC();
                     // rotated sample tr + j ti = |x| e^{j(theta + sgn phi)}
                     for (int i = lane; i < n; i += 64) {

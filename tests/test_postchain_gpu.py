@@ -281,3 +281,34 @@ def test_config_c5_10msps_fm_to_resampler(oracle):
     skip = len(got) // 3                                      # PLL / AGC lock-in
     assert np.abs(got[skip:] - want[skip:]).max() <= 1e-3 * FULL_SCALE
     assert np.abs(want[skip:]).max() > 100.0                  # there is audio to compare
+
+
+def test_pll_unlockable_carrier_and_relock(oracle):
+    """The PLL tiles are solved as a linear system under the guess 'locked, clamp idle' and walked
+    sample by sample when the guess fails its check.  A carrier outside the loop's frequency clamp
+    (FM +-6 kHz, SAM +-1 kHz) never satisfies it, a carrier inside does: both paths, and the switch
+    between them inside one stream, match the oracle."""
+    import cutesdr_amd as ca
+    L = 1024
+    fs = 62500.0
+    n = 12 * L
+    t = np.arange(3 * n) / fs
+    seg = lambda f, k: 8000.0 * np.exp(2j * np.pi * f * t[k * n:(k + 1) * n])
+    for stereo in (False, True):
+        x = np.concatenate([seg(9000.0, 0), seg(800.0, 1), seg(-11000.0, 2)])      # out, in, out of the clamp
+        d, r = ca.CFmDemod(fs), oracle.CFmDemod(fs)
+        d.SetSquelch(50); r.SetSquelch(50)
+        for i in range(3 * n // L):
+            got, want = d.ProcessData(x[i * L:(i + 1) * L], 5000.0, stereo), r.ProcessData(x[i * L:(i + 1) * L], 5000.0, stereo)
+            assert d.squelched() == r.squelched(), i
+            if i % 12 >= 2:                                 # two hops after each frequency jump
+                assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, (stereo, i)
+    fs = 31250.0
+    t = np.arange(3 * n) / fs
+    for stereo in (False, True):
+        x = np.concatenate([seg(3000.0, 0), seg(200.0, 1), seg(-2500.0, 2)]) * (1.0 + 0.3 * np.sin(2 * np.pi * 700.0 * t))
+        d, r = ca.CSamDemod(fs), oracle.CSamDemod(fs)
+        for i in range(3 * n // L):
+            got, want = d.ProcessData(x[i * L:(i + 1) * L], stereo), r.ProcessData(x[i * L:(i + 1) * L], stereo)
+            if i % 12 >= 4:
+                assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, (stereo, i)

@@ -15,7 +15,28 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T = 1 << 21
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
-x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * 3276.7
+# synthetic receivers: every channel is tuned to its own carrier, -20 dBFS, AWGN -70 dBFS per
+# component; channel c % 3: AM 50 % / 1 kHz, FM +-3 kHz / 1 kHz, two-tone SSB.  NOISE_ONLY=1: -20 dBFS noise
+# (no carrier: the PLLs never lock and take their sample-by-sample path)
+FS, A = 2e6, 3276.7
+if os.environ.get("NOISE_ONLY"):
+    x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * A
+else:
+    x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * (32767.0 * 10 ** (-70 / 20))
+    t = torch.arange(T, device=dev, dtype=torch.float64) / FS
+    for c in range(C):
+        fc = 100e3 + 500.0 * c
+        if c % 3 == 0:
+            ph = 2 * torch.pi * fc * t; amp = A * (1.0 + 0.5 * torch.sin(2 * torch.pi * 1000.0 * t))
+            x[c, :, 0] += (amp * torch.cos(ph)).float(); x[c, :, 1] += (amp * torch.sin(ph)).float()
+        elif c % 3 == 1:
+            ph = 2 * torch.pi * fc * t + 3.0 * torch.sin(2 * torch.pi * 1000.0 * t)
+            x[c, :, 0] += (A * torch.cos(ph)).float(); x[c, :, 1] += (A * torch.sin(ph)).float()
+        else:
+            for off in (1200.0, 2340.0):
+                ph = 2 * torch.pi * (fc + off) * t
+                x[c, :, 0] += (0.5 * A * torch.cos(ph)).float(); x[c, :, 1] += (0.5 * A * torch.sin(ph)).float()
+    del t, ph
 y = torch.empty((C, T // 16, 2), device=dev, dtype=torch.float32)
 stream = torch.cuda.current_stream().cuda_stream
 out = {}
