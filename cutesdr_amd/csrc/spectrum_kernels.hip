@@ -87,6 +87,17 @@ void spectrum_kernel(SpectrumArgs a)
     float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
     int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
     int over = 0;
+    // every thread owns the same 32 bins in every frame: the running sum and mean stay in registers
+    // for the whole call, only the last frame's bels are written
+    int tt = t;
+    asm volatile("" : "+v"(tt));              // keep the scattered addresses out of LICM's hands
+    const int k0 = tt >> 5, k1 = tt & 31;
+    float sm[32];                             // the mean is sum / count: recomputed, not carried
+    static_for<0, 32>([&](auto Rr) {
+        constexpr int r = Rr.value, k2 = bitrev<32>(r);
+        const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);     // display order, fft.cpp:564-589
+        sm[r] = sum[j];
+    });
     for (int f = 0; f < a.nframes; f++) {
         const v2f *src = in + (long)f * N;
         v2f x[32];
@@ -100,26 +111,26 @@ void spectrum_kernel(SpectrumArgs a)
                 if (s.x > 32000.0f) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
                 x[e * R0 + n1] = v2f{w * s.y, w * s.x};           // I/Q swapped, fft.cpp:280-281
             }
+        const float prev_count = (float)ave_count;
         total++;                                                  // CpxFFT counters, fft.cpp:515-517
         if (ave_count < a.ave_size) ave_count++;
         __syncthreads();
         fft_fwd_passes<LOG2N>(x, lds, tw2, w1);
-        int tt = t;
-        asm volatile("" : "+v"(tt));          // keep the 96 scattered addresses out of LICM's hands
-        const int k0 = tt >> 5, k1 = tt & 31;
+        static_for<0, 32>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const float p = x[r].x * x[r].x + x[r].y * x[r].y;
+            if (total <= a.ave_size) sm[r] = sm[r] + p;
+            else sm[r] = sm[r] - sm[r] / prev_count + p;          // minus the previous mean (fft.cpp:570-574)
+        });
+    }
+    if (a.nframes > 0) {
         static_for<0, 32>([&](auto Rr) {
             constexpr int r = Rr.value, k2 = bitrev<32>(r);
-            const int k = k0 + R0 * (k1 + 32 * k2);
-            const int j = (k + N / 2) & (N - 1);                  // display order, fft.cpp:564-589
-            const float p = x[r].x * x[r].x + x[r].y * x[r].y;
-            float sm = sum[j];
-            if (total <= a.ave_size) sm = sm + p;
-            else sm = sm - pwr[j] + p;
-            sum[j] = sm;
-            const float m = sm / (float)ave_count;
-            pwr[j] = m;
+            const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);
+            const float m = sm[r] / (float)ave_count;
+            sum[j] = sm[r]; pwr[j] = m;
             ave[j] = (float)((double)log10f(m + a.kc) + a.kb);
-            if constexpr ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the live loads
+            if constexpr ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         });
     }
     if (t == 0) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }

@@ -58,6 +58,21 @@ out["k2_ms"] = round(ms, 3)
 out["k2_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["k2_alg_GBps"] = round(C * T * (8 + 8 / 32) / ms / 1e6, 1)
 
+# K3: display spectrum, 4096-point frames (BASELINE config 1's transform), 256 channels x 512 frames, ave 4
+fb = ca.FftBatch(C)
+fb.set_params(4096, False, 0.0, 2e6); fb.set_ave(4)
+def k3():
+    fb.put_display_ptr(x.data_ptr(), T, 512, stream)
+for _ in range(2): k3()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5): k3()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+out["k3_ms"] = round(ms, 3)
+out["k3_MSps"] = round(C * 512 * 4096 / ms / 1e3, 1)
+out["k3_alg_GBps"] = round(C * 512 * 4096 * 12 / ms / 1e6, 1)
+
 if os.environ.get('K2_ONLY'):
     print(json.dumps(out)); sys.exit(0)
 
