@@ -121,3 +121,25 @@ def test_resampler_all_overloads(oracle, rate):
     g = ca.CFractResampler(); g.Init(8192)
     y = g.Resample(x[:4096], 1.6276)
     assert len(y) == 2517                                    # App. A.9 anchor
+
+
+def test_resampler_rate_varies_per_call_like_the_sound_sink(oracle):
+    """CSoundOut::PutOutQueue (interface/soundout.cpp:196-305) calls Resample with
+    m_OutRatio*(1+m_RateCorrection), a rate that moves by up to +-500 ppm from call to call
+    (CalcError, :456-468), and with the volume gain on the int16 variants: counts exact, values
+    within 1 LSB, across a sequence of calls with changing rate and ragged lengths."""
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(21)
+    g, r = ca.CFractResampler(), oracle.CFractResampler()
+    g.Init(8192); r.Init(8192)
+    base = 62500.0 / 48000.0
+    gain = 10 ** ((80 - 99.0) / 39.2)                         # SetVolume(80), soundout.cpp:181-190
+    total = 0
+    for k in range(40):
+        n = int(rng.integers(200, 1200))
+        x = 9000.0 * np.sin(2 * np.pi * 0.01 * (np.arange(n) + total)) + 200.0 * rng.standard_normal(n)
+        total += n
+        rate = base * (1.0 + 2.38e-7 * float(rng.integers(-2000, 2000)))
+        got, want = g.Resample(x, rate, gain), r.Resample(x, rate, gain)
+        assert len(got) == len(want), k
+        assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1, k
