@@ -7,11 +7,12 @@
 //   fmdemod.cpp:113-236, ssbdemod.cpp:48-60) with their CFir (dsp/fir.cpp:72-127) and CIir
 //   (dsp/iir.cpp:171-201) helpers.
 //
-// These stages are strictly sequential in time inside one channel (sliding-window peak with an
-// equality test, attack/decay averagers, second-order PLLs, biquads, a hysteresis squelch that
-// is decided once per burst), so the parallel axis is the channel: one lane per channel, 64
-// channels per wave, every lane walking its own burst.  The rate here is the decimated one
-// (<= 78 kS/s per channel): this kernel is latency-bound by construction, not bandwidth-bound.
+// The reference runs these as one per-sample loop full of running state.  Here one wave owns one
+// channel and walks it in 1024-sample tiles staged in LDS; what is not a recurrence runs on all
+// 64 lanes, linear recurrences are lane scans, the two piecewise-linear ones (AGC averagers, PLLs)
+// are solved under a guess that is checked afterwards and walked sample by sample when the guess
+// fails (see the comment blocks below and DESIGN.md K4).  The rate here is the decimated one
+// (<= 78 kS/s per channel): the kernel is measured in cycles per sample, not against a roofline.
 #include <hip/hip_runtime.h>
 #include "postchain.h"
 
@@ -65,77 +66,6 @@ __device__ __forceinline__ float iir_b(PcIir &f, float x)
     return (float)y;
 }
 
-// ---- CSMeter (dsp/smeter.cpp:62-93) --------------------------------------------------------------
-__device__ __forceinline__ void smeter_step(PcSMeter &s, float re, float im)
-{
-    // 10 log10(|x|^2/32767^2 + 1e-50): the 1e-50 floor only matters for an all-zero sample
-    const float pw = (re * re + im * im) * (1.0f / (32767.0f * 32767.0f));
-    const double mag = pw > 0.f ? 10.0 * (double)log10f(pw) : -500.0;
-    s.att_ave = (1.0 - s.att_a) * s.att_ave + s.att_a * mag;
-    s.dec_ave = (1.0 - s.dec_a) * s.dec_ave + s.dec_a * mag;
-    if (s.att_ave > s.dec_ave) { s.ave_mag = s.att_ave; s.dec_ave = s.att_ave; }
-    else s.ave_mag = s.dec_ave;
-    if (mag > s.peak_mag) s.peak_mag = mag;
-}
-
-// ---- CAgc (dsp/agc.cpp:174-296 / 301-401) ----------------------------------------------------------
-// one tracker step; mag ring in HBM; returns the gain for the delayed sample
-__device__ __forceinline__ float agc_track(PcAgc &a, float *ring, float mag)
-{
-    const float oldest = ring[a.mag_pos];
-    ring[a.mag_pos] = mag;
-    if (++a.mag_pos >= a.win_n) a.mag_pos = 0;
-    float peak = (float)a.peak;
-    if (mag > peak) {
-        peak = mag;
-    } else if (oldest == peak) {                 // the evicted sample was the peak: rescan (:220-230)
-        peak = -8.0f;
-        for (int i = 0; i < a.win_n; i++) { const float v = ring[i]; if (v > peak) peak = v; }
-    }
-    a.peak = peak;
-    const double pk = peak;
-    if (pk > a.attack_ave) a.attack_ave = (1.0 - a.att_rise) * a.attack_ave + a.att_rise * pk;
-    else                   a.attack_ave = (1.0 - a.att_fall) * a.attack_ave + a.att_fall * pk;
-    if (a.hang) {
-        if (pk > a.decay_ave) {
-            a.decay_ave = (1.0 - a.dec_rise) * a.decay_ave + a.dec_rise * pk;
-            a.hang_timer = 0;
-        } else if (a.hang_timer < a.hang_time) {
-            a.hang_timer++;
-        } else {
-            a.decay_ave = (1.0 - a.dec_fall) * a.decay_ave + a.dec_fall * pk;
-        }
-    } else {
-        if (pk > a.decay_ave) a.decay_ave = (1.0 - a.dec_rise) * a.decay_ave + a.dec_rise * pk;
-        else                  a.decay_ave = (1.0 - a.dec_fall) * a.decay_ave + a.dec_fall * pk;
-    }
-    const double m = a.attack_ave > a.decay_ave ? a.attack_ave : a.decay_ave;
-    if (m <= a.knee) return (float)a.fixed_gain;
-    return 0.7f * exp10f((float)(m * (a.gain_slope - 1.0)));
-}
-__device__ __forceinline__ void agc_cpx(PcAgc &a, float *dly, float *ring, float &re, float &im)
-{
-    if (!a.on) { re *= (float)a.manual_gain; im *= (float)a.manual_gain; return; }
-    const float dr = dly[2 * a.dly_pos], di = dly[2 * a.dly_pos + 1];
-    dly[2 * a.dly_pos] = re; dly[2 * a.dly_pos + 1] = im;
-    if (++a.dly_pos >= a.dly_n) a.dly_pos = 0;
-    float mag = fabsf(re);
-    const float mim = fabsf(im);
-    if (mim > mag) mag = mim;
-    mag = log10f(mag + 3.2767e-4f) - 4.51543987f;          // log10(32767)
-    const float g = agc_track(a, ring, mag);
-    re = dr * g; im = di * g;
-}
-__device__ __forceinline__ float agc_real(PcAgc &a, float *dly, float *ring, float x)
-{
-    if (!a.on) return x * (float)a.manual_gain;
-    const float d = dly[2 * a.dly_pos];
-    dly[2 * a.dly_pos] = x;
-    if (++a.dly_pos >= a.dly_n) a.dly_pos = 0;
-    const float g = agc_track(a, ring, log10f(fabsf(x) + 3.2767e-4f) - 4.51543987f);
-    return d * g;
-}
-
 // =====================================================================================================
 // One wave per channel.  Everything that does not depend on the previous output sample (log
 // magnitudes, sliding-window peak, gain law, delay line, arg(x), envelopes, FIR dot products) is
@@ -170,13 +100,6 @@ struct PcLds {
     double pm[(LC + 1) * 4];             // PLL transition-matrix powers     // log table over the chunk maxima of the sliding peak                    // third work array (S-meter dB, PLL phase)
 };
 
-__device__ __forceinline__ double wrap_pi(double a)
-{   // (-pi, pi], the range of atan2
-    if (a > kPiD) a -= kTwoPiD;
-    else if (a <= -kPiD) a += kTwoPiD;
-    return a;
-}
-
 // acc[j] = sum_k h[k] * x[i_j - k] for this lane's outputs i_j = lane + 64 j; x points at the tile
 // (ntaps-1 history samples sit in front of it), h and x in LDS.  Each tap is fetched once per lane
 // and reused for the 16 outputs.
@@ -192,7 +115,6 @@ __device__ __forceinline__ void fir16(const float *h, int ntaps, const float *x,
         for (int j = 0; j < 16; j++) acc[j] += hk * p[64 * j - k];
     }
 }
-__device__ __forceinline__ void vreg(double &x) { asm volatile("" : "+v"(x)); }    // keep a loop constant in VGPRs
 __device__ __forceinline__ double wrap_turn(double a) { return a - rint(a); }    // [-0.5, 0.5]
 constexpr double kInvTwoPiD = 1.0 / (2.0 * 3.14159265358979323846);
 // keep the last `hist` entries of [hist | n] in front for the next tile
