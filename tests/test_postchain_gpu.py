@@ -312,3 +312,39 @@ def test_pll_unlockable_carrier_and_relock(oracle):
             got, want = d.ProcessData(x[i * L:(i + 1) * L], stereo), r.ProcessData(x[i * L:(i + 1) * L], stereo)
             if i % 12 >= 4:
                 assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, (stereo, i)
+
+
+def test_leaf_objects_ragged_call_lengths(oracle):
+    """Leaf objects take any call length: 1-sample calls, lengths that leave partly filled lanes in
+    the scans (17, 1000), lengths that span several 1024-sample tiles (1025, 2500, 4099)."""
+    import cutesdr_amd as ca
+    cuts = np.cumsum([0, 1, 17, 1000, 1025, 2500, 1, 4099, 333, 2048])
+    fs = 31250.0
+    x = am_carrier(int(cuts[-1]), fs, 120.0, fmod=600.0, depth=0.5, dbfs=-10.0)
+    g, r = ca.CAgc(), oracle.CAgc()
+    for o in (g, r):
+        o.SetParameters(True, False, -80, 0, 2, 300, fs)
+    ga, ra = ca.CAmDemod(fs), oracle.CAmDemod(fs)
+    gs, rs = ca.CSamDemod(fs), oracle.CSamDemod(fs)
+    gm, rm = ca.CSMeter(), oracle.CSMeter()
+    for k in range(len(cuts) - 1):
+        part = x[cuts[k]:cuts[k + 1]]
+        got, want = g.ProcessData(part), r.ProcessData(part)
+        assert len(got) == len(want) == len(part)
+        assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, ("agc", k)
+        assert np.abs(ga.ProcessData(part) - ra.ProcessData(part)).max() <= 1e-3 * FULL_SCALE, ("am", k)
+        sg, sr = gs.ProcessData(part), rs.ProcessData(part)
+        if cuts[k] >= 4000:
+            assert np.abs(sg - sr).max() <= 1e-3 * FULL_SCALE, ("sam", k)
+        gm.ProcessData(part, fs); rm.ProcessData(part, fs)
+        assert gm.GetAve() == pytest.approx(rm.GetAve(), abs=0.02), ("smeter", k)
+    fs = 62500.0
+    x = fm_carrier(int(cuts[-1]), fs, 300.0, fmod=1000.0, dev=3000.0, dbfs=-6.0, noise_dbfs=-60.0)
+    gf, rf = ca.CFmDemod(fs), oracle.CFmDemod(fs)
+    gf.SetSquelch(50); rf.SetSquelch(50)
+    for k in range(len(cuts) - 1):
+        part = x[cuts[k]:cuts[k + 1]]
+        got, want = gf.ProcessData(part, 5000.0), rf.ProcessData(part, 5000.0)
+        assert gf.squelched() == rf.squelched(), k
+        if cuts[k] >= 3000:
+            assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, ("fm", k)
