@@ -243,10 +243,14 @@ struct csdr_demod_batch {
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> joins;
     hipEvent_t fork = nullptr;
+    float *d_raw = nullptr, *d_blank = nullptr;      // unpacked / blanked input of process_packets
+    long raw_cap = 0;
     ~csdr_demod_batch()
     {
         for (auto *k : cores) delete k;
         for (auto *p : d_rows) if (p) (void)hipFree(p);
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_blank) (void)hipFree(d_blank);
         for (auto st : streams) (void)hipStreamDestroy(st);
         for (auto ev : joins) (void)hipEventDestroy(ev);
         if (fork) (void)hipEventDestroy(fork);
@@ -481,6 +485,34 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
         }
     }
     return err ? err : CSDR_OK;
+}
+int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets, int npackets, int pkt_len,
+                                     struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride,
+                                     void *stream)
+{
+    if (!b || !d_packets || !d_out || npackets < 0) return fail(CSDR_EINVAL, "bad argument");
+    if (pkt_len != 1028 && pkt_len != 1444) return fail(CSDR_EINVAL, "packet length %d", pkt_len);
+    if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (npackets == 0) return CSDR_OK;
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    const long n = (long)npackets * (pkt_len == 1444 ? 240 : 256);
+    if (n > b->raw_cap) {
+        if (b->d_raw) (void)hipFree(b->d_raw);
+        if (b->d_blank) (void)hipFree(b->d_blank);
+        b->d_raw = b->d_blank = nullptr; b->raw_cap = 0;
+        CSDR_HIP(hipMalloc((void **)&b->d_raw, (size_t)b->channels * n * 8));
+        CSDR_HIP(hipMalloc((void **)&b->d_blank, (size_t)b->channels * n * 8));
+        b->raw_cap = n;
+    }
+    int rc = csdr_ingest_unpack(b->device, d_packets, b->channels, npackets, pkt_len, b->d_raw, b->raw_cap, nullptr, stream);
+    if (rc < 0) return rc;
+    const float *src = b->d_raw;
+    if (nb) {
+        rc = csdr_noiseproc_batch_process(nb, b->d_raw, b->raw_cap, (int)n, b->d_blank, b->raw_cap, stream);
+        if (rc < 0) return rc;
+        src = b->d_blank;
+    }
+    return csdr_demod_batch_process(b, src, b->raw_cap, (int)n, d_out, out_stride, stream);
 }
 /* audio samples channel `channel` received in the last process call */
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel)

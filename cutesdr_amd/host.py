@@ -593,6 +593,22 @@ class DemodBatch(_Obj):
         check(lib().csdr_demod_batch_process(self.h, C.c_void_p(d_in), in_stride, n, C.c_void_p(d_out), out_stride,
                                              C.c_void_p(stream) if stream else None), "csdr_demod_batch_process")
 
+    def process_packets(self, raw, pkt_len, blanker=None):
+        """raw uint8 [channels, npackets, pkt_len] -> list of audio arrays (unpack, optional blanker, chain)"""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        assert raw.shape[0] == self.channels and raw.shape[2] == pkt_len
+        npk = raw.shape[1]
+        T = npk * (240 if pkt_len == 1444 else 256)
+        cap = T // 8 + self.n + 4096
+        dp, dout = DeviceBuffer(raw.nbytes, self.device), DeviceBuffer(self.channels * cap * 4, self.device)
+        dp.upload(raw)
+        check(lib().csdr_demod_batch_process_packets(self.h, C.c_void_p(dp.ptr), npk, pkt_len,
+                                                     blanker.h if blanker is not None else None,
+                                                     C.c_void_p(dout.ptr), cap, None), "csdr_demod_batch_process_packets")
+        sync(self.device)
+        flat = dout.download(np.float32, self.channels * cap).reshape(self.channels, cap)
+        return [flat[c, :check(lib().csdr_demod_batch_out_count(self.h, c))].copy() for c in range(self.channels)]
+
     def process(self, x):
         x = np.ascontiguousarray(x, dtype=np.complex64)
         T = x.shape[1]

@@ -97,3 +97,44 @@ def test_spurcal_matches_oracle(oracle):
         dg = ca.spurcal(dg, x[a:b]); dr = oracle.spurcal(dr, x[a:b])
         assert np.abs(dg - dr).max() <= 1e-9 * 50.0
     assert dg[0] == pytest.approx(12.5 * (1 - (1 - 1e-5) ** 300000), abs=0.6)     # + the noise the mean has not averaged out
+
+
+def test_packets_to_audio_whole_front_end(oracle):
+    """Datagrams -> unpack -> blanker -> down-converter -> FastFIR -> AGC -> demodulator, all on the
+    device (csdr_demod_batch_process_packets), against the oracle's composition of the same steps."""
+    import cutesdr_amd as ca
+    from util_signals import fm_carrier, am_carrier, FULL_SCALE
+    fs, C, npk = 2e6, 2, 2496                                # 2496 * 256 = 32 * 19968 samples per call
+    n = npk * 256
+    sig = [fm_carrier(2 * n, fs, 100e3, dbfs=-20.0), am_carrier(2 * n, fs, 101e3, dbfs=-20.0, channel=1)]
+    rng = np.random.default_rng(5)
+    for x in sig:                                             # impulses for the blanker to remove
+        hits = rng.random(2 * n) < 5e-5
+        x[hits] += 30000.0
+    def packets(x):                                           # 16-bit wire format, 4 header bytes per datagram
+        iq = np.empty(2 * len(x), dtype=np.int16)
+        iq[0::2] = np.clip(np.round(x.real), -32768, 32767); iq[1::2] = np.clip(np.round(x.imag), -32768, 32767)
+        body = iq.view(np.uint8).reshape(-1, 1024)
+        return np.concatenate([np.zeros((body.shape[0], 4), dtype=np.uint8), body], axis=1)
+    raw = np.stack([packets(x) for x in sig])                 # [C, 2*npk, 1028]
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    nb = ca.NoiseProcBatch(C); nb.setup(True, 30.0, 10.0, fs)
+    refs, rnb = [], []
+    for c, (name, f) in enumerate((("FM", -100e3), ("AM", -101e3))):
+        import test_postchain_gpu as T
+        m, kw = T.MODES[name]
+        b.set_demod(c, m, T.info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, T.info(oracle, **kw)); r.SetDemodFreq(f)
+        refs.append(r)
+        q = oracle.CNoiseProc(); q.SetupBlanker(True, 30.0, 10.0, fs); rnb.append(q)
+    b.commit()
+    b.set_freq(0, -100e3); b.set_freq(1, -101e3)
+    for call in range(2):
+        part = raw[:, call * npk:(call + 1) * npk]
+        got = b.process_packets(part, 1028, nb)
+        for c in range(C):
+            xs = oracle.unpack_packets(part[c], 1028)
+            want = refs[c].process_append(rnb[c].ProcessBlanker(xs))
+            assert len(got[c]) == len(want) > 0, c
+            if call == 1:
+                assert np.abs(got[c] - want).max() <= 1e-3 * FULL_SCALE, c
