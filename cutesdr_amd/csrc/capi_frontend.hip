@@ -15,7 +15,7 @@ struct NbHost {                          // the SetupBlanker comparands (noisepr
 
 struct csdr_noiseproc_batch {
     int device, channels;
-    NbChan *d_chan = nullptr;
+    NbChan *d_chan = nullptr;            // [2][channels], ping-pong with the history
     float *d_hist = nullptr;             // [2][channels][NB_HIST] complex
     int cur = 0;
     std::vector<NbHost> h;
@@ -46,7 +46,7 @@ static int nb_setup_one(csdr_noiseproc_batch *b, int c, int on, double thresh, d
     n.since_trig = 1LL << 40;
     h.configured = true; h.on = on != 0; h.thresh = thresh; h.width = width; h.fs = fs;
     CSDR_HIP(hipDeviceSynchronize());
-    CSDR_HIP(hipMemcpy(b->d_chan + c, &n, sizeof(n), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; k++) CSDR_HIP(hipMemcpy(b->d_chan + (size_t)k * b->channels + c, &n, sizeof(n), hipMemcpyHostToDevice));
     const size_t row = (size_t)NB_HIST * 8, half = (size_t)b->channels * row;
     for (int k = 0; k < 2; k++)           // SetupBlanker clears the delay and magnitude buffers (:108-115)
         CSDR_HIP(hipMemset((char *)b->d_hist + k * half + (size_t)c * row, 0, row));
@@ -61,7 +61,7 @@ csdr_noiseproc_batch *csdr_noiseproc_batch_create(int device, int channels)
     if (!device_ok(device)) return nullptr;
     csdr_noiseproc_batch *b = new csdr_noiseproc_batch();
     b->device = device; b->channels = channels; b->h.resize(channels);
-    if (hipMalloc((void **)&b->d_chan, sizeof(NbChan) * channels) != hipSuccess ||
+    if (hipMalloc((void **)&b->d_chan, sizeof(NbChan) * 2 * channels) != hipSuccess ||
         hipMalloc((void **)&b->d_hist, (size_t)2 * channels * NB_HIST * 8) != hipSuccess) {
         fail(CSDR_EHIP, "hipMalloc failed");
         delete b;
@@ -93,9 +93,19 @@ int csdr_noiseproc_batch_process(csdr_noiseproc_batch *b, const float *d_in, lon
     if (!device_ok(b->device)) return CSDR_EHIP;
     const size_t half = (size_t)b->channels * NB_HIST * 2;
     NbArgs a;
-    a.chan = b->d_chan; a.in = d_in; a.in_stride = in_stride; a.out = d_out; a.out_stride = out_stride;
+    a.chan = b->d_chan + (size_t)b->cur * b->channels; a.chan_next = b->d_chan + (size_t)(b->cur ^ 1) * b->channels; a.in = d_in; a.in_stride = in_stride; a.out = d_out; a.out_stride = out_stride;
     a.hist = b->d_hist + b->cur * half; a.hist_next = b->d_hist + (b->cur ^ 1) * half;
     a.channels = b->channels; a.n = n_per_channel;
+    // segments: enough workgroups to fill the chip, each at least 32 tiles long (the longest blank
+    // width is 4 tiles, the moving-sum reduction at a segment start another ~10-32 tiles' worth of reads)
+    long nseg = (1024 + b->channels - 1) / b->channels;
+    const long min_seg = 32 * 1024;
+    if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
+    if (nseg < 1) nseg = 1;
+    long seg_len = (n_per_channel + nseg - 1) / nseg;
+    seg_len = (seg_len + 1023) / 1024 * 1024;
+    a.seg_len = (int)seg_len;
+    a.nseg = (int)((n_per_channel + seg_len - 1) / seg_len);
     CSDR_HIP(noiseblank_launch(a, (hipStream_t)stream));
     b->cur ^= 1;
     return CSDR_OK;

@@ -16,11 +16,14 @@ struct NbChan {                         // CNoiseProc state (dsp/noiseproc.h:36-
 };
 
 struct NbArgs {
-    NbChan *chan;                       // [channels]
+    const NbChan *chan;                 // [channels] state at the start of the call
+    NbChan *chan_next;                  // [channels] state after it (ping-pong, like the history)
     const float *in;  long in_stride;   // complex fp32 [channels][in_stride]
     float *out;       long out_stride;  // complex fp32 [channels][out_stride]; may alias `in` only if hist is kept
     const float *hist; float *hist_next;    // [channels][NB_HIST] complex: the last NB_HIST inputs, ping-pong
     int channels, n;
+    int nseg, seg_len;                  // each channel's call is cut into nseg segments of seg_len samples (a
+                                        // multiple of 1024, >= 4 blank widths), one workgroup each
 };
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream);
 

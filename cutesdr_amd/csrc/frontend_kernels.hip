@@ -40,29 +40,49 @@ void noiseblank_kernel(NbArgs a)
 {
     __shared__ double wsum[NB_T / 64];
     __shared__ long long wmax[NB_T / 64];
-    const int ch = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
-    NbChan &C = a.chan[ch];
+    const int ch = blockIdx.x / a.nseg, seg = blockIdx.x % a.nseg, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const NbChan C = a.chan[ch];                        // state at the start of the call (the last segment writes chan_next)
     const f2 *in = reinterpret_cast<const f2 *>(a.in) + (long)ch * a.in_stride;
     f2 *out = reinterpret_cast<f2 *>(a.out) + (long)ch * a.out_stride;
     const f2 *hist = reinterpret_cast<const f2 *>(a.hist) + (long)ch * NB_HIST;
     f2 *hist_next = reinterpret_cast<f2 *>(a.hist_next) + (long)ch * NB_HIST;
     const int n = a.n;
     auto X = [&](long i) -> f2 { return i >= 0 ? in[i] : hist[NB_HIST + i]; };   // i >= -NB_HIST
+    // this workgroup's segment [seg_a, seg_b) of the call
+    const long seg_a = (long)seg * a.seg_len;
+    const long seg_b = seg_a + a.seg_len < n ? seg_a + a.seg_len : n;
+    const bool last_seg = seg == a.nseg - 1;
 
     if (C.on) {
         const int M1 = C.mag_n + 1, D1 = C.delay_n + 1, W = C.width_n;
         const double ratio = C.ratio;
         double S0 = C.sum;
         long long last = -C.since_trig;                    // index of the last trigger, relative to this call
-        for (int base = 0; base < n; base += NB_TILE) {
+        long first = 0;
+        if (seg > 0) {
+            // a later segment rebuilds its start state: the moving sum at its warm-up origin is a plain
+            // reduction over the mag_n+1 samples before it, and width_n samples of warm-up (outputs
+            // dropped) recover the blank window that may reach into the segment
+            first = seg_a - (long)((W + NB_TILE - 1) / NB_TILE) * NB_TILE;         // >= 0: seg_len >= 4 warm-ups
+            double part = 0.0;
+            for (long k = first - M1 + t; k < first; k += NB_T) { const f2 v = X(k); part += (double)fmaxf(fabsf(v.x), fabsf(v.y)); }
+            part = wave_incl_scan_add(part, lane);
+            if (lane == 63) wsum[w] = part;
+            __syncthreads();
+            S0 = 0.0;
+            for (int q = 0; q < NB_T / 64; q++) S0 += wsum[q];
+            last = -(1LL << 40);
+            __syncthreads();
+        }
+        for (long base = first; base < seg_b; base += NB_TILE) {
             f2 xd[NB_PER];
             float mag[NB_PER];
             double d[NB_PER], run = 0.0;
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                const long i = base + t * NB_PER + k;
+                const long i = base + (long)t * NB_PER + k;
                 mag[k] = 0.f; d[k] = 0.0; xd[k] = f2{0.f, 0.f};
-                if (i < n) {
+                if (i < seg_b) {
                     const f2 x = in[i], xo = X(i - M1);
                     xd[k] = X(i - D1);
                     mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
@@ -82,8 +102,8 @@ void noiseblank_kernel(NbArgs a)
             long long lt[NB_PER], runmax = -(1LL << 60);
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                const long i = base + t * NB_PER + k;
-                const bool trig = i < n && (double)mag[k] * ratio > off + d[k];
+                const long i = base + (long)t * NB_PER + k;
+                const bool trig = i < seg_b && (double)mag[k] * ratio > off + d[k];
                 if (trig) runmax = i;
                 lt[k] = runmax;
             }
@@ -98,8 +118,8 @@ void noiseblank_kernel(NbArgs a)
             for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                const long i = base + t * NB_PER + k;
-                if (i < n) {
+                const long i = base + (long)t * NB_PER + k;
+                if (i < seg_b && i >= seg_a) {
                     const long long l = lt[k] > before ? lt[k] : before;
                     out[i] = (i - l < W) ? f2{0.f, 0.f} : xd[k];
                 }
@@ -108,22 +128,28 @@ void noiseblank_kernel(NbArgs a)
             last = tile_last;
             __syncthreads();                               // wsum / wmax reused by the next tile
         }
-        if (t == 0) {
-            C.sum = S0;
+        if (t == 0 && last_seg) {
+            NbChan N = C;
+            N.sum = S0;
             long long age = (long long)n - last;
             if (age > (1LL << 40)) age = 1LL << 40;
-            C.since_trig = age;
+            N.since_trig = age;
+            a.chan_next[ch] = N;
         }
-    } else if (a.out != a.in) {
-        for (long i = t; i < n; i += NB_T) out[i] = in[i];  // off: the data passes through (:125-129)
+    } else {
+        if (t == 0 && last_seg) a.chan_next[ch] = C;
+    }
+    if (!C.on && a.out != a.in) {
+        for (long i = seg_a + t; i < seg_b; i += NB_T) out[i] = in[i];  // off: the data passes through (:125-129)
     }
     // the last NB_HIST inputs of [history | this call] are the next call's history
-    for (long j = t; j < NB_HIST; j += NB_T) hist_next[j] = X((long)n - NB_HIST + j);
+    if (last_seg)
+        for (long j = t; j < NB_HIST; j += NB_T) hist_next[j] = X((long)n - NB_HIST + j);
 }
 
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(noiseblank_kernel, dim3(a.channels), dim3(NB_T), 0, stream, a);
+    hipLaunchKernelGGL(noiseblank_kernel, dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -73,6 +73,34 @@ out["k3_ms"] = round(ms, 3)
 out["k3_MSps"] = round(C * 512 * 4096 / ms / 1e3, 1)
 out["k3_alg_GBps"] = round(C * 512 * 4096 * 12 / ms / 1e6, 1)
 
+# K6: noise blanker at input rate (16 B per sample: 8 in + 8 out), wire-format unpack (6 B in + 8 B out per sample)
+nbk = ca.NoiseProcBatch(C); nbk.setup(True, 50.0, 2.0, 2e6)
+xb = torch.empty_like(x)
+def k6():
+    nbk.process_ptr(x.data_ptr(), T, T, xb.data_ptr(), T, stream)
+for _ in range(2): k6()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5): k6()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+out["k6_blanker_ms"] = round(ms, 3)
+out["k6_blanker_alg_GBps"] = round(C * T * 16 / ms / 1e6, 1)
+npk = T // 240
+pk = torch.randint(0, 256, (C, npk, 1444), device=dev, dtype=torch.uint8)
+def k6u():
+    rc = ca.lib().csdr_ingest_unpack(0, pk.data_ptr(), C, npk, 1444, xb.data_ptr(), T, None, stream)
+    assert rc == npk * 240
+for _ in range(2): k6u()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5): k6u()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+out["k6_unpack24_ms"] = round(ms, 3)
+out["k6_unpack24_alg_GBps"] = round(C * npk * 240 * 14 / ms / 1e6, 1)
+del xb, pk
+
 if os.environ.get('K2_ONLY'):
     print(json.dumps(out)); sys.exit(0)
 
