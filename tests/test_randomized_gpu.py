@@ -82,3 +82,58 @@ def test_fm_sam_random_offsets_and_levels(oracle, seed):
             if seg_pos >= 2 and np.abs(got - want).max() > 1e-3 * FULL_SCALE:
                 bad += 1
         assert bad == 0, (seed, kind, stereo)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_downconvert_random_rates_and_calls(oracle, seed):
+    """Random input rate / bandwidth (hence decimator chain), NCO frequency, CW offset and call
+    lengths (multiples of the decimation, large enough for the reference's in-place stages:
+    SURVEY App. A.3), several calls per stream."""
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(3000 + seed)
+    in_rate = float(rng.choice([250e3, 1e6, 2e6, 5e6, 10e6]))
+    bw = float(rng.choice([500.0, 2000.0, 6000.0, 15000.0, 40000.0, 150000.0]))
+    freq = float(rng.uniform(-0.4, 0.4) * in_rate)
+    cw = float(rng.choice([0.0, 700.0, -650.0]))
+    g, r = ca.CDownConvert(), oracle.CDownConvert()
+    for o in (g, r):
+        o.SetCwOffset(cw)
+    assert g.SetDataRate(in_rate, bw) == r.SetDataRate(in_rate, bw)
+    assert g.stages() == r.stages()
+    for o in (g, r):
+        o.SetFrequency(freq)
+    assert g.nco_freq() == r.nco_freq()
+    ns = len(g.stages())
+    unit = 1 << ns
+    tol = 1e-5 * FULL_SCALE
+    for call in range(4):
+        n = int(rng.integers(40, 200)) * unit * 8            # every stage keeps more input than taps
+        n = min(n, 32768 // unit * unit)                     # the reference's half-band scratch holds 32768 samples
+        t = np.arange(n) + call * 100000
+        x = 8000.0 * np.exp(2j * np.pi * (-(freq + cw) + 0.3 * min(bw, in_rate / 8)) * t / in_rate) \
+            + 100.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        got, want = g.ProcessData(x), r.ProcessData(x)
+        assert len(got) == len(want) == n >> ns, (seed, call)
+        assert np.abs(got - want).max() <= tol, (seed, call, in_rate, bw, g.stages())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fastfir_random_filters_and_calls(oracle, seed):
+    import cutesdr_amd as ca
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([2048, 4096, 8192, 16384]))
+    fs = float(rng.choice([15625.0, 62500.0, 78125.0]))
+    lo = float(rng.uniform(-0.45, 0.2) * fs)
+    hi = float(lo + rng.uniform(0.02, 0.25) * fs)
+    off = float(rng.choice([0.0, 700.0]))
+    g, r = ca.CFastFIR(n), oracle.CFastFIR(n)
+    g.SetupParameters(lo, hi, off, fs); r.SetupParameters(lo, hi, off, fs)
+    total = 0
+    for call in range(6):
+        m = int(rng.choice([1, 240, 777, n // 2, n // 2 + 1, 3 * n + 5]))
+        x = 5000.0 * (rng.standard_normal(m) + 1j * rng.standard_normal(m))
+        got, want = g.ProcessData(x), r.ProcessData(x)
+        assert len(got) == len(want), (seed, call)
+        if len(want):
+            assert np.abs(got - want).max() <= 2e-5 * 5000.0 * 5, (seed, call, n)   # 5 sigma peaks of the noise
+        total += m
