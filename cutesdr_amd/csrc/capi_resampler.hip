@@ -120,3 +120,86 @@ int csdr_resampler_resample_cpx_i16(csdr_resampler *r, int n, double rate, const
 { return rs_run(r, n, rate, true, in_iq, nullptr, out_lr, gain); }
 
 }  // extern "C"
+
+/* ---------------- batch form: every channel on one clock ---------------- */
+struct csdr_resampler_batch {
+    int device, channels;
+    double t = 0.0;                      // m_FloatTime, shared
+    float *d_sinc = nullptr, *d_hist = nullptr;      // hist: [2][channels][RS_PERIODS]
+    double *d_times = nullptr; size_t cap_times = 0;
+    int cur = 0;
+    std::vector<double> times;
+};
+
+static int rs_build_sinc(float **d_sinc)
+{
+    std::vector<float> tab(RS_LEN);
+    for (int i = 0; i < RS_LEN; i++) {
+        const double w = 0.35875 - 0.48829 * std::cos((kTwoPi * i) / (RS_LEN - 1)) +
+                         0.14128 * std::cos((2.0 * kTwoPi * i) / (RS_LEN - 1)) -
+                         0.01168 * std::cos((3.0 * kTwoPi * i) / (RS_LEN - 1));
+        const double fi = kPi * (double)(i - RS_LEN / 2) / (double)RS_PTS;
+        tab[i] = (i != RS_LEN / 2) ? (float)(w * std::sin(fi) / fi) : 1.0f;
+    }
+    CSDR_HIP(hipMalloc((void **)d_sinc, sizeof(float) * RS_LEN));
+    CSDR_HIP(hipMemcpy(*d_sinc, tab.data(), sizeof(float) * RS_LEN, hipMemcpyHostToDevice));
+    return CSDR_OK;
+}
+
+extern "C" {
+
+csdr_resampler_batch *csdr_resampler_batch_create(int device, int channels)
+{
+    if (channels < 1) { fail(CSDR_EINVAL, "channels >= 1"); return nullptr; }
+    if (!device_ok(device)) return nullptr;
+    csdr_resampler_batch *b = new csdr_resampler_batch();
+    b->device = device; b->channels = channels;
+    const size_t hb = sizeof(float) * 2 * channels * RS_PERIODS;
+    if (rs_build_sinc(&b->d_sinc) != CSDR_OK || hipMalloc((void **)&b->d_hist, hb) != hipSuccess ||
+        hipMemset(b->d_hist, 0, hb) != hipSuccess) {
+        csdr_resampler_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+void csdr_resampler_batch_destroy(csdr_resampler_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->d_sinc) (void)hipFree(b->d_sinc);
+    if (b->d_hist) (void)hipFree(b->d_hist);
+    if (b->d_times) (void)hipFree(b->d_times);
+    delete b;
+}
+int csdr_resampler_batch_resample(csdr_resampler_batch *b, const float *d_in, long long in_stride, int n, double rate,
+                                  float *d_out_f32, short *d_out_i16, long long out_stride, double gain, void *stream)
+{
+    if (!b || !d_in || n < 0 || rate <= 0 || (!d_out_f32 == !d_out_i16)) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    // output times: the reference's sequential fp64 accumulation (fractresampler.cpp:157-178)
+    b->times.clear();
+    int it = (int)b->t;
+    while (it < n) { b->times.push_back(b->t); b->t += rate; it = (int)b->t; }
+    b->t -= (double)n;
+    const int nout = (int)b->times.size();
+    if (nout > out_stride) return fail(CSDR_EINVAL, "out_stride %lld < %d output samples", out_stride, nout);
+    if ((size_t)nout > b->cap_times) {
+        CSDR_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (b->d_times) (void)hipFree(b->d_times);
+        b->d_times = nullptr; b->cap_times = 0;
+        CSDR_HIP(hipMalloc((void **)&b->d_times, (size_t)nout * 2 * 8));
+        b->cap_times = (size_t)nout * 2;
+    }
+    if (nout) CSDR_HIP(hipMemcpyAsync(b->d_times, b->times.data(), (size_t)nout * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    CSDR_HIP(hipStreamSynchronize((hipStream_t)stream));      // b->times is reused by the next call
+    const size_t half = (size_t)b->channels * RS_PERIODS;
+    ResampleBatchArgs a;
+    a.in = d_in; a.in_stride = in_stride; a.hist = b->d_hist + b->cur * half; a.hist_next = b->d_hist + (b->cur ^ 1) * half;
+    a.sinc = b->d_sinc; a.times = b->d_times; a.out_f32 = d_out_f32; a.out_i16 = d_out_i16; a.out_stride = out_stride;
+    a.gain = (float)gain; a.channels = b->channels; a.n = n; a.nout = nout;
+    CSDR_HIP(resample_batch_launch(a, (hipStream_t)stream));
+    b->cur ^= 1;
+    return nout;
+}
+
+}  // extern "C"

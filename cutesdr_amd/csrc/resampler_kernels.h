@@ -19,4 +19,17 @@ struct ResampleArgs {
 };
 hipError_t resample_launch(const ResampleArgs &a, int n_in, hipStream_t s);
 
+// batch form: mono fp32 rows, every channel on the same clock (one set of output times)
+struct ResampleBatchArgs {
+    const float *in;  long in_stride;    // [channels][in_stride] real fp32, n valid per row
+    const float *hist; float *hist_next; // [channels][RS_PERIODS]: the last 28 inputs, ping-pong
+    const float *sinc;                   // [RS_LEN]
+    const double *times;                 // [nout], relative to the first history sample
+    float *out_f32; short *out_i16;      // [channels][out_stride], one of them
+    long out_stride;
+    float gain;
+    int channels, n, nout;
+};
+hipError_t resample_batch_launch(const ResampleBatchArgs &a, hipStream_t s);
+
 }  // namespace csdr

@@ -57,4 +57,39 @@ hipError_t resample_launch(const ResampleArgs &a, int n_in, hipStream_t s)
     return hipGetLastError();
 }
 
+// batch form: the chain's mono audio rows, all channels on one clock
+__global__ void resample_batch_kernel(ResampleBatchArgs a)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    const float *in = a.in + (long)ch * a.in_stride, *hist = a.hist + (long)ch * RS_PERIODS;
+    if (m < a.nout) {
+        const double t = a.times[m];
+        const int it = (int)t;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int i = 1; i <= RS_PERIODS; i++) {
+            const int j = it + i;
+            const int k = (int)(((double)j - t) * (double)RS_PTS);    // fractresampler.cpp:166
+            acc += (j < RS_PERIODS ? hist[j] : in[j - RS_PERIODS]) * a.sinc[k];
+        }
+        if (a.out_i16) {
+            const float x = fminf(fmaxf(acc * a.gain, -32767.0f), 32767.0f);
+            a.out_i16[(long)ch * a.out_stride + m] = (short)x;
+        } else {
+            a.out_f32[(long)ch * a.out_stride + m] = acc;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < RS_PERIODS) {                // next call's history (fractresampler.cpp:179-182)
+        const int j = a.n + threadIdx.x;
+        a.hist_next[(long)ch * RS_PERIODS + threadIdx.x] = j < RS_PERIODS ? hist[j] : in[j - RS_PERIODS];
+    }
+}
+
+hipError_t resample_batch_launch(const ResampleBatchArgs &a, hipStream_t s)
+{
+    const int gx = a.nout > 0 ? (a.nout + 255) / 256 : 1;
+    hipLaunchKernelGGL(resample_batch_kernel, dim3(gx, a.channels), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace csdr

@@ -729,3 +729,32 @@ class CFractResampler(_Obj):
         out = np.zeros(cap, dtype=np.int16)
         k = check(lib().csdr_resampler_resample_real_i16(self.h, len(a), Rate, _vp(a), _vp(out), gain))
         return out[:k]
+
+
+class ResamplerBatch(_Obj):
+    """CFractResampler over the chain's mono audio rows: [channels][n] fp32, all channels on one clock"""
+    _destroy = "csdr_resampler_batch_destroy"
+
+    def __init__(self, channels, device=0):
+        self.channels, self.device = channels, device
+        self.h = check_ptr(lib().csdr_resampler_batch_create(device, channels), "csdr_resampler_batch_create")
+
+    def resample_ptr(self, d_in, in_stride, n, rate, d_out, out_stride, gain=None, stream=None):
+        f32 = C.c_void_p(d_out) if gain is None else None
+        i16 = None if gain is None else C.c_void_p(d_out)
+        return check(lib().csdr_resampler_batch_resample(self.h, C.c_void_p(d_in), in_stride, n, rate, f32, i16, out_stride,
+                                                         0.0 if gain is None else gain,
+                                                         C.c_void_p(stream) if stream else None), "csdr_resampler_batch_resample")
+
+    def resample(self, x, rate, gain=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.shape[0] == self.channels
+        n = x.shape[1]
+        cap = int(n / rate) + 8
+        din = DeviceBuffer(max(x.nbytes, 4), self.device)
+        dout = DeviceBuffer(self.channels * cap * (4 if gain is None else 2), self.device)
+        din.upload(x)
+        k = self.resample_ptr(din.ptr, n, n, rate, dout.ptr, cap, gain)
+        sync(self.device)
+        out = dout.download(np.float32 if gain is None else np.int16, self.channels * cap).reshape(self.channels, cap)
+        return out[:, :k].copy()

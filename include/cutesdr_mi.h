@@ -309,6 +309,16 @@ int csdr_resampler_resample_real_i16(csdr_resampler *r, int n, double rate, cons
 int csdr_resampler_resample_cpx_i16(csdr_resampler *r, int n, double rate, const double *in_iq, short *out_lr,
                                     double gain);                            /* :194-249 */
 
+/* device-resident batch form for the chain's mono audio rows: [channels][stride] fp32 in; fp32 or
+ * int16 (scaled by gain, clipped, truncated: fractresampler.cpp:306-352) out.  Every channel runs
+ * on the same clock: one rate and one time accumulator (m_FloatTime) for the batch.  Returns the
+ * output samples per channel; asynchronous on `stream`. */
+typedef struct csdr_resampler_batch csdr_resampler_batch;
+csdr_resampler_batch *csdr_resampler_batch_create(int device, int channels);
+void csdr_resampler_batch_destroy(csdr_resampler_batch *b);
+int csdr_resampler_batch_resample(csdr_resampler_batch *b, const float *d_in, long long in_stride, int n, double rate,
+                                  float *d_out_f32, short *d_out_i16, long long out_stride, double gain, void *stream);
+
 /* ----------------------------------------------------------------------------------------
  * Input-rate stages in front of the down-converter
  *

@@ -143,3 +143,25 @@ def test_resampler_rate_varies_per_call_like_the_sound_sink(oracle):
         got, want = g.Resample(x, rate, gain), r.Resample(x, rate, gain)
         assert len(got) == len(want), k
         assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1, k
+
+
+def test_resampler_batch_rows_on_one_clock(oracle):
+    import cutesdr_amd as ca
+    C = 5
+    rng = np.random.default_rng(31)
+    b = ca.ResamplerBatch(C)
+    refs = [oracle.CFractResampler() for _ in range(C)]
+    for r in refs:
+        r.Init(8192)
+    rate = 62500.0 / 48000.0
+    for call, n in enumerate((1024, 1, 777, 4096, 2048)):
+        x = (6000.0 * rng.standard_normal((C, n))).astype(np.float32)
+        gain = None if call % 2 == 0 else 0.8
+        got = b.resample(x, rate * (1 + 1e-4 * call), gain)
+        for c in range(C):
+            want = refs[c].Resample(x[c].astype(np.float64), rate * (1 + 1e-4 * call), gain)
+            assert got.shape[1] == len(want), (call, c)
+            if gain is None:
+                assert np.abs(got[c] - want).max() <= 1e-5 * 6000.0 * 5, (call, c)
+            else:
+                assert np.abs(got[c].astype(np.int32) - want.astype(np.int32)).max() <= 1, (call, c)
