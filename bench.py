@@ -148,6 +148,9 @@ def cpu_baseline(budget_s=18.0):
                   "without it = lean_value" % (res["faithful_samples"], res["lean_samples"]),
         "lean_value": round(res["lean"], 3),
         "allcores_value": round(res["allcores"], 3), "allcores": ncores,
+        "true_reference_note": "the reference's own CFastFIR patched to 16384/8193 ran at 14.5 MSamples/s on one "
+                               "Xeon 2.1 GHz thread in the survey container (BASELINE.md section 2); it cannot be "
+                               "built on this box (Qt headers), so the timed code is the fp64 port",
     }
 
 

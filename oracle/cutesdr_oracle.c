@@ -21,9 +21,34 @@ static void *zalloc(size_t n) { void *p = calloc(1, n ? n : 1); return p; }
 /* FFT: plain iterative radix-2, same transform as the reference's Ooura cdft           */
 /* (dsp/fft.cpp:416-426: isgn=+1 forward has the POSITIVE exponent, no scaling).        */
 /* ==================================================================================== */
+/* cos/sin(2 pi k / n), k < n/2, built once per size (threads may race to build: the loser frees its
+ * copy).  A stage of length len uses every (n/len)-th entry: k/len and (k n/len)/n are the same
+ * double, so the values are exactly those of a per-stage cos/sin call. */
+static double *fft_twiddles(int n)
+{
+    static double *cache[32];
+    int lg = 0, k;
+    double *t;
+    while ((1 << lg) < n) lg++;
+    t = __atomic_load_n(&cache[lg], __ATOMIC_ACQUIRE);
+    if (t) return t;
+    t = (double *)malloc(sizeof(double) * (size_t)n);
+    for (k = 0; k < n / 2; k++) {
+        const double ang = TWO_PI * (double)k / (double)n;
+        t[2 * k] = cos(ang); t[2 * k + 1] = sin(ang);
+    }
+    {
+        double *expect = NULL;
+        if (!__atomic_compare_exchange_n(&cache[lg], &expect, t, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { free(t); t = expect; }
+    }
+    return t;
+}
+
 void orc_fft(int n, int sign, orc_cpx *a)
 {
     int i, j, len;
+    const double *tw = n > 1 ? fft_twiddles(n) : NULL;
+    const double sg = (double)sign;
     for (i = 1, j = 0; i < n; i++) {            /* bit reversal */
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -31,16 +56,16 @@ void orc_fft(int n, int sign, orc_cpx *a)
         if (i < j) { orc_cpx t = a[i]; a[i] = a[j]; a[j] = t; }
     }
     for (len = 2; len <= n; len <<= 1) {
-        int half = len >> 1, k, b;
-        for (k = 0; k < half; k++) {
-            double ang = sign * TWO_PI * (double)k / (double)len;
-            double wr = cos(ang), wi = sin(ang);
-            for (b = k; b < n; b += len) {
-                orc_cpx u = a[b], v = a[b + half], t;
+        const int half = len >> 1, step = n / len;
+        int k, b;
+        for (b = 0; b < n; b += len) {
+            for (k = 0; k < half; k++) {
+                const double wr = tw[2 * k * step], wi = sg * tw[2 * k * step + 1];
+                orc_cpx u = a[b + k], v = a[b + k + half], t;
                 t.re = v.re * wr - v.im * wi;
                 t.im = v.re * wi + v.im * wr;
-                a[b].re = u.re + t.re;          a[b].im = u.im + t.im;
-                a[b + half].re = u.re - t.re;   a[b + half].im = u.im - t.im;
+                a[b + k].re = u.re + t.re;          a[b + k].im = u.im + t.im;
+                a[b + k + half].re = u.re - t.re;   a[b + k + half].im = u.im - t.im;
             }
         }
     }
