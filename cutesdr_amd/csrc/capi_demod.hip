@@ -62,13 +62,14 @@ struct ChainCore {
         for (auto &e : ev_agc) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return CSDR_OK;
     }
-    // S-meter, AGC and demodulator of nb bursts.  Short calls: one fused launch.  Long calls: the
-    // S-meter on its own stream, AGC -> demodulator pipelined over burst groups through d_agc, so the
-    // three sequential recurrences of a channel overlap instead of adding up.
+    // S-meter, AGC and demodulator of nb bursts: one fused launch.  Optionally (long calls, see below) the
+    // S-meter on its own stream and AGC -> demodulator pipelined over burst groups through d_agc.
     int post(const float *filt, float *d_out, long out_stride, const int *d_out_rows, bool stereo, int nb, hipStream_t s)
     {
         const int st = stereo ? PC_STEREO : 0;
-        static const bool pipelined = !(getenv("CSDR_CHAIN_PIPELINE") && atoi(getenv("CSDR_CHAIN_PIPELINE")) == 0);
+        // off by default: with four waves per channel one fused launch already fills the chip and the
+        // extra launches cost more than the overlap returns (CSDR_CHAIN_PIPELINE=1 turns it on)
+        static const bool pipelined = getenv("CSDR_CHAIN_PIPELINE") && atoi(getenv("CSDR_CHAIN_PIPELINE")) != 0;
         if (nb < 16 || !pipelined)
             return pc.run(PC_DO_SMETER | PC_DO_AGC | PC_DO_DEMOD | st, filt, cap, d_out, out_stride, nb, L, s, d_out_rows);
         int rc = pipeline_init();

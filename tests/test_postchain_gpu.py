@@ -221,10 +221,22 @@ def test_demod_batch_mixed_modes(oracle):
         assert b.smeter_ave(c) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02)
 
 
-def test_batch_long_calls_use_the_stage_pipeline(oracle):
-    """Calls of >= 16 FastFIR hops run S-meter | AGC | demodulator as concurrent launches over burst
-    groups (capi_demod.hip ChainCore::post): same results as the fused launch / the oracle, whole
-    second call compared (the first one holds the lock-in transient)."""
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_batch_long_calls_fused_and_pipelined(oracle, pipeline, monkeypatch):
+    """Long calls (>= 16 FastFIR hops) through the fused launch and through the optional stage
+    pipeline (S-meter | AGC | demodulator as concurrent launches over burst groups, capi_demod.hip
+    ChainCore::post, CSDR_CHAIN_PIPELINE=1): same results as the oracle, whole second call compared
+    (the first one holds the lock-in transient).  The switch is read once per process, so the
+    pipelined case runs in a child interpreter."""
+    if pipeline == "1":
+        import subprocess, sys, os
+        env = dict(os.environ, CSDR_CHAIN_PIPELINE="1")
+        code = ("import sys; sys.path.insert(0, %r); import pytest; "
+                "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', "
+                "%r + '::test_batch_long_calls_fused_and_pipelined[0]']))" % (os.path.dirname(__file__), __file__))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     import cutesdr_amd as ca
     fs, C = 2e6, 4
     names = ["FM", "USB", "SAM", "AM"]
