@@ -1,5 +1,6 @@
 // capi_fastfir.hip -- C ABI for CFastFIR (single-channel host form and batched device form).
 #include "capi_common.hpp"
+#include <algorithm>
 #include "fastfir_kernels.h"
 #include "host_math.hpp"
 #include <cstdlib>
@@ -201,12 +202,20 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.channels = b->channels;
     a.nblocks = n_per_channel / L;
     if (blocks_per_wg <= 0) {
-        // enough workgroups to fill 256 CUs a few times over, runs as long as that allows
-        long want = 1024;
-        long runs = (want + b->channels - 1) / b->channels;
-        if (runs < 1) runs = 1;
-        if (runs > a.nblocks) runs = a.nblocks;
-        blocks_per_wg = (int)((a.nblocks + runs - 1) / runs);
+        // One workgroup walks a run of consecutive blocks of one channel.  Runs per channel: the count
+        // whose workgroups fill whole rounds of the resident slots best (256 CUs x workgroups per CU
+        // at this size: the LDS block is N*8.5 bytes), fewest runs on a tie -- longer runs re-read
+        // less overlap.  C3 (256 channels, N=16384): one run of 64 blocks per channel.
+        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : 8));
+        const long slots = 256 * per_cu;
+        long best_runs = 1; double best_eff = -1.0;
+        const long max_runs = std::min<long>(a.nblocks, std::max<long>(1, 4 * ((slots + b->channels - 1) / b->channels)));
+        for (long runs = 1; runs <= max_runs; runs++) {
+            const long wgs = runs * b->channels;
+            const double eff = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best_runs = runs; }
+        }
+        blocks_per_wg = (int)((a.nblocks + best_runs - 1) / best_runs);
     }
     if (blocks_per_wg > a.nblocks) blocks_per_wg = a.nblocks;
     a.blocks_per_run = blocks_per_wg;
