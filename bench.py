@@ -157,8 +157,8 @@ def cpu_baseline(budget_s=18.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)   # the first dozens of launches run ~13 % slower (clock ramp)
     ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU")
     ap.add_argument("--blocks-per-wg", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
