@@ -47,13 +47,13 @@ for c in range(C):
     dc.set_frequency(-100e3 - 500.0 * c, channel=c)
 def k2():
     dc.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T // 16, stream)
-for _ in range(2): k2()
+for _ in range(30): k2()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(5): k2()
+for _ in range(50): k2()
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
+ms = e0.elapsed_time(e1) / 50
 out["k2_ms"] = round(ms, 3)
 out["k2_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["k2_alg_GBps"] = round(C * T * (8 + 8 / 32) / ms / 1e6, 1)
@@ -63,12 +63,12 @@ fb = ca.FftBatch(C)
 fb.set_params(4096, False, 0.0, 2e6); fb.set_ave(4)
 def k3():
     fb.put_display_ptr(x.data_ptr(), T, 512, stream)
-for _ in range(2): k3()
+for _ in range(20): k3()
 torch.cuda.synchronize()
 e0.record()
-for _ in range(5): k3()
+for _ in range(30): k3()
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
+ms = e0.elapsed_time(e1) / 30
 out["k3_ms"] = round(ms, 3)
 out["k3_MSps"] = round(C * 512 * 4096 / ms / 1e3, 1)
 out["k3_alg_GBps"] = round(C * 512 * 4096 * 12 / ms / 1e6, 1)
@@ -78,12 +78,12 @@ nbk = ca.NoiseProcBatch(C); nbk.setup(True, 50.0, 2.0, 2e6)
 xb = torch.empty_like(x)
 def k6():
     nbk.process_ptr(x.data_ptr(), T, T, xb.data_ptr(), T, stream)
-for _ in range(2): k6()
+for _ in range(15): k6()
 torch.cuda.synchronize()
 e0.record()
-for _ in range(5): k6()
+for _ in range(30): k6()
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
+ms = e0.elapsed_time(e1) / 30
 out["k6_blanker_ms"] = round(ms, 3)
 out["k6_blanker_alg_GBps"] = round(C * T * 16 / ms / 1e6, 1)
 npk = T // 240
@@ -91,12 +91,12 @@ pk = torch.randint(0, 256, (C, npk, 1444), device=dev, dtype=torch.uint8)
 def k6u():
     rc = ca.lib().csdr_ingest_unpack(0, pk.data_ptr(), C, npk, 1444, xb.data_ptr(), T, None, stream)
     assert rc == npk * 240
-for _ in range(2): k6u()
+for _ in range(15): k6u()
 torch.cuda.synchronize()
 e0.record()
-for _ in range(5): k6u()
+for _ in range(30): k6u()
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
+ms = e0.elapsed_time(e1) / 30
 out["k6_unpack24_ms"] = round(ms, 3)
 out["k6_unpack24_alg_GBps"] = round(C * npk * 240 * 14 / ms / 1e6, 1)
 del xb, pk
@@ -122,11 +122,12 @@ for c in range(C):
 aud = torch.empty((C, T // 16 + 4096), device=dev, dtype=torch.float32)
 def chain():
     b.process_ptr(x.data_ptr(), T, T, aud.data_ptr(), T // 16 + 4096, stream)
-chain(); torch.cuda.synchronize()
+for _ in range(15): chain()
+torch.cuda.synchronize()
 e0.record()
-for _ in range(3): chain()
+for _ in range(30): chain()
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 3
+ms = e0.elapsed_time(e1) / 30
 out["chain_ms"] = round(ms, 3)
 out["chain_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["chain_alg_GBps"] = round(C * T * (8 + 4 / 32) / ms / 1e6, 1)

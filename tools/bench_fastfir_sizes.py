@@ -14,12 +14,12 @@ res = {}
 for n in (2048, 4096, 8192, 16384):
     ff = ca.FastFirBatch(C, n)
     ff.setup(-5000, 5000, 0, 62500.0)
-    for _ in range(3): ff.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T, st)
+    for _ in range(60): ff.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T, st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20): ff.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T, st)
+    for _ in range(200): ff.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T, st)
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
+    ms = e0.elapsed_time(e1) / 200
     res[n] = {"ms": round(ms, 4), "GBps": round(C * T * 16 / ms / 1e6, 1)}
 print(json.dumps(res))
