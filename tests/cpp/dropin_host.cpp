@@ -1,6 +1,7 @@
 // Stand-in for the reference host's use of the dsp/ classes (interface/sdrinterface.cpp:878-922:
 // CFft::PutInDisplayFFT + CDemodulator::ProcessData on 256-sample packets; interface/soundout.cpp:204:
-// CFractResampler), compiled against the drop-in headers with plain g++.
+// CFractResampler; the blanker CNoiseProc runs in place in front of both, sdrinterface.cpp:884),
+// compiled against the drop-in headers with plain g++.
 //   dropin_host <in.bin> <out_prefix> <mode> <fs> <freq>
 // in.bin: interleaved doubles.  Writes <prefix>.audio (doubles), <prefix>.spec (int32 x 700),
 // <prefix>.meta (text).
@@ -21,6 +22,7 @@
 #include "dsp/fmdemod.h"
 #include "dsp/ssbdemod.h"
 #include "dsp/fractresampler.h"
+#include "dsp/noiseproc.h"
 
 int main(int argc, char **argv)
 {
@@ -37,6 +39,7 @@ int main(int argc, char **argv)
     CDemodulator demod;                      // by-value members, as CSdrInterface holds them
     CFft fft;
     CFractResampler rs;
+    CNoiseProc nb;
     tDemodInfo info;
     info.HiCut = 5000; info.HiCutmin = 5000; info.HiCutmax = 15000; info.LowCut = -5000; info.LowCutmin = -15000;
     info.LowCutmax = -5000; info.FilterClickResolution = 100; info.Offset = 0; info.SquelchValue = 0;
@@ -48,6 +51,7 @@ int main(int argc, char **argv)
     fft.SetFFTParams(4096, false, 0.0, fs);
     fft.SetFFTAve(1);
     rs.Init(8192);
+    nb.SetupBlanker(true, 40.0, 10.0, fs);
 
     std::vector<double> audio, snd(16384);
     std::vector<TYPEREAL> out(8192);         // the host's stack buffer, sdrinterface.cpp:910
@@ -55,6 +59,7 @@ int main(int argc, char **argv)
     int total = 0, rtotal = 0;
     const double rate = demod.GetOutputRate() / 48000.0;
     for (size_t i = 0; i + 256 <= x.size(); i += 256) {
+        nb.ProcessBlanker(256, &x[i], &x[i]);       // in place, as the host does
         if (i + 256 - fftpos >= 4096) { fft.PutInDisplayFFT(4096, &x[fftpos]); fftpos += 4096; }
         const int n = demod.ProcessData(256, &x[i], out.data());
         if (n > 0) {

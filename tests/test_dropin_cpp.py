@@ -49,6 +49,8 @@ def test_dropin_host_matches_oracle(oracle, tmp_path):
     exe = build_exe()
     fs, n = 2e6, 19968 * 20
     x = fm_carrier(n, fs, 100e3, dbfs=-20.0)
+    x[np.random.default_rng(8).random(n) < 4e-5] += 28000.0     # impulses for the blanker
+    x = x.astype(np.complex64).astype(np.complex128)            # the device sees fp32: identical trigger decisions
     x.tofile(tmp_path / "in.bin")
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "o"), "2", str(fs), "-100000"],
                        capture_output=True, text=True, timeout=300)
@@ -59,8 +61,11 @@ def test_dropin_host_matches_oracle(oracle, tmp_path):
     d, f, rs = oracle.CDemodulator(2048), oracle.CFft(), oracle.CFractResampler()
     d.SetInputSampleRate(fs); d.SetDemod(oracle.DEMOD_FM, oracle.fm_defaults()); d.SetDemodFreq(-100e3)
     f.SetFFTParams(4096, False, 0.0, fs); f.SetFFTAve(1); rs.Init(8192)
+    nb = oracle.CNoiseProc(); nb.SetupBlanker(True, 40.0, 10.0, fs)
+    x = x.copy()
     want, wtotal, wr, fftpos = [], 0, 0, 0
     for i in range(0, n - 255, 256):
+        x[i:i + 256] = nb.ProcessBlanker(x[i:i + 256])             # in place in front of FFT and chain
         if i + 256 - fftpos >= 4096:
             f.PutInDisplayFFT(x[fftpos:fftpos + 4096]); fftpos += 4096
         k, o = d.ProcessData(x[i:i + 256])
