@@ -140,3 +140,16 @@ def test_full_size_properties():
     b.reset(); y2 = b.process(x2)
     b.reset(); y3 = b.process((2.0 * x1 + x2).astype(np.complex64))
     assert np.abs(y3 - (2.0 * y1 + y2)).max() <= 2e-5 * 6
+
+
+def test_selectable_16_wave_variant_in_child_process():
+    """CSDR_FASTFIR_VARIANT=1 selects the 16-wave 16384-point kernel (fastfir16k_kernels.hip); the
+    switch is read when a batch object is created, so the parity cases run in a child interpreter."""
+    import os, subprocess, sys
+    env = dict(os.environ, CSDR_FASTFIR_VARIANT="1")
+    here = os.path.dirname(__file__)
+    code = ("import sys; sys.path.insert(0, %r); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', '16384', %r]))"
+            % (here, os.path.join(here, "test_fastfir_gpu.py") + "::test_batch_matches_oracle_shared_filter"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
