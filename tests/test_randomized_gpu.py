@@ -137,3 +137,16 @@ def test_fastfir_random_filters_and_calls(oracle, seed):
         if len(want):
             assert np.abs(got - want).max() <= 2e-5 * 5000.0 * 5, (seed, call, n)   # 5 sigma peaks of the noise
         total += m
+
+
+def test_one_wave_per_channel_path_in_child_process():
+    """Launches of more than 1024 channels use one wave per channel (postchain_kernel<1>); the tests
+    above run with four.  CSDR_POSTCHAIN_WAVES=1 forces the one-wave kernel for the same sweep."""
+    import os, subprocess, sys
+    env = dict(os.environ, CSDR_POSTCHAIN_WAVES="1")
+    here = os.path.dirname(__file__)
+    code = ("import sys; sys.path.insert(0, %r); import pytest; "
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', 'agc_random or fm_sam_random', %r]))"
+            % (here, os.path.join(here, "test_randomized_gpu.py")))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
