@@ -4,6 +4,7 @@
 // CDemodulator::ProcessData call for call, and the batched multi-channel form.
 #include "capi_common.hpp"
 #include "pc_unit.hpp"
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -123,15 +124,19 @@ struct ChainCore {
     // one pass of the chain over n input samples per row (demodulator.cpp:172-207); returns the
     // audio samples produced per row (0 or a multiple of the FastFIR hop)
     int step(const float *d_in, long in_stride, const int *d_in_rows, int n, float *d_out, long out_stride,
-             const int *d_out_rows, bool stereo, hipStream_t s)
+             const int *d_out_rows, bool stereo, hipStream_t s, hipEvent_t dc_after = nullptr, hipEvent_t dc_done = nullptr)
     {
         const int m = csdr_downconvert_batch_out_count(dc, 0, n);
         if (m < 0) return m;
         int rc = ensure((long)pending + m);
         if (rc) return rc;
+        // the down-converters of the groups run one after the other (each fills the chip on its own);
+        // what follows a group's down-converter overlaps with the next group's
+        if (dc_after) CSDR_HIP(hipStreamWaitEvent(s, dc_after, 0));
         rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, d_stage + 2 * (size_t)pending,
                                                   cap, s);
         if (rc) return rc;
+        if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
         const int total = pending + m, nb = total / L;
         last_out = 0;
         if (nb > 0) {
@@ -243,6 +248,8 @@ struct csdr_demod_batch {
     // the groups are independent: each runs on its own stream, forked from and joined to the caller's
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> joins;
+    std::vector<int> order;                           // cores, heaviest post-chain first
+    std::vector<hipEvent_t> dc_done;                  // core -> its down-converter has been issued and finished
     hipEvent_t fork = nullptr;
     float *d_raw = nullptr, *d_blank = nullptr;      // unpacked / blanked input of process_packets
     long raw_cap = 0;
@@ -254,6 +261,7 @@ struct csdr_demod_batch {
         if (d_blank) (void)hipFree(d_blank);
         for (auto st : streams) (void)hipStreamDestroy(st);
         for (auto ev : joins) (void)hipEventDestroy(ev);
+        for (auto ev : dc_done) (void)hipEventDestroy(ev);
         if (fork) (void)hipEventDestroy(fork);
     }
 };
@@ -430,14 +438,34 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
             if (rc) return rc;
         }
     }
+    // The group whose post-chain is the longest pole (FM: PLL + squelch filters, at the highest
+    // decimated rate) goes first and on the highest-priority stream: its down-converter should not
+    // share the chip with the other groups' while its demodulators wait.
+    std::vector<double> weight(b->cores.size(), 0.0);
+    for (int c = 0; c < b->channels; c++) {
+        const int m = b->cfg[c].mode;
+        const double w = (m == PC_MODE_FM ? 3.0 : m == PC_MODE_SAM ? 2.5 : m == PC_MODE_AM ? 1.5 : 1.0) * b->cfg[c].out_rate;
+        weight[b->core_of[c]] = std::max(weight[b->core_of[c]], w);
+    }
+    b->order.resize(b->cores.size());
+    for (size_t i = 0; i < b->order.size(); i++) b->order[i] = (int)i;
+    std::sort(b->order.begin(), b->order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
     if (b->cores.size() > 1) {
         CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+        int pr_lo = 0, pr_hi = 0;                       // numerically lower = higher priority
+        CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        b->streams.resize(b->cores.size());
+        for (size_t rank = 0; rank < b->order.size(); rank++) {
+            int pr = pr_hi + (int)rank;
+            if (pr > pr_lo) pr = pr_lo;
+            CSDR_HIP(hipStreamCreateWithPriority(&b->streams[b->order[rank]], hipStreamNonBlocking, pr));
+        }
         for (size_t ki = 0; ki < b->cores.size(); ki++) {
-            hipStream_t st; hipEvent_t ev;
-            CSDR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            b->streams.push_back(st);
+            hipEvent_t ev;
             CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             b->joins.push_back(ev);
+            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            b->dc_done.push_back(ev);
         }
     }
     return CSDR_OK;
@@ -474,11 +502,14 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
     const bool forked = b->cores.size() > 1;
     if (forked) CSDR_HIP(hipEventRecord(b->fork, caller));
     int err = 0;
-    for (size_t ki = 0; ki < b->cores.size(); ki++) {
+    for (size_t oi = 0; oi < b->cores.size(); oi++) {
+        const size_t ki = (size_t)b->order[oi];
         hipStream_t st = forked ? b->streams[ki] : caller;
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
         const int rc = b->cores[ki]->step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride,
-                                          b->d_rows[ki], false, st);
+                                          b->d_rows[ki], false, st,
+                                          forked && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr,
+                                          forked ? b->dc_done[ki] : nullptr);
         if (rc < 0 && !err) err = rc;
         if (forked) {                                   // join even after an error: the caller's stream stays ordered
             CSDR_HIP(hipEventRecord(b->joins[ki], st));
