@@ -229,6 +229,29 @@ int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max
     return over ? 1 : 0;
 }
 
+int csdr_fft_batch_get_screen_all(csdr_fft_batch *f, int max_h, int max_w, double max_db, double min_db,
+                                  int start_hz, int stop_hz, int *d_out, long long out_stride, int *d_overload,
+                                  void *stream)
+{
+    if (!f || !d_out || max_w < 0 || out_stride < max_w) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    const int n = f->size, maxbin = n - 1;
+    ScreenArgs a;
+    a.ave = f->d_ave; a.out = d_out; a.out_stride = out_stride; a.n = n; a.channels = f->channels;
+    a.bin_min = (int)((double)start_hz * (double)n / f->fs) + n / 2;      // fft.cpp:336-349
+    a.bin_max = (int)((double)stop_hz * (double)n / f->fs) + n / 2;
+    if (a.bin_min < 0) a.bin_min = 0;
+    if (a.bin_min >= maxbin) a.bin_min = maxbin;
+    if (a.bin_max < 0) a.bin_max = 0;
+    if (a.bin_max >= maxbin) a.bin_max = maxbin;
+    a.plot_w = max_w; a.max_h = max_h; a.invert = f->invert;
+    a.off = max_db / 10.0; a.gain = -10.0 / (max_db - min_db);
+    CSDR_HIP(screen_launch(a, (hipStream_t)stream));
+    if (d_overload)
+        CSDR_HIP(hipMemcpyAsync(d_overload, f->d_over, sizeof(int) * f->channels, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CSDR_OK;
+}
+
 }  // extern "C"
 
 /* ---------------- single-channel host form: CFft drop-in ---------------- */

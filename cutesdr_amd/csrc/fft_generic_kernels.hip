@@ -102,4 +102,54 @@ hipError_t fft_generic_plain_launch(int log2n, int sign, const float *in, float 
     return hipGetLastError();
 }
 
+// ---------------- screen mapping for a batch of spectra ----------------
+__device__ __forceinline__ int screen_level(const ScreenArgs &a, const float *ave, int bin)
+{
+    int b = a.invert ? (a.n - bin) : bin;
+    if (b >= a.n) b = a.n - 1;                          // the reference reads one past the end here
+    int v = (int)((double)a.max_h * a.gain * ((double)ave[b] - a.off));
+    return v < 0 ? 0 : (v > a.max_h ? a.max_h : v);
+}
+// more bins than pixels: pixel x shows the smallest y (= strongest bin) of the bins that map to it
+// (fft.cpp:372-389: first bin of a pixel sets it, later smaller values replace it)
+__global__ void screen_bins_kernel(ScreenArgs a)
+{
+    const int i = a.bin_min + blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (i > a.bin_max) return;
+    const int x = ((i - a.bin_min) * a.plot_w) / (a.bin_max - a.bin_min);
+    if (x >= a.plot_w) return;                          // the reference writes OutBuf[MaxWidth] here
+    atomicMin(&a.out[(long)ch * a.out_stride + x], screen_level(a, a.ave + (long)ch * a.n, i));
+}
+__global__ void screen_fill_kernel(ScreenArgs a, int value)
+{   // pixels that receive at least one bin start from "+infinity" for the atomicMin
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (x >= a.plot_w) return;
+    // pixel x receives a bin iff some i in [bin_min, bin_max] has ((i-bin_min)*plot_w)/(range) == x
+    const long range = a.bin_max - a.bin_min;
+    const long lo = ((long)x * range + a.plot_w - 1) / a.plot_w;       // smallest i-bin_min with value >= x
+    if (lo <= range && (lo * a.plot_w) / range == x) a.out[(long)ch * a.out_stride + x] = value;
+}
+// at least as many pixels as bins: pixel x shows bin bin_min + x*range/plot_w (fft.cpp:391-407)
+__global__ void screen_pixels_kernel(ScreenArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (x >= a.plot_w) return;
+    const int xi = x < a.n ? x : a.n - 1;               // the translate table has n entries
+    const int bin = a.bin_min + (xi * (a.bin_max - a.bin_min)) / a.plot_w;
+    a.out[(long)ch * a.out_stride + x] = screen_level(a, a.ave + (long)ch * a.n, bin);
+}
+
+hipError_t screen_launch(const ScreenArgs &a, hipStream_t st)
+{
+    if (a.plot_w <= 0) return hipSuccess;
+    if ((a.bin_max - a.bin_min) > a.plot_w) {
+        hipLaunchKernelGGL(screen_fill_kernel, dim3((a.plot_w + 255) / 256, a.channels), dim3(256), 0, st, a, 0x7fffffff);
+        const int nb = a.bin_max - a.bin_min + 1;
+        hipLaunchKernelGGL(screen_bins_kernel, dim3((nb + 255) / 256, a.channels), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(screen_pixels_kernel, dim3((a.plot_w + 255) / 256, a.channels), dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace csdr

@@ -21,6 +21,15 @@ hipError_t spectrum_launch(int log2n, const SpectrumArgs &a, hipStream_t stream)
 hipError_t fft_plain_launch(int log2n, int sign, const float *in, float *out, const float *tw1,
                             const float *tw2, hipStream_t stream);
 
+// CFft::GetScreenIntegerFFTData (fft.cpp:308-410) for every channel: ave [channels][n] bels (display order)
+// -> out [channels][out_stride] pixels; the bin range / pixel count come precomputed from the host
+struct ScreenArgs {
+    const float *ave; int *out; long out_stride;
+    int n, channels, bin_min, bin_max, plot_w, max_h, invert;
+    double off, gain;                   // MaxdB/10 and -10/(MaxdB-MindB)
+};
+hipError_t screen_launch(const ScreenArgs &a, hipStream_t stream);
+
 // sizes outside 2048..16384 (512, 1024, 32768, 65536): multi-launch transform through HBM.
 // work: [2][channels][N] complex for the spectrum, [2][N] for the plain transform
 hipError_t spectrum_generic_launch(int log2n, const SpectrumArgs &a, float *work, hipStream_t stream);

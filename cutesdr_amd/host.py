@@ -696,6 +696,18 @@ class FftBatch(_Obj):
         check(lib().csdr_fft_batch_get_ave(self.h, channel, _vp(out)))
         return out
 
+    def screen_all(self, MaxHeight, MaxWidth, MaxdB, MindB, StartFreq, StopFreq):
+        """GetScreenIntegerFFTData of every channel at once on the device -> (overload [C], pixels [C, MaxWidth])"""
+        dout = DeviceBuffer(self.channels * max(MaxWidth, 1) * 4, self.device)
+        dov = DeviceBuffer(self.channels * 4, self.device)
+        dout.upload(np.full(self.channels * max(MaxWidth, 1), -1, dtype=np.int32))
+        check(lib().csdr_fft_batch_get_screen_all(self.h, MaxHeight, MaxWidth, MaxdB, MindB, StartFreq, StopFreq,
+                                                  C.c_void_p(dout.ptr), max(MaxWidth, 1), C.c_void_p(dov.ptr), None),
+              "csdr_fft_batch_get_screen_all")
+        sync(self.device)
+        return (dov.download(np.int32, self.channels) != 0,
+                dout.download(np.int32, self.channels * max(MaxWidth, 1)).reshape(self.channels, -1))
+
     def total_count(self, channel):
         return check(lib().csdr_fft_batch_get_total_count(self.h, channel))
 

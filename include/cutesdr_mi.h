@@ -293,6 +293,13 @@ int csdr_fft_batch_get_ave(csdr_fft_batch *f, int channel, float *out);
 int csdr_fft_batch_get_total_count(csdr_fft_batch *f, int channel);
 int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max_w, double max_db,
                               double min_db, int start_hz, int stop_hz, int *out);
+/* the same mapping for every channel at once, on the device: d_out is
+ * [channels][out_stride] int32 on the device, out_stride >= max_w; pixels that no bin maps to keep
+ * what d_out held (the reference leaves them untouched too).  d_overload: optional [channels] int32,
+ * the overload flag of each channel's last PutInDisplayFFT.  Asynchronous on `stream`. */
+int csdr_fft_batch_get_screen_all(csdr_fft_batch *f, int max_h, int max_w, double max_db, double min_db,
+                                  int start_hz, int stop_hz, int *d_out, long long out_stride, int *d_overload,
+                                  void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * CFractResampler (dsp/fractresampler.h:17-33)

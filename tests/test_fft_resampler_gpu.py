@@ -165,3 +165,30 @@ def test_resampler_batch_rows_on_one_clock(oracle):
                 assert np.abs(got[c] - want).max() <= 1e-5 * 6000.0 * 5, (call, c)
             else:
                 assert np.abs(got[c].astype(np.int32) - want.astype(np.int32)).max() <= 1, (call, c)
+
+
+@pytest.mark.parametrize("invert", [False, True])
+def test_screen_mapping_on_device_for_all_channels(oracle, invert):
+    """csdr_fft_batch_get_screen_all (device, every channel) against the per-channel host mapping and
+    the oracle: more bins than pixels (per-pixel strongest bin), fewer bins than pixels, a narrow span."""
+    import ctypes as C
+    import cutesdr_amd as ca
+    n, Cn, fs = 4096, 3, 2e6
+    b = ca.FftBatch(Cn)
+    b.set_params(n, invert, 0.0, fs); b.set_ave(1)
+    x = np.stack([tones_plus_noise(70 + c, n, fs, [150e3 * (c + 1), -333e3]) for c in range(Cn)])
+    b.put_display(x)
+    refs = []
+    for c in range(Cn):
+        r = oracle.CFft(); r.SetFFTParams(n, invert, 0.0, fs); r.SetFFTAve(1); r.PutInDisplayFFT(x[c]); refs.append(r)
+    for (h, w, lo, hi) in ((255, 700, -900000, 900000), (1000, 3000, -250000, 250000), (400, 300, 100000, 180000)):
+        ov, pix = b.screen_all(h, w, 0.0, -160.0, lo, hi)
+        for c in range(Cn):
+            one = np.full(w + 1, -1, dtype=np.int32)
+            rc = ca.lib().csdr_fft_batch_get_screen(b.h, c, h, w, 0.0, -160.0, lo, hi, one.ctypes.data_as(C.c_void_p))
+            assert rc >= 0
+            assert np.array_equal(pix[c], one[:w]), (c, h, w)
+            _, want = refs[c].GetScreenIntegerFFTData(h, w, 0.0, -160.0, lo, hi)
+            touched = pix[c] >= 0                             # pixels no bin maps to stay as they were
+            assert np.abs(pix[c][touched] - want[touched]).max() <= 1, (c, h, w)
+        assert not ov.any()
