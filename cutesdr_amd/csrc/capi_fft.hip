@@ -23,6 +23,7 @@ struct csdr_fft_batch {
     std::vector<int> xlat;
     float *d_win, *d_tw1, *d_tw2, *d_sum, *d_pwr, *d_ave;
     float *d_work;                               // transform work space of the multi-launch sizes
+    float *d_part = nullptr; size_t part_cap = 0; // frame-group partial sums
     int *d_cnt, *d_over;
     std::vector<float> h_ave;
     std::vector<int> h_over;
@@ -113,6 +114,7 @@ void csdr_fft_batch_destroy(csdr_fft_batch *f)
     fft_free_dev(f);
     if (f->d_cnt) (void)hipFree(f->d_cnt);
     if (f->d_over) (void)hipFree(f->d_over);
+    if (f->d_part) (void)hipFree(f->d_part);
     delete f;
 }
 int csdr_fft_batch_set_params(csdr_fft_batch *f, int size, int invert, double db_comp, double fs)
@@ -147,6 +149,23 @@ int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long i
     a.in = d_in; a.in_stride = in_stride; a.win = f->d_win; a.tw1 = f->d_tw1; a.tw2 = f->d_tw2;
     a.sum = f->d_sum; a.pwr = f->d_pwr; a.ave = f->d_ave; a.counters = f->d_cnt; a.overload = f->d_over;
     a.channels = f->channels; a.nframes = nframes; a.ave_size = f->ave_size;
+    // long calls on few channels: cut each channel's frames into groups so that ~1024 workgroups exist
+    a.nparts = 1; a.part = nullptr;
+    {
+        long np = (1024 + f->channels - 1) / f->channels;
+        if (np > nframes / 8) np = nframes / 8;
+        if (np > 1) {
+            const size_t need = (size_t)f->channels * np * f->size;
+            if (need > f->part_cap) {
+                CSDR_HIP(hipStreamSynchronize((hipStream_t)stream));
+                if (f->d_part) (void)hipFree(f->d_part);
+                f->d_part = nullptr; f->part_cap = 0;
+                CSDR_HIP(hipMalloc((void **)&f->d_part, need * 4));
+                f->part_cap = need;
+            }
+            a.nparts = (int)np; a.part = f->d_part;
+        }
+    }
     a.kc = (float)f->kc; a.kb = f->kb;
     const int l2 = log2_of(f->size);
     if (l2 >= 11 && l2 <= 14) CSDR_HIP(spectrum_launch(l2, a, (hipStream_t)stream));

@@ -13,6 +13,8 @@ struct SpectrumArgs {
     int *counters;                      // [channels][2]: ave_count, total_count
     int *overload;                      // [channels]
     int channels, nframes, ave_size;
+    int nparts;                         // frame groups per channel (1: the frames of a channel run in one workgroup)
+    float *part;                        // [channels][nparts][N] partial sums, nparts > 1 only
     float kc; double kb;
 };
 hipError_t spectrum_launch(int log2n, const SpectrumArgs &a, hipStream_t stream);

@@ -78,7 +78,11 @@ void spectrum_kernel(SpectrumArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f *lds = reinterpret_cast<v2f *>(smem_raw);
     v2f *tw2 = lds + Cfg::LDS_DATA;
-    const int t = threadIdx.x, ch = blockIdx.x;
+    // With nparts > 1 the frames of a channel are cut into nparts groups, one workgroup each: the
+    // running sum is the linear map sum <- alpha_f sum + p_f, so a group accumulates its frames from
+    // zero into `part` and spectrum_combine_kernel folds the groups in order.
+    const int t = threadIdx.x, ch = blockIdx.x / a.nparts, part = blockIdx.x % a.nparts;
+    const int f0 = (int)((long)a.nframes * part / a.nparts), f1 = (int)((long)a.nframes * (part + 1) / a.nparts);
     for (int i = t; i < 1024; i += T) tw2[i] = reinterpret_cast<const v2f *>(a.tw2)[i];
     v2f w1[G];
 #pragma unroll
@@ -86,6 +90,8 @@ void spectrum_kernel(SpectrumArgs a)
     const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
     float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
     int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    total += f0;                                              // counters at this group's first frame
+    ave_count = ave_count + f0 < a.ave_size ? ave_count + f0 : (ave_count > a.ave_size ? ave_count : a.ave_size);
     int over = 0;
     // every thread owns the same 32 bins in every frame: the running sum and mean stay in registers
     // for the whole call, only the last frame's bels are written
@@ -96,9 +102,9 @@ void spectrum_kernel(SpectrumArgs a)
     static_for<0, 32>([&](auto Rr) {
         constexpr int r = Rr.value, k2 = bitrev<32>(r);
         const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);     // display order, fft.cpp:564-589
-        sm[r] = sum[j];
+        sm[r] = a.nparts == 1 ? sum[j] : 0.f;
     });
-    for (int f = 0; f < a.nframes; f++) {
+    for (int f = f0; f < f1; f++) {
         const v2f *src = in + (long)f * N;
         v2f x[32];
 #pragma unroll
@@ -123,7 +129,13 @@ void spectrum_kernel(SpectrumArgs a)
             else sm[r] = sm[r] - sm[r] / prev_count + p;          // minus the previous mean (fft.cpp:570-574)
         });
     }
-    if (a.nframes > 0) {
+    if (a.nparts > 1) {
+        float *dst = a.part + ((long)ch * a.nparts + part) * N;
+        static_for<0, 32>([&](auto Rr) {
+            constexpr int r = Rr.value, k2 = bitrev<32>(r);
+            dst[((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1)] = sm[r];
+        });
+    } else if (a.nframes > 0) {
         static_for<0, 32>([&](auto Rr) {
             constexpr int r = Rr.value, k2 = bitrev<32>(r);
             const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);
@@ -133,7 +145,7 @@ void spectrum_kernel(SpectrumArgs a)
             if constexpr ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         });
     }
-    if (t == 0) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }
+    if (t == 0 && a.nparts == 1) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }
     if (over) a.overload[ch] = 1;
 }
 
@@ -171,6 +183,39 @@ void fft_plain_kernel(const v2f *in, v2f *out, const v2f *tw1g, const v2f *tw2g,
     });
 }
 
+// folds the frame groups of spectrum_kernel (nparts > 1) into the running sum, writes mean and bels,
+// advances the counters
+__global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (j >= n) return;
+    int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    float sm = a.sum[(long)ch * n + j];
+    for (int g = 0; g < a.nparts; g++) {
+        const int f0 = (int)((long)a.nframes * g / a.nparts), f1 = (int)((long)a.nframes * (g + 1) / a.nparts);
+        float al = 1.f;                                            // product of the group's alpha_f
+        for (int f = f0; f < f1; f++) {
+            const float prev = (float)ave_count;
+            total++;
+            if (ave_count < a.ave_size) ave_count++;
+            if (total > a.ave_size) al = al - al / prev;
+        }
+        sm = al * sm + a.part[((long)ch * a.nparts + g) * n + j];
+    }
+    const float m = sm / (float)ave_count;
+    a.sum[(long)ch * n + j] = sm; a.pwr[(long)ch * n + j] = m;
+    a.ave[(long)ch * n + j] = (float)((double)log10f(m + a.kc) + a.kb);
+}
+// the counters move once per channel, after every bin has read them
+__global__ void spectrum_count_kernel(SpectrumArgs a)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.channels) return;
+    int ave_count = a.counters[2 * ch] + a.nframes;
+    a.counters[2 * ch] = ave_count < a.ave_size ? ave_count : (a.counters[2 * ch] > a.ave_size ? a.counters[2 * ch] : a.ave_size);
+    a.counters[2 * ch + 1] += a.nframes;
+}
+
 template <int LOG2N>
 static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
 {
@@ -178,7 +223,11 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spectrum_kernel<LOG2N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
+    if (a.nparts > 1) {
+        hipLaunchKernelGGL(spectrum_combine_kernel, dim3(Cfg::N / 256, a.channels), dim3(256), 0, s, a, (int)Cfg::N);
+        hipLaunchKernelGGL(spectrum_count_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
+    }
     return hipGetLastError();
 }
 template <int LOG2N>

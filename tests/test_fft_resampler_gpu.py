@@ -192,3 +192,25 @@ def test_screen_mapping_on_device_for_all_channels(oracle, invert):
             touched = pix[c] >= 0                             # pixels no bin maps to stay as they were
             assert np.abs(pix[c][touched] - want[touched]).max() <= 1, (c, h, w)
         assert not ov.any()
+
+
+@pytest.mark.parametrize("ave", [1, 3, 10])
+def test_fft_batch_many_frames_are_split_into_groups(oracle, ave):
+    """Calls with many frames on few channels cut each channel's frames into groups (one workgroup
+    each, running sum folded afterwards as a linear map): same spectrum as the frame-by-frame oracle,
+    across two calls (warm-up of the average inside the first, steady state in the second)."""
+    import cutesdr_amd as ca
+    n, C, frames, fs = 2048, 2, 72, 2e6
+    b = ca.FftBatch(C)
+    b.set_params(n, False, 0.0, fs); b.set_ave(ave)
+    refs = []
+    for c in range(C):
+        r = oracle.CFft(); r.SetFFTParams(n, False, 0.0, fs); r.SetFFTAve(ave); refs.append(r)
+    for call in range(2):
+        x = np.stack([tones_plus_noise(90 + c + 7 * call, frames * n, fs, [120e3 * (c + 1), -400e3 + 50e3 * call]) for c in range(C)])
+        b.put_display(x)
+        for c in range(C):
+            for k in range(frames):
+                refs[c].PutInDisplayFFT(x[c, k * n:(k + 1) * n])
+            assert b.total_count(c) == frames * (call + 1)
+            assert_spectrum_close(b.ave_buf(c).astype(np.float64), refs[c].ave_buf())
