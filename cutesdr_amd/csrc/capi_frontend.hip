@@ -4,6 +4,7 @@
 #include "capi_common.hpp"
 #include "frontend_kernels.h"
 #include <cmath>
+#include <cstdint>
 #include <vector>
 
 using namespace csdr;
@@ -174,6 +175,8 @@ int csdr_ingest_unpack(int device, const void *d_packets, int channels, int npac
                     "datagrams", pkt_len);
     const int per = pkt_len == 1444 ? 240 : 256;
     if ((long long)npackets * per > out_stride) return fail(CSDR_EINVAL, "out_stride too small");
+    if ((out_stride & 1) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_packets & 3))
+        return fail(CSDR_EINVAL, "unpack: d_packets must be 4-byte aligned, d_out 16-byte aligned, out_stride even");
     if (!device_ok(device)) return CSDR_EHIP;
     CSDR_HIP(unpack_launch((const unsigned char *)d_packets, (long)npackets * pkt_len, channels, npackets, pkt_len,
                            d_out, out_stride, d_dc, (hipStream_t)stream));

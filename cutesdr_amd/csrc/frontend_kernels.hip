@@ -154,36 +154,47 @@ hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 }
 
 // ---------------- wire format -> complex fp32 ----------------
+// A thread converts two consecutive samples of a datagram with aligned 32-bit loads (datagram
+// lengths, the 4-byte header and a sample pair -- 12 or 8 bytes -- are all multiples of 4) and one
+// 16-byte store.
 __global__ void unpack_kernel(const unsigned char *pk, long chan_stride, int npackets, int pkt_len, int per,
                               float *out, long out_stride, const double *dc)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // complex sample within the channel
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;        // sample pair within the channel
     const int ch = blockIdx.y;
-    if (i >= (long)npackets * per) return;
-    const long p = i / per;
-    const int j = (int)(i - p * per);
-    const unsigned char *b = pk + (long)ch * chan_stride + p * pkt_len + 4;
-    float re, im;
-    if (pkt_len == 1444) {                                            // 24 bit: << 8 into an int32, / 65536
-        b += 6 * j;
-        const int vi = (int)(((unsigned)b[0] << 8) | ((unsigned)b[1] << 16) | ((unsigned)b[2] << 24));
-        const int vq = (int)(((unsigned)b[3] << 8) | ((unsigned)b[4] << 16) | ((unsigned)b[5] << 24));
-        re = (float)vi * (1.0f / 65536.0f); im = (float)vq * (1.0f / 65536.0f);   // exact: 24 significant bits
+    const int half = per / 2;
+    if (p >= (long)npackets * half) return;
+    const long q = p / half;
+    const int j = (int)(p - q * half);
+    const unsigned *w = reinterpret_cast<const unsigned *>(pk + (long)ch * chan_stride + q * pkt_len + 4);
+    float v[4];
+    if (pkt_len == 1444) {                                            // 24 bit: value << 8 in an int32, / 65536
+        const unsigned d0 = w[3 * j], d1 = w[3 * j + 1], d2 = w[3 * j + 2];
+        const int i0 = (int)(d0 << 8);
+        const int q0 = (int)(((d0 >> 24) << 8) | (d1 << 16));
+        const int i1 = (int)(((d1 >> 16) << 8) | (d2 << 24));
+        const int q1 = (int)(d2 & 0xffffff00u);
+        v[0] = (float)i0 * (1.0f / 65536.0f); v[1] = (float)q0 * (1.0f / 65536.0f);   // exact: 24 significant bits
+        v[2] = (float)i1 * (1.0f / 65536.0f); v[3] = (float)q1 * (1.0f / 65536.0f);
     } else {                                                          // 16 bit
-        b += 4 * j;
-        re = (float)(short)((unsigned short)b[0] | ((unsigned short)b[1] << 8));
-        im = (float)(short)((unsigned short)b[2] | ((unsigned short)b[3] << 8));
+        const unsigned d0 = w[2 * j], d1 = w[2 * j + 1];
+        v[0] = (float)(short)(d0 & 0xffffu); v[1] = (float)(short)(d0 >> 16);
+        v[2] = (float)(short)(d1 & 0xffffu); v[3] = (float)(short)(d1 >> 16);
     }
-    if (dc) { re = (float)((double)re - dc[2 * ch]); im = (float)((double)im - dc[2 * ch + 1]); }
-    float *o = out + 2 * ((long)ch * out_stride + i);
-    o[0] = re; o[1] = im;
+    if (dc) {
+        const double di = dc[2 * ch], dq = dc[2 * ch + 1];
+        v[0] = (float)((double)v[0] - di); v[1] = (float)((double)v[1] - dq);
+        v[2] = (float)((double)v[2] - di); v[3] = (float)((double)v[3] - dq);
+    }
+    float4 *o = reinterpret_cast<float4 *>(out + 2 * ((long)ch * out_stride + q * per + 2 * j));
+    *o = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 hipError_t unpack_launch(const unsigned char *pk, long chan_stride_bytes, int channels, int npackets, int pkt_len,
                          float *out, long out_stride, const double *dc, hipStream_t stream)
 {
     const int per = pkt_len == 1444 ? 240 : 256;
-    const long tot = (long)npackets * per;
+    const long tot = (long)npackets * (per / 2);
     if (tot == 0) return hipSuccess;
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((tot + 255) / 256), channels), dim3(256), 0, stream,
                        pk, chan_stride_bytes, npackets, pkt_len, per, out, out_stride, dc);

@@ -356,6 +356,7 @@ int csdr_noiseproc_batch_process(csdr_noiseproc_batch *b, const float *d_in, lon
  * (scaled onto the 16-bit range).  d_packets: [channels][npackets][pkt_len] bytes on the device;
  * d_out: [channels][out_stride] complex fp32; d_dc: optional [channels][2] doubles (I, Q offsets,
  * subtracted as CSdrInterface::ProcessIQData does for the display path, sdrinterface.cpp:889-894).
+ * d_packets 4-byte aligned, d_out 16-byte aligned, out_stride even.
  * Returns the complex samples written per channel. */
 int csdr_ingest_unpack(int device, const void *d_packets, int channels, int npackets, int pkt_len, float *d_out,
                        long long out_stride, const double *d_dc, void *stream);
