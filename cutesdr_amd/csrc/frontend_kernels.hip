@@ -74,6 +74,17 @@ void noiseblank_kernel(NbArgs a)
             last = -(1LL << 40);
             __syncthreads();
         }
+        // the three loads of a tile (new sample, the one leaving the window, the delayed one) are issued
+        // one tile ahead, so that they are in flight while the current tile goes through its scans
+        f2 nx[NB_PER], nxo[NB_PER], nxd[NB_PER];
+        auto fetch = [&](long b0) {
+#pragma unroll
+            for (int k = 0; k < NB_PER; k++) {
+                const long i = b0 + (long)t * NB_PER + k;
+                if (i < seg_b) { nx[k] = in[i]; nxo[k] = X(i - M1); nxd[k] = X(i - D1); }
+            }
+        };
+        fetch(first);
         for (long base = first; base < seg_b; base += NB_TILE) {
             f2 xd[NB_PER];
             float mag[NB_PER];
@@ -83,14 +94,15 @@ void noiseblank_kernel(NbArgs a)
                 const long i = base + (long)t * NB_PER + k;
                 mag[k] = 0.f; d[k] = 0.0; xd[k] = f2{0.f, 0.f};
                 if (i < seg_b) {
-                    const f2 x = in[i], xo = X(i - M1);
-                    xd[k] = X(i - D1);
+                    const f2 x = nx[k], xo = nxo[k];
+                    xd[k] = nxd[k];
                     mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
                     d[k] = (double)mag[k] - (double)fmaxf(fabsf(xo.x), fabsf(xo.y));
                 }
                 run += d[k];
                 d[k] = run;                                // thread-local inclusive prefix
             }
+            if (base + NB_TILE < seg_b) fetch(base + NB_TILE);
             const double incl = wave_incl_scan_add(run, lane);
             if (lane == 63) wsum[w] = incl;
             __syncthreads();
