@@ -360,3 +360,30 @@ def test_leaf_objects_ragged_call_lengths(oracle):
         assert gf.squelched() == rf.squelched(), k
         if cuts[k] >= 3000:
             assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, ("fm", k)
+
+
+def test_batch_above_1024_channels_takes_the_one_wave_kernel(oracle):
+    """More than 1024 channels in one launch: one wave per channel (postchain_kernel<1>), and grids
+    beyond the four-wave case everywhere else.  Every channel gets the same stream and tuning, three
+    of them are compared with one oracle run."""
+    import cutesdr_amd as ca
+    fs, C = 2e6, 1100
+    m, kw = MODES["FM"]
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    for c in range(C):
+        b.set_demod(c, m, info(ca, **kw))
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -100e3)
+    r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-100e3)
+    n = 19968 * 10
+    x1 = make_input("FM", 2 * n, fs).astype(np.complex64)
+    for call in range(2):
+        part = np.broadcast_to(x1[call * n:(call + 1) * n], (C, n))
+        got = b.process(part)
+        want = r.process_append(x1[call * n:(call + 1) * n].astype(np.complex128))
+        for c in (0, 517, C - 1):
+            assert len(got[c]) == len(want)
+            if call == 1:                                     # the last 2048 samples: AGC and PLL have settled
+                assert np.abs(got[c][-2048:] - want[-2048:]).max() <= 1e-3 * FULL_SCALE, c
+    assert b.smeter_ave(C - 1) == pytest.approx(r.GetSMeterAve(), abs=0.02)
