@@ -15,7 +15,12 @@
  *    reference does not have: HIP errors, bad handles);
  *  - "batch" entry points are the multi-channel extension: device-resident interleaved fp32
  *    I/Q, channel-major [channels][stride], no host copies, launched on the caller's stream;
- *  - the library never falls back to a CPU path: without a usable GPU every create() fails.
+ *  - the library never falls back to a CPU path: without a usable GPU every create() fails;
+ *  - batch process calls only enqueue work on `stream` (NULL = the default stream) and return; the
+ *    caller synchronises.  Setters, getters and the host entry points synchronise the device;
+ *  - a handle is not locked internally: one thread at a time per handle (the drop-in C++ classes
+ *    hold the per-object lock the reference's QMutex members provide); different handles are
+ *    independent.
  */
 #ifndef CUTESDR_MI_H
 #define CUTESDR_MI_H
