@@ -160,3 +160,18 @@ def test_fastfir_16384_delay_anchor(oracle):
     want = np.exp(2j * np.pi * 1000.0 * (t[:len(y)] - 4096) / fs)
     err = np.abs(y[n:] - want[n:]).max()
     assert err < 5e-4
+
+
+def test_oracle_has_not_drifted():
+    """tests/golden/oracle_regression.json holds digests of the oracle's own outputs on seeded inputs
+    (written by tests/golden/make_oracle_regression.py): the checker must not change silently."""
+    import importlib.util
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_oracle_regression", os.path.join(here, "golden", "make_oracle_regression.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "oracle_regression.json")))
+    got = mod.build()
+    assert got.keys() == want.keys()
+    for k in want:
+        for f in want[k]:
+            assert got[k][f] == pytest.approx(want[k][f], rel=1e-9, abs=1e-6), (k, f)
