@@ -703,12 +703,32 @@ void postchain_kernel(PcArgs a)
     if (mode == PC_MODE_SAM) pll_table(S.pm, C.sam.alpha, C.sam.beta, t);
     g.sync();
 
+    // with several waves per channel a tile's samples are fetched into registers one tile ahead (a
+    // channel's workgroup usually has its CU to itself: nothing else would hide the HBM latency)
+    constexpr bool kPrefetch = NW > 1;
+    float2 nxt[LC];
+    const long total = (long)a.nbursts * a.burst;
+    auto fetch = [&](long g0, int cnt) {
+#pragma unroll
+        for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < cnt) nxt[j] = in[g0 + i]; }
+    };
+    if (kPrefetch && total > 0) fetch(0, a.burst < PT ? a.burst : PT);
     for (int b = 0; b < a.nbursts; b++) {
         for (int t0 = 0; t0 < a.burst; t0 += PT) {
             const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
             const long gi = (long)b * a.burst + t0;
             float2 *x = S.dl + ((do_agc && agc.on) ? D : 0);           // tile samples (AGC: behind the delay history)
-            for (int i = t; i < n; i += NT) x[i] = in[gi + i];
+            if (kPrefetch) {
+#pragma unroll
+                for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < n) x[i] = nxt[j]; }
+                const long gn = gi + n;                                // bursts are contiguous: the next tile follows
+                if (gn < total) {
+                    const int left = a.burst - ((t0 + n) % a.burst);
+                    fetch(gn, left < PT ? left : PT);
+                }
+            } else {
+                for (int i = t; i < n; i += NT) x[i] = in[gi + i];
+            }
             g.sync();
             // ---------------- S-meter (smeter.cpp:62-93) ----------------
             if (do_sm) {
