@@ -16,6 +16,9 @@ LIB = os.path.join(HERE, "libcutesdr_mi.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"] + \
     os.environ.get("CSDR_EXTRA_HIPCC_FLAGS", "").split()
+# per-source additions: the overlap-save kernel is a long straight-line butterfly chain with two waves
+# per SIMD; LLVM's "max-ILP" machine scheduler orders it ~4 % faster than the default (measured A/B)
+FILE_FLAGS = {"fastfir_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc():
@@ -44,7 +47,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, os.path.basename(src) + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
