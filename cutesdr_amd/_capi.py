@@ -7,7 +7,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcutesdr_mi.so")
+# CSDR_LIB_PATH: a diagnostic build of the same library (tools/k1_stamps.py), never a different implementation
+LIB_PATH = os.environ.get("CSDR_LIB_PATH") or os.path.join(HERE, "libcutesdr_mi.so")
 HEADER = os.path.join(HERE, "..", "include", "cutesdr_mi.h")
 
 CSDR_OK, CSDR_EINVAL, CSDR_EHIP, CSDR_ENOMEM, CSDR_ESTATE = 0, -1, -2, -3, -4

@@ -23,7 +23,7 @@ struct csdr_fastfir_batch {
     float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
     int hist_cur;                     // which half holds the previous call's tail
     int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
-    int variant;                      // 0: 8-wave kernel, 1: 16-wave pair kernel (N = 16384 only)
+    int variant;                      // 0: generic kernel (every size); 2 + opt: pipelined build (N = 16384, fastfir2_kernels.hip)
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
@@ -34,13 +34,6 @@ static void build_perm(csdr_fastfir_batch *b)
 {
     const int T = b->n / 32;
     b->perm.resize(b->n);
-    if (b->variant == 1) {
-        // 1024 threads x 16 registers: float4 index j*1024 + t holds registers 2j, 2j+1 of thread t
-        for (int j = 0; j < 8; j++)
-            for (int t = 0; t < 1024; t++)
-                for (int e = 0; e < 2; e++) b->perm[(j * 1024 + t) * 2 + e] = fastfir16k_bin_of(t, 2 * j + e);
-        return;
-    }
     // slot layout: float4 index j*T + t holds registers r = 2j, 2j+1 of thread t
     for (int j = 0; j < 16; j++)
         for (int t = 0; t < T; t++)
@@ -75,14 +68,17 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
     b->device = device; b->channels = channels; b->n = fft_size; b->log2n = l2;
     b->per_channel = false; b->hist_cur = 0; b->dbg_stage = 0; b->dbg_out = nullptr;
     {
+        // N = 16384 runs the software-pipelined build (priority ladder + spread H loads); CSDR_FASTFIR_VARIANT=0
+        // forces the generic kernel (diagnostics; launches it cannot take fall back to the generic one anyway)
         const char *v = getenv("CSDR_FASTFIR_VARIANT");
-        b->variant = (fft_size == 16384 && v) ? atoi(v) : 0;
+        b->variant = fft_size == 16384 ? (v ? atoi(v) : 5) : 0;
+        if (b->variant == 1 || b->variant < 0 || b->variant > 5) b->variant = 0;
     }
     b->d_h = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
     build_perm(b);
     const size_t hbytes = (size_t)fft_size * 8, histbytes = 2 * (size_t)channels * (fft_size / 2) * 8;
-    std::vector<float> tw1(2 * 1024), tw2(2 * (1024 + 48));
+    std::vector<float> tw1(2 * 1024), tw2(2 * 1024);
     for (int i = 0; i < 1024; i++) {
         const double a = kTwoPi * (double)i / (double)fft_size;
         tw1[2 * i] = (float)std::cos(a); tw1[2 * i + 1] = (float)std::sin(a);
@@ -92,15 +88,14 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
             const double a = kTwoPi * (double)(i * k) / 1024.0;
             tw2[2 * (k * 32 + i)] = (float)std::cos(a); tw2[2 * (k * 32 + i) + 1] = (float)std::sin(a);
         }
-    fastfir16k_pair_twiddles(tw2.data() + 2048);
     bool ok = hipMalloc((void **)&b->d_h, hbytes) == hipSuccess &&
               hipMalloc((void **)&b->d_hist, histbytes) == hipSuccess &&
               hipMalloc((void **)&b->d_tw1, 8192) == hipSuccess &&
-              hipMalloc((void **)&b->d_tw2, 8192 + 384) == hipSuccess &&
+              hipMalloc((void **)&b->d_tw2, 8192) == hipSuccess &&
               hipMemset(b->d_h, 0, hbytes) == hipSuccess &&
               hipMemset(b->d_hist, 0, histbytes) == hipSuccess &&
               hipMemcpy(b->d_tw1, tw1.data(), 8192, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(b->d_tw2, tw2.data(), 8192 + 384, hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(b->d_tw2, tw2.data(), 8192, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
         fail(CSDR_ENOMEM, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         csdr_fastfir_batch_destroy(b);
@@ -221,9 +216,23 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.blocks_per_run = blocks_per_wg;
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
     a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
-    if (b->variant == 1) CSDR_HIP(fastfir16k_launch(a, s));
+    if (b->variant >= 2 && (a.blocks_per_run & 1) == 0 && (a.nblocks % a.blocks_per_run & 1) == 0)
+        CSDR_HIP(fastfir2_launch(a, s, b->variant - 2));     // walks its blocks in pairs
     else CSDR_HIP(fastfir_launch(b->log2n, a, s));
     b->hist_cur ^= 1;        // the kernel left this call's tail in the other half
+    return CSDR_OK;
+}
+
+/* test-only hook, not part of the public ABI: choose the kernel build of this object (A/B timing in one process) */
+int csdr__fastfir_set_variant(csdr_fastfir_batch *b, int variant)
+{
+    if (!b || variant < 0 || variant == 1 || variant > 5 || (variant && b->n != 16384)) return CSDR_EINVAL;
+    b->variant = variant;
+    build_perm(b);
+    for (size_t i = 0; i < b->resp.size(); i++) {
+        int rc = upload_response(b, (int)i, b->resp[i]);
+        if (rc) return rc;
+    }
     return CSDR_OK;
 }
 

@@ -1,0 +1,446 @@
+// fastfir2_kernels.hip -- batched overlap-save FFT FIR for gfx950, software-pipelined build (K1).
+//
+// Same algorithm, LDS image, spectrum order and HBM traffic as fastfir_os_kernel
+// (fastfir_kernels.hip; reference dsp/fastfir.cpp:268-321, dsp/fft.cpp:416-426): passes
+// F1 (radix-R0 from HBM) | F2 (radix-32) | F3 + H + I1 (registers) | I2 (radix-32) | I3 (radix-R0,
+// store the valid half).  What differs is the ORDER of the instruction stream.  The first build
+// left the compiler a free hand and got, per pass, "all LDS reads | all butterflies | all LDS
+// writes": with two waves per SIMD running in lockstep between the workgroup barriers, the LDS
+// pipe and the VALU took turns (13.8k VALU + 9.2k LDS cycles per block against 24.8k measured).
+// Here every pass is cut into groups of four points (fft_core.hpp: head / tail4 / head4 / tail):
+//   * the points of a group are fetched in the order the first two stages need them, so the
+//     butterflies start after four reads instead of thirty-two;
+//   * a group's results are written while the next group's butterflies issue (one group behind);
+//   * the 8-byte LDS accesses are relaxed atomics: hipcc neither merges them into ds_read2_b64 /
+//     ds_write2_b64 (half the LDS rate of ds_read_b64) nor reorders them, and still counts them
+//     in its s_waitcnt bookkeeping;
+//   * sched_barrier(0) between groups pins that order against the machine scheduler.
+// The outer-pass twiddle powers are computed once per block (pass I3) and reused by pass F1 of the
+// next block.
+#include "fastfir_dev.hpp"
+#include "fastfir_kernels.h"
+
+namespace csdr {
+
+#define CSDR_SB() __builtin_amdgcn_sched_barrier(0)
+
+// Diagnostic build only (-DCSDR_K1_STAMPS, tools/k1_stamps.py): cycle shares of the passes of one block,
+// summed per wave in scalar registers and written to a.dbg after the loop.  No stamp executes otherwise.
+#ifdef CSDR_K1_STAMPS
+#define CSDR_STAMP(i)                                                                         \
+    do {                                                                                      \
+        CSDR_SB();                                                                            \
+        unsigned long long now_;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");         \
+        CSDR_SB();                                                                            \
+        acc_[i] += now_ - last_;                                                              \
+        last_ = now_;                                                                         \
+    } while (0)
+#else
+#define CSDR_STAMP(i) do { } while (0)
+#endif
+
+// 8-byte LDS access that stays a single ds_read_b64 / ds_write_b64 in program order
+__device__ __forceinline__ v2f lds_ld8(const v2f *p)
+{
+    return __builtin_bit_cast(v2f, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WAVEFRONT));
+}
+__device__ __forceinline__ void lds_st8(v2f *p, v2f v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// OPT: experiment switches (bit 0: priority ladder between the workgroup barriers)
+#define CSDR_PRIO(p) do { if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(p); } while (0)
+
+template <int LOG2N, int OPT>
+__global__ __launch_bounds__(FastFirCfg<LOG2N>::T)
+void fastfir_os2_kernel(FastFirArgs a)
+{
+    using Cfg = FastFirCfg<LOG2N>;
+    constexpr int N = Cfg::N, T = Cfg::T, R0 = Cfg::R0, G = Cfg::G, L = N / 2;
+    constexpr int HALF = R0 / 2;
+    static_assert(R0 == 16 && G == 2, "the grouped outer pass is written for N = 16384");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+    v2f *tw2 = lds + Cfg::LDS_DATA;           // tw2[k1*32 + n2] = W_1024^{n2*k1}
+
+    const int t = threadIdx.x;
+    int wg = blockIdx.x, ch, run;
+    if ((a.channels & 7) == 0) {
+        int xcd = wg & 7, slot = wg >> 3;
+        ch = (slot / a.runs) * 8 + xcd;
+        run = slot % a.runs;
+    } else {
+        ch = wg / a.runs;
+        run = wg % a.runs;
+    }
+    const int b0 = run * a.blocks_per_run;
+    int b1 = b0 + a.blocks_per_run;
+    if (b1 > a.nblocks) b1 = a.nblocks;
+    if (ch >= a.channels || b0 >= b1) return;          // uniform per workgroup
+
+    for (int i = t; i < 1024; i += T) tw2[i] = a.tw2[i];
+
+    const rsrc_t r_in = make_rsrc(a.in + (long)ch * a.in_stride, (unsigned)a.nblocks * L * 8u);
+    const rsrc_t r_hist = make_rsrc(a.hist + (long)ch * L, L * 8u);
+    const rsrc_t r_out = make_rsrc(a.out + (long)ch * a.out_stride, (unsigned)a.nblocks * L * 8u);
+    const rsrc_t r_h = make_rsrc(a.h + (long)ch * a.h_stride, N * 8u);
+    const int voff = t * (G * 8);
+    auto load_half = [&](rsrc_t r, int soff, v2f (&dst)[16]) {
+#pragma unroll
+        for (int n1 = 0; n1 < HALF; n1++) {
+            v4f v = buf_load16(r, voff, soff + n1 * 8192);
+            dst[n1] = v2f{v.x, v.y};
+            dst[HALF + n1] = v2f{v.z, v.w};
+        }
+    };
+
+    // outer-pass twiddles W_N^{n2 k0}, n2 = 2t+e, k0 = 1..15: pw[e][k0].  Rebuilt at the top of every
+    // I3 and kept for F1 of the next block only: live across the whole loop they would not fit beside H
+    v2f w1[G];
+#pragma unroll
+    for (int e = 0; e < G; e++) w1[e] = a.tw1[G * t + e];
+    v2f pw[G][R0];
+#pragma unroll
+    for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);
+
+    v2f x[32];           // phase B: the 32 points of this thread
+    // The two halves of a block's input, [n1] = column 2t row n1, [8 + n1] = column 2t+1 row n1.  The new
+    // half of one block is the old half of the next: the block loop is unrolled by two and the buffers
+    // swap roles, so nothing is copied; the samples after next are fetched into the old half's registers
+    // as soon as the first butterfly stage has read them.
+    v2f hp[16], hq[16];
+
+    if (b0 == 0) load_half(r_hist, 0, hp);
+    else load_half(r_in, (b0 - 1) * (L * 8), hp);
+    load_half(r_in, b0 * (L * 8), hq);
+
+    const int sb = t >> 5, sn = t & 31;       // sub-transform and column of passes F2 / I2
+    v2f *const col = lds + lds_pad(1024 * sb) + sn;         // F2 / I2: point n1 at col[34 * n1]
+    const v2f *const twc = tw2 + sn;                        // twiddle k1 at twc[32 * k1]
+    v2f *const rowp = lds + 34 * t;                         // F3: this thread's 32 consecutive points
+    v2f *const outer = lds + lds_pad(G * t);                // F1 / I3: row k0 at outer[lds_pad(1024) * k0]
+    constexpr int OUTER_ROW = 1024 + 2 * (1024 / 32);       // padded elements between rows of the outer pass
+
+#ifdef CSDR_K1_STAMPS
+    unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
+    // one block: [oldh | newh] in, the valid half out; block b+1's new half is left in oldh
+    auto one_block = [&](const int b, v2f (&oldh)[16], v2f (&newh)[16]) {
+        // ================= F1: radix-16 DIF on [oldh | newh], twiddle, scatter to LDS =================
+        CSDR_SB();
+        CSDR_PRIO(1);
+        {
+            v2f y0[R0], y1[R0];
+#pragma unroll
+            for (int n1 = 0; n1 < HALF; n1++) {
+                y0[n1] = oldh[n1];        y0[HALF + n1] = newh[n1];
+                y1[n1] = oldh[HALF + n1]; y1[HALF + n1] = newh[HALF + n1];
+            }
+            static_for<0, R0 / 4>([&](auto I) { dif_head<I.value, R0, +1>(y0); dif_head<I.value, R0, +1>(y1); });
+            CSDR_SB();
+            // block b+1's new half: into the registers of the old half, which the butterflies above have read
+            // (unconditional, so that the block stays one straight line of code: after the last block of the
+            // call the last block is fetched again, after the last of a run the samples are simply not used)
+            load_half(r_in, (b + 1 < a.nblocks ? b + 1 : a.nblocks - 1) * (L * 8), oldh);
+            CSDR_SB();
+            CSDR_PRIO(0);
+            v4f wv[R0];
+            static_for<0, R0 / 4 + 1>([&](auto Gg) {
+                constexpr int g = Gg.value;
+                if constexpr (g < R0 / 4) {
+                    dif_tail4<g, R0, +1>(y0);
+                    dif_tail4<g, R0, +1>(y1);
+                    static_for<4 * g, 4 * g + 4>([&](auto Rr) {
+                        constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+                        if constexpr (k0 != 0) {
+                            y0[r] = cmul(y0[r], pw[0][k0]);
+                            y1[r] = cmul(y1[r], pw[1][k0]);
+                        }
+                        wv[r] = store_operand(y0[r], y1[r]);
+                    });
+                }
+                if constexpr (g > 0) {                 // rows of the previous group: written while this one computes
+                    CSDR_STORE_GROUP_BEGIN();
+                    static_for<4 * (g - 1), 4 * g>([&](auto Rr) {
+                        constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+                        *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0) = wv[r];
+                    });
+                    CSDR_STORE_GROUP_END();
+                } else {
+                    CSDR_SB();
+                }
+            });
+        }
+        CSDR_STAMP(0);                                 // F1 (and the loop-carried moves)
+        __syncthreads();
+        CSDR_STAMP(1);                                 // barrier after F1
+
+        // ================= F2: radix-32 DIF inside sub-transform sb, column sn =================
+        CSDR_PRIO(3);
+        v4f hv[16];
+        {
+            // the four points of head group i; three groups ahead of the butterflies (lgkmcnt counts to 15)
+            auto fetch = [&](auto I) {
+                constexpr int i = I.value;
+                x[i] = lds_ld8(col + 34 * i);
+                x[i + 8] = lds_ld8(col + 34 * (i + 8));
+                x[i + 16] = lds_ld8(col + 34 * (i + 16));
+                x[i + 24] = lds_ld8(col + 34 * (i + 24));
+            };
+            static_for<0, 3>(fetch);
+            CSDR_SB();
+            static_for<0, 8>([&](auto I) {
+                if constexpr (I.value + 3 < 8) fetch(std::integral_constant<int, I.value + 3>{});
+                dif_head<I.value, 32, +1>(x);
+                CSDR_SB();
+            });
+            CSDR_STAMP(7);                             // F2 heads
+            dif_single<8, 32, +1>(x);
+            CSDR_SB();
+            // H[k] comes from L2: in flight from here to the multiply in F3 (OPT bit 1: two loads per tail
+            // group instead of a burst of sixteen, whose issue alone held the wave for ~500 cycles)
+            if constexpr (!(OPT & 2)) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) hv[j] = buf_load16(r_h, t * 16, j * (T * 16));
+            }
+            v2f tw[2][4];
+            static_for<1, 4>([&](auto Rr) { tw[0][Rr.value] = lds_ld8(twc + 32 * bitrev<32>(Rr.value)); });
+            CSDR_SB();
+            CSDR_STAMP(8);                             // F2 middle stage, H loads issued
+            static_for<0, 9>([&](auto Gg) {
+                constexpr int g = Gg.value;
+                if constexpr (g < 7)                   // twiddles of the next group
+                    static_for<0, 4>([&](auto Q) {
+                        tw[(g + 1) & 1][Q.value] = lds_ld8(twc + 32 * bitrev<32>(4 * (g + 1) + Q.value));
+                    });
+                if constexpr ((OPT & 2) != 0 && g < 8) {
+                    hv[2 * g] = buf_load16(r_h, t * 16, (2 * g) * (T * 16));
+                    hv[2 * g + 1] = buf_load16(r_h, t * 16, (2 * g + 1) * (T * 16));
+                }
+                if constexpr (g < 8) {
+                    dif_tail4<g, 32, +1>(x);
+                    static_for<0, 4>([&](auto Q) {
+                        constexpr int r = 4 * g + Q.value;
+                        if constexpr (r != 0) x[r] = cmul(x[r], tw[g & 1][Q.value]);
+                    });
+                }
+                if constexpr (g > 0)
+                    static_for<4 * (g - 1), 4 * g>([&](auto Rr) {
+                        constexpr int r = Rr.value;
+                        lds_st8(col + 34 * bitrev<32>(r), x[r]);
+                    });
+                CSDR_SB();
+            });
+        }
+        CSDR_STAMP(2);                                 // F2
+        // F2 -> F3 stays inside the half-wave that owns sub-transform sb
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ================= F3 + H + I1: points 32t..32t+31, registers only =================
+        CSDR_PRIO(2);
+        {
+            // rows q, q+4, q+8, q+12 of 16-byte pairs feed head groups 2q and 2q+1
+            static_for<0, 4>([&](auto Q) {
+                static_for<0, 4>([&](auto P) {
+                    constexpr int j = Q.value + 4 * P.value;
+                    const v4f v = *reinterpret_cast<const v4f *>(rowp + 2 * j);
+                    x[2 * j] = v2f{v.x, v.y};
+                    x[2 * j + 1] = v2f{v.z, v.w};
+                });
+            });
+            CSDR_SB();
+            static_for<0, 8>([&](auto I) {
+                dif_head<I.value, 32, +1>(x);
+                if constexpr ((I.value & 1) == 1) CSDR_SB();
+            });
+            dif_single<8, 32, +1>(x);
+            CSDR_SB();
+            static_for<0, 8>([&](auto Gg) {
+                constexpr int g = Gg.value;
+                dif_tail4<g, 32, +1>(x);
+                x[4 * g] = cmul(x[4 * g], v2f{hv[2 * g].x, hv[2 * g].y});
+                x[4 * g + 1] = cmul(x[4 * g + 1], v2f{hv[2 * g].z, hv[2 * g].w});
+                x[4 * g + 2] = cmul(x[4 * g + 2], v2f{hv[2 * g + 1].x, hv[2 * g + 1].y});
+                x[4 * g + 3] = cmul(x[4 * g + 3], v2f{hv[2 * g + 1].z, hv[2 * g + 1].w});
+                dit_head4<g, 32, -1>(x);
+                if constexpr ((g & 1) == 1) CSDR_SB();
+            });
+            CSDR_PRIO(1);
+            dit_single<8, 32, -1>(x);
+            CSDR_SB();
+            v4f wv[16];
+            static_for<0, 5>([&](auto Q) {
+                constexpr int q = Q.value;
+                if constexpr (q < 4) {
+                    dit_tail<2 * q, 32, -1>(x);
+                    dit_tail<2 * q + 1, 32, -1>(x);
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int j = q + 4 * P.value;
+                        wv[j] = store_operand(x[2 * j], x[2 * j + 1]);
+                    });
+                }
+                if constexpr (q > 0) {
+                    CSDR_STORE_GROUP_BEGIN();
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int j = (q - 1) + 4 * P.value;
+                        *reinterpret_cast<v4f *>(rowp + 2 * j) = wv[j];
+                    });
+                    CSDR_STORE_GROUP_END();
+                } else {
+                    CSDR_SB();
+                }
+            });
+        }
+        CSDR_STAMP(3);                                 // F3 + H + I1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ================= I2: conj twiddle, radix-32 DIT inverse =================
+        CSDR_PRIO(0);
+        {
+            v2f tw[32];
+            // points and twiddles of head group g, two groups ahead of the butterflies
+            auto fetch = [&](auto Gg) {
+                static_for<0, 4>([&](auto Q) {
+                    constexpr int r = 4 * Gg.value + Q.value;
+                    x[r] = lds_ld8(col + 34 * bitrev<32>(r));
+                });
+                static_for<0, 4>([&](auto Q) {
+                    constexpr int r = 4 * Gg.value + Q.value;
+                    if constexpr (r != 0) tw[r] = lds_ld8(twc + 32 * bitrev<32>(r));
+                });
+            };
+            static_for<0, 2>(fetch);
+            CSDR_SB();
+            static_for<0, 8>([&](auto Gg) {
+                constexpr int g = Gg.value;
+                if constexpr (g + 2 < 8) fetch(std::integral_constant<int, g + 2>{});
+                static_for<0, 4>([&](auto Q) {
+                    constexpr int r = 4 * g + Q.value;
+                    if constexpr (r != 0) x[r] = cmul_conj(x[r], tw[r]);
+                });
+                dit_head4<g, 32, -1>(x);
+                CSDR_SB();
+            });
+            dit_single<8, 32, -1>(x);
+            CSDR_SB();
+            static_for<0, 9>([&](auto I) {
+                constexpr int i = I.value;
+                if constexpr (i < 8) dit_tail<i, 32, -1>(x);
+                if constexpr (i > 0)
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int n1 = (i - 1) + 8 * P.value;
+                        lds_st8(col + 34 * n1, x[n1]);
+                    });
+                CSDR_SB();
+            });
+        }
+        CSDR_STAMP(4);                                 // I2
+        __syncthreads();
+        CSDR_STAMP(5);                                 // barrier after I2
+
+        // ================= I3: conj twiddle, radix-16 DIT inverse, store the valid half =================
+        CSDR_PRIO(3);
+        {
+            v2f y0[R0], y1[R0];
+            static_for<0, R0>([&](auto Rr) {
+                constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+                const v4f v = *reinterpret_cast<const v4f *>(outer + OUTER_ROW * k0);
+                y0[r] = v2f{v.x, v.y};
+                y1[r] = v2f{v.z, v.w};
+            });
+#pragma unroll
+            for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);     // while the reads are in flight
+            CSDR_SB();
+            static_for<0, R0 / 4>([&](auto Gg) {
+                constexpr int g = Gg.value;
+                static_for<4 * g, 4 * g + 4>([&](auto Rr) {
+                    constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+                    if constexpr (k0 != 0) {
+                        y0[r] = cmul_conj(y0[r], pw[0][k0]);
+                        y1[r] = cmul_conj(y1[r], pw[1][k0]);
+                    }
+                });
+                dit_head4<g, R0, -1>(y0);
+                dit_head4<g, R0, -1>(y1);
+                if constexpr ((g & 1) == 1) CSDR_SB();
+            });
+            // sample 1024*n1 + 2t + e, n1 >= 8  ->  output offset 1024*(n1-8) + 2t + e
+            CSDR_PRIO(2);
+            v4f sv[8];
+            static_for<0, R0 / 4 + 1>([&](auto I) {
+                constexpr int i = I.value;
+                if constexpr (i < R0 / 4) {
+                    dit_tail<i, R0, -1>(y0);
+                    dit_tail<i, R0, -1>(y1);
+                    sv[2 * i] = store_operand(y0[i + 8], y1[i + 8]);
+                    sv[2 * i + 1] = store_operand(y0[i + 12], y1[i + 12]);
+                }
+                if constexpr (i > 0) {
+                    CSDR_STORE_GROUP_BEGIN();
+                    buf_store16(r_out, voff, b * (L * 8) + (i - 1) * 8192, sv[2 * (i - 1)]);
+                    buf_store16(r_out, voff, b * (L * 8) + (i - 1 + 4) * 8192, sv[2 * (i - 1) + 1]);
+                    CSDR_STORE_GROUP_END();
+                } else {
+                    CSDR_SB();
+                }
+            });
+        }
+        CSDR_STAMP(6);                                 // I3
+    };
+    // the host launches this kernel only with an even number of blocks in every run
+    for (int b = b0; b < b1; b += 2) {
+        one_block(b, hp, hq);
+        one_block(b + 1, hq, hp);
+    }
+
+#ifdef CSDR_K1_STAMPS
+    if (a.dbg && (t & 63) == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg) + ((long)blockIdx.x * (T / 64) + (t >> 6)) * 16;
+        for (int i = 0; i < 16; i++) o[i] = acc_[i];
+    }
+#endif
+    // the tail of this call's input is the overlap of the next call (fastfir.cpp:280-300);
+    // written to the other half of the ping-pong history so no workgroup can still be reading it
+    if (b1 == a.nblocks) {
+        const rsrc_t r_hn = make_rsrc(a.hist_next + (long)ch * L, L * 8u);
+        v4f sv[8];
+#pragma unroll
+        for (int n1 = 0; n1 < HALF; n1++) sv[n1] = store_operand(hp[n1], hp[HALF + n1]);
+        CSDR_STORE_GROUP_BEGIN();
+#pragma unroll
+        for (int n1 = 0; n1 < HALF; n1++) buf_store16(r_hn, voff, n1 * 8192, sv[n1]);
+        CSDR_STORE_GROUP_END();
+    }
+}
+
+template <int OPT>
+static hipError_t launch2(const FastFirArgs &a, hipStream_t stream)
+{
+    using Cfg = FastFirCfg<14>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<14, OPT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fastfir_os2_kernel<14, OPT>), dim3(a.channels * a.runs), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream, int opt)
+{
+    switch (opt) {
+    case 0: return launch2<0>(a, stream);
+    case 1: return launch2<1>(a, stream);
+    case 3: return launch2<3>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace csdr

@@ -29,9 +29,7 @@ struct FastFirArgs {
 hipError_t fastfir_launch(int log2n, const FastFirArgs &a, hipStream_t stream);
 int fastfir_bin_of(int log2n, int t, int r);
 
-// 16-wave variant for N = 16384 (fastfir16k_kernels.hip)
-hipError_t fastfir16k_launch(const FastFirArgs &a, hipStream_t stream);
-int fastfir16k_bin_of(int t, int r);
-void fastfir16k_pair_twiddles(float *out96);
+// software-pipelined build for N = 16384 (fastfir2_kernels.hip): same LDS image and H order as fastfir_launch
+hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream, int opt);
 
 }  // namespace csdr

@@ -208,6 +208,73 @@ __host__ __device__ __forceinline__ void dft_dit(v2f (&x)[R])
     if constexpr (R > 1) dit_stage<2, R, SIGN>(x);
 }
 
+// ---- the same transforms cut into groups, for passes that overlap their LDS traffic with the
+//      butterflies (fastfir_kernels.hip): a radix-R DIF is  head<I> (I = 0..R/4-1: its first two
+//      stages on the elements {I, I+R/4, I+R/2, I+3R/4}, needs only those four loaded), the
+//      middle stages 8 (R = 32 only), then tail4<G> (G = 0..R/4-1: stages 4 and 2 on elements
+//      4G..4G+3, which are final afterwards).  The DIT mirrors it: head4<G>, middle, tail<I>
+//      (last two stages on {I, I+R/4, I+R/2, I+3R/4}, final afterwards).
+template <int LEN, int R, int SIGN>
+__host__ __device__ __forceinline__ void dif_single(v2f (&x)[R])
+{
+    constexpr int H = LEN / 2;
+    static_for<0, R / LEN>([&](auto B) {
+        static_for<0, H>([&](auto I) {
+            constexpr int a = B.value * LEN + I.value, b = a + H;
+            bfly_dif<I.value *(32 / LEN), SIGN>(x[a], x[b]);
+        });
+    });
+}
+template <int LEN, int R, int SIGN>
+__host__ __device__ __forceinline__ void dit_single(v2f (&x)[R])
+{
+    constexpr int H = LEN / 2;
+    static_for<0, R / LEN>([&](auto B) {
+        static_for<0, H>([&](auto I) {
+            constexpr int a = B.value * LEN + I.value, b = a + H;
+            bfly_dit<I.value *(32 / LEN), SIGN>(x[a], x[b]);
+        });
+    });
+}
+template <int I, int R, int SIGN>
+__host__ __device__ __forceinline__ void dif_head(v2f (&x)[R])
+{
+    static_assert(R >= 8 && I < R / 4, "dif_head");
+    constexpr int Q = R / 4;
+    bfly_dif<I *(32 / R), SIGN>(x[I], x[I + 2 * Q]);                 // stage R
+    bfly_dif<(I + Q) * (32 / R), SIGN>(x[I + Q], x[I + 3 * Q]);
+    bfly_dif<I *(64 / R), SIGN>(x[I], x[I + Q]);                     // stage R/2
+    bfly_dif<I *(64 / R), SIGN>(x[I + 2 * Q], x[I + 3 * Q]);
+}
+template <int G, int R, int SIGN>
+__host__ __device__ __forceinline__ void dif_tail4(v2f (&x)[R])
+{
+    constexpr int a = 4 * G;
+    bfly_dif<0, SIGN>(x[a], x[a + 2]);                               // stage 4
+    bfly_dif<8, SIGN>(x[a + 1], x[a + 3]);
+    bfly_dif<0, SIGN>(x[a], x[a + 1]);                               // stage 2
+    bfly_dif<0, SIGN>(x[a + 2], x[a + 3]);
+}
+template <int G, int R, int SIGN>
+__host__ __device__ __forceinline__ void dit_head4(v2f (&x)[R])
+{
+    constexpr int a = 4 * G;
+    bfly_dit<0, SIGN>(x[a], x[a + 1]);                               // stage 2
+    bfly_dit<0, SIGN>(x[a + 2], x[a + 3]);
+    bfly_dit<0, SIGN>(x[a], x[a + 2]);                               // stage 4
+    bfly_dit<8, SIGN>(x[a + 1], x[a + 3]);
+}
+template <int I, int R, int SIGN>
+__host__ __device__ __forceinline__ void dit_tail(v2f (&x)[R])
+{
+    static_assert(R >= 8 && I < R / 4, "dit_tail");
+    constexpr int Q = R / 4;
+    bfly_dit<I *(64 / R), SIGN>(x[I], x[I + Q]);                     // stage R/2
+    bfly_dit<I *(64 / R), SIGN>(x[I + 2 * Q], x[I + 3 * Q]);
+    bfly_dit<I *(32 / R), SIGN>(x[I], x[I + 2 * Q]);                 // stage R
+    bfly_dit<(I + Q) * (32 / R), SIGN>(x[I + Q], x[I + 3 * Q]);
+}
+
 // w^k for k = 0..R-1 by a log-depth product tree (pw[0] unused = 1)
 template <int R>
 __host__ __device__ __forceinline__ void twiddle_powers(v2f w, v2f (&pw)[R])
