@@ -18,12 +18,14 @@ static int log2_of(int n)
 
 struct csdr_fastfir_batch {
     int device, channels, n, log2n;
+    int cus;                          // compute units of the device (run-length heuristic)
+    hipStream_t last_stream;          // stream of the most recent process call (setup waits for it)
     bool per_channel;                 // false: one shared filter
     float *d_h;                       // [filters][n] complex fp32 in pass-F3 register order
     float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
     int hist_cur;                     // which half holds the previous call's tail
     int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
-    int variant;                      // 0: generic kernel (every size); 2 + opt: pipelined build (N = 16384, fastfir2_kernels.hip)
+    int variant;                      // 0: generic kernel (every size); 2: pipelined build (N = 16384, fastfir2_kernels.hip)
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
@@ -67,12 +69,17 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
     csdr_fastfir_batch *b = new csdr_fastfir_batch();
     b->device = device; b->channels = channels; b->n = fft_size; b->log2n = l2;
     b->per_channel = false; b->hist_cur = 0; b->dbg_stage = 0; b->dbg_out = nullptr;
+    b->last_stream = nullptr;
     {
-        // N = 16384 runs the software-pipelined build (priority ladder + spread H loads); CSDR_FASTFIR_VARIANT=0
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        b->cus = cus;
+    }
+    {
+        // N = 16384 runs the software-pipelined build; CSDR_FASTFIR_VARIANT=0
         // forces the generic kernel (diagnostics; launches it cannot take fall back to the generic one anyway)
         const char *v = getenv("CSDR_FASTFIR_VARIANT");
-        b->variant = fft_size == 16384 ? (v ? atoi(v) : 5) : 0;
-        if (b->variant == 1 || b->variant < 0 || b->variant > 5) b->variant = 0;
+        b->variant = (fft_size == 16384 && !(v && atoi(v) == 0)) ? 2 : 0;
     }
     b->d_h = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
@@ -129,6 +136,9 @@ int csdr_fastfir_batch_setup(csdr_fastfir_batch *b, int channel, double flo, dou
     std::vector<cd> H;
     if (!fastfir_design(b->n, flo, fhi, offset, fs, H))
         return fail(CSDR_EINVAL, "filter parameter error (reference keeps the previous taps)");
+    // H is single-buffered: a kernel of an earlier process call (possibly on a non-blocking stream that the
+    // null-stream copy below does not order against) may still be reading it
+    CSDR_HIP(hipDeviceSynchronize());
     if (channel >= 0 && !b->per_channel) {
         // switch to one filter per channel, seeded with the shared one
         float *nh = nullptr;
@@ -184,8 +194,12 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
         return fail(CSDR_EINVAL, "channel stride shorter than n_per_channel");
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15 || (in_stride & 1) || (out_stride & 1))
         return fail(CSDR_EINVAL, "buffers must be 16-byte aligned and strides even");
+    // the kernels address a channel row through a 32-bit buffer descriptor range and byte offsets
+    if ((long long)n_per_channel * 8 >= (1ll << 31))
+        return fail(CSDR_EINVAL, "n_per_channel (%d) too large for one call: at most %d samples", n_per_channel, (1 << 28) - L);
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t s = (hipStream_t)stream;
+    b->last_stream = s;
     FastFirArgs a;
     const size_t hist_half = (size_t)b->channels * L * 2;      // floats
     a.in = (const v2f_h *)d_in; a.out = (v2f_h *)d_out;
@@ -198,11 +212,11 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.nblocks = n_per_channel / L;
     if (blocks_per_wg <= 0) {
         // One workgroup walks a run of consecutive blocks of one channel.  Runs per channel: the count
-        // whose workgroups fill whole rounds of the resident slots best (256 CUs x workgroups per CU
+        // whose workgroups fill whole rounds of the resident slots best (CUs of the device x workgroups per CU
         // at this size: the LDS block is N*8.5 bytes), fewest runs on a tie -- longer runs re-read
         // less overlap.  C3 (256 channels, N=16384): one run of 64 blocks per channel.
         const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : 8));
-        const long slots = 256 * per_cu;
+        const long slots = (long)b->cus * per_cu;
         long best_runs = 1; double best_eff = -1.0;
         const long max_runs = std::min<long>(a.nblocks, std::max<long>(1, 4 * ((slots + b->channels - 1) / b->channels)));
         for (long runs = 1; runs <= max_runs; runs++) {
@@ -217,7 +231,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
     a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
     if (b->variant >= 2 && (a.blocks_per_run & 1) == 0 && (a.nblocks % a.blocks_per_run & 1) == 0)
-        CSDR_HIP(fastfir2_launch(a, s, b->variant - 2));     // walks its blocks in pairs
+        CSDR_HIP(fastfir2_launch(a, s));     // walks its blocks in pairs
     else CSDR_HIP(fastfir_launch(b->log2n, a, s));
     b->hist_cur ^= 1;        // the kernel left this call's tail in the other half
     return CSDR_OK;
@@ -226,7 +240,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
 /* test-only hook, not part of the public ABI: choose the kernel build of this object (A/B timing in one process) */
 int csdr__fastfir_set_variant(csdr_fastfir_batch *b, int variant)
 {
-    if (!b || variant < 0 || variant == 1 || variant > 5 || (variant && b->n != 16384)) return CSDR_EINVAL;
+    if (!b || (variant != 0 && variant != 2) || (variant && b->n != 16384)) return CSDR_EINVAL;
     b->variant = variant;
     build_perm(b);
     for (size_t i = 0; i < b->resp.size(); i++) {

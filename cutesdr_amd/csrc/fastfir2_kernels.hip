@@ -17,6 +17,7 @@
 //   * sched_barrier(0) between groups pins that order against the machine scheduler.
 // The outer-pass twiddle powers are computed once per block (pass I3) and reused by pass F1 of the
 // next block.
+#define CSDR_FMA_BFLY 1          // FMA-form decimation-in-time butterflies (fft_core.hpp)
 #include "fastfir_dev.hpp"
 #include "fastfir_kernels.h"
 
@@ -52,10 +53,15 @@ __device__ __forceinline__ void lds_st8(v2f *p, v2f v)
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-// OPT: experiment switches (bit 0: priority ladder between the workgroup barriers)
-#define CSDR_PRIO(p) do { if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(p); } while (0)
+// Priority ladder.  The two waves of a SIMD (w and w+4) run the same code between two workgroup barriers, and
+// the SIMD issues by priority, then age: left alone, the older wave takes every slot it can use, reaches the
+// barrier thousands of cycles early and waits while the younger one runs alone at a single wave's issue
+// rate (in-kernel stamps: 8.3k of 21.7k cycles per block spent waiting).  Lowering the priority step by step
+// through the interval (3, 2, 1, 0) makes whichever wave is behind the preferred one: the pair stays within
+// one segment of each other and the waits fall to 2k cycles.
+#define CSDR_PRIO(p) __builtin_amdgcn_s_setprio(p)
 
-template <int LOG2N, int OPT>
+template <int LOG2N>
 __global__ __launch_bounds__(FastFirCfg<LOG2N>::T)
 void fastfir_os2_kernel(FastFirArgs a)
 {
@@ -202,12 +208,8 @@ void fastfir_os2_kernel(FastFirArgs a)
             CSDR_STAMP(7);                             // F2 heads
             dif_single<8, 32, +1>(x);
             CSDR_SB();
-            // H[k] comes from L2: in flight from here to the multiply in F3 (OPT bit 1: two loads per tail
-            // group instead of a burst of sixteen, whose issue alone held the wave for ~500 cycles)
-            if constexpr (!(OPT & 2)) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) hv[j] = buf_load16(r_h, t * 16, j * (T * 16));
-            }
+            // H[k] comes from L2, two loads per tail group below (a burst of sixteen held the wave for ~500
+            // cycles of issue alone); in flight from there to the multiply in F3
             v2f tw[2][4];
             static_for<1, 4>([&](auto Rr) { tw[0][Rr.value] = lds_ld8(twc + 32 * bitrev<32>(Rr.value)); });
             CSDR_SB();
@@ -218,7 +220,7 @@ void fastfir_os2_kernel(FastFirArgs a)
                     static_for<0, 4>([&](auto Q) {
                         tw[(g + 1) & 1][Q.value] = lds_ld8(twc + 32 * bitrev<32>(4 * (g + 1) + Q.value));
                     });
-                if constexpr ((OPT & 2) != 0 && g < 8) {
+                if constexpr (g < 8) {
                     hv[2 * g] = buf_load16(r_h, t * 16, (2 * g) * (T * 16));
                     hv[2 * g + 1] = buf_load16(r_h, t * 16, (2 * g + 1) * (T * 16));
                 }
@@ -323,11 +325,7 @@ void fastfir_os2_kernel(FastFirArgs a)
             static_for<0, 8>([&](auto Gg) {
                 constexpr int g = Gg.value;
                 if constexpr (g + 2 < 8) fetch(std::integral_constant<int, g + 2>{});
-                static_for<0, 4>([&](auto Q) {
-                    constexpr int r = 4 * g + Q.value;
-                    if constexpr (r != 0) x[r] = cmul_conj(x[r], tw[r]);
-                });
-                dit_head4<g, 32, -1>(x);
+                dit_head4_conjtw<g, 32, -1, g == 0>(x, tw[4 * g], tw[4 * g + 1], tw[4 * g + 2], tw[4 * g + 3]);
                 CSDR_SB();
             });
             dit_single<8, 32, -1>(x);
@@ -362,15 +360,10 @@ void fastfir_os2_kernel(FastFirArgs a)
             CSDR_SB();
             static_for<0, R0 / 4>([&](auto Gg) {
                 constexpr int g = Gg.value;
-                static_for<4 * g, 4 * g + 4>([&](auto Rr) {
-                    constexpr int r = Rr.value, k0 = bitrev<R0>(r);
-                    if constexpr (k0 != 0) {
-                        y0[r] = cmul_conj(y0[r], pw[0][k0]);
-                        y1[r] = cmul_conj(y1[r], pw[1][k0]);
-                    }
-                });
-                dit_head4<g, R0, -1>(y0);
-                dit_head4<g, R0, -1>(y1);
+                dit_head4_conjtw<g, R0, -1, g == 0>(y0, pw[0][bitrev<R0>(4 * g)], pw[0][bitrev<R0>(4 * g + 1)],
+                                                    pw[0][bitrev<R0>(4 * g + 2)], pw[0][bitrev<R0>(4 * g + 3)]);
+                dit_head4_conjtw<g, R0, -1, g == 0>(y1, pw[1][bitrev<R0>(4 * g)], pw[1][bitrev<R0>(4 * g + 1)],
+                                                    pw[1][bitrev<R0>(4 * g + 2)], pw[1][bitrev<R0>(4 * g + 3)]);
                 if constexpr ((g & 1) == 1) CSDR_SB();
             });
             // sample 1024*n1 + 2t + e, n1 >= 8  ->  output offset 1024*(n1-8) + 2t + e
@@ -422,25 +415,15 @@ void fastfir_os2_kernel(FastFirArgs a)
     }
 }
 
-template <int OPT>
-static hipError_t launch2(const FastFirArgs &a, hipStream_t stream)
+hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream)
 {
     using Cfg = FastFirCfg<14>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<14, OPT>),
+    // per launch: the attribute belongs to the current device, and a process may drive several
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<14>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fastfir_os2_kernel<14, OPT>), dim3(a.channels * a.runs), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((fastfir_os2_kernel<14>), dim3(a.channels * a.runs), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
-}
-
-hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream, int opt)
-{
-    switch (opt) {
-    case 0: return launch2<0>(a, stream);
-    case 1: return launch2<1>(a, stream);
-    case 3: return launch2<3>(a, stream);
-    default: return hipErrorInvalidValue;
-    }
 }
 
 }  // namespace csdr

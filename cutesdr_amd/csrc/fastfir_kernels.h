@@ -30,6 +30,6 @@ hipError_t fastfir_launch(int log2n, const FastFirArgs &a, hipStream_t stream);
 int fastfir_bin_of(int log2n, int t, int r);
 
 // software-pipelined build for N = 16384 (fastfir2_kernels.hip): same LDS image and H order as fastfir_launch
-hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream, int opt);
+hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream);
 
 }  // namespace csdr

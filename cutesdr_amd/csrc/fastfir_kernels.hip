@@ -297,12 +297,10 @@ template <int LOG2N>
 static hipError_t launch_one(const FastFirArgs &a, hipStream_t stream)
 {
     using Cfg = FastFirCfg<LOG2N>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per launch: the attribute belongs to the current device, and a process may drive several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os_kernel<LOG2N, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     dim3 grid(a.channels * a.runs), block(Cfg::T);
     if (a.dbg_stage > 0) {

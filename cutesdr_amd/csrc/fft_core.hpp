@@ -128,11 +128,64 @@ __host__ __device__ __forceinline__ void bfly_dif(v2f &xa, v2f &xb)
         xb = cmul_c(u - v, v2f{c, s});
     }
 }
+// FMA forms of the decimation-in-time butterfly (translation units that define CSDR_FMA_BFLY):
+//   a' = a + b w  as two packed FMAs (b.x (c, s) + a, then b.y (-s, c) + that),  b' = 2 a - a'
+// three packed instructions instead of four (complex product, sum, difference); w in an SGPR pair.
+#if CSDR_PK_ASM && defined(CSDR_FMA_BFLY)
+#define CSDR_FMA_DIT 1
+#else
+#define CSDR_FMA_DIT 0
+#endif
+// a' = a + b*w, b' = a - b*w, w a run-time (VGPR) or compile-time value
+__host__ __device__ __forceinline__ void bfly_fma(v2f &xa, v2f &xb, v2f w)
+{
+#if CSDR_FMA_DIT
+    v2f t, a;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(xb), "v"(w), "v"(xa));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(a) : "v"(xb), "v"(w), "v"(t));
+    xb = xa * 2.0f - a;
+    xa = a;
+#else
+    const v2f v = cmul(xb, w);
+    const v2f u = xa;
+    xa = u + v; xb = u - v;
+#endif
+}
+// a' = a + b*conj(w), b' = a - b*conj(w)
+__host__ __device__ __forceinline__ void bfly_fma_conj(v2f &xa, v2f &xb, v2f w)
+{
+#if CSDR_FMA_DIT
+    v2f t, a;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(t) : "v"(xb), "v"(w), "v"(xa));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(a) : "v"(xb), "v"(w), "v"(t));
+    xb = xa * 2.0f - a;
+    xa = a;
+#else
+    const v2f v = cmul_conj(xb, w);
+    const v2f u = xa;
+    xa = u + v; xb = u - v;
+#endif
+}
+
 // DIT butterfly: v = b * e^{SIGN j 2 pi K/32}; a' = a + v, b' = a - v
 template <int K, int SIGN>
 __host__ __device__ __forceinline__ void bfly_dit(v2f &xa, v2f &xb)
 {
     const v2f u = xa;
+#if CSDR_FMA_DIT
+    if constexpr (K != 0 && K != 8) {
+        // (K = 4, 12 included: c = +-s = sqrt(1/2) needs no special case in this form)
+        constexpr float c = kCos32[K];
+        constexpr float s = (SIGN > 0 ? 1.0f : -1.0f) * kCos32[(K + 24) & 31];
+        v2f t, a;
+        const v2f w = {c, s};
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(xb), "s"(w), "v"(u));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(a) : "v"(xb), "s"(w), "v"(t));
+        xb = u * 2.0f - a;
+        xa = a;
+        return;
+    }
+#endif
     if constexpr (K == 0) {
         const v2f v = xb;
         xa = u + v; xb = u - v;
@@ -261,6 +314,19 @@ __host__ __device__ __forceinline__ void dit_head4(v2f (&x)[R])
     constexpr int a = 4 * G;
     bfly_dit<0, SIGN>(x[a], x[a + 1]);                               // stage 2
     bfly_dit<0, SIGN>(x[a + 2], x[a + 3]);
+    bfly_dit<0, SIGN>(x[a], x[a + 2]);                               // stage 4
+    bfly_dit<8, SIGN>(x[a + 1], x[a + 3]);
+}
+// dit_head4 with the conjugate pass twiddles of its four inputs folded in: x[4G+q] *= conj(tq) first
+// (FIRST_PLAIN: x[4G] carries no twiddle).  The odd inputs' products ride in the FMA butterflies.
+template <int G, int R, int SIGN, bool FIRST_PLAIN>
+__host__ __device__ __forceinline__ void dit_head4_conjtw(v2f (&x)[R], v2f t0, v2f t1, v2f t2, v2f t3)
+{
+    constexpr int a = 4 * G;
+    if constexpr (!FIRST_PLAIN) x[a] = cmul_conj(x[a], t0);
+    x[a + 2] = cmul_conj(x[a + 2], t2);
+    bfly_fma_conj(x[a], x[a + 1], t1);                               // stage 2
+    bfly_fma_conj(x[a + 2], x[a + 3], t3);
     bfly_dit<0, SIGN>(x[a], x[a + 2]);                               // stage 4
     bfly_dit<8, SIGN>(x[a + 1], x[a + 3]);
 }

@@ -157,9 +157,10 @@ def test_generic_kernel_at_16384_in_child_process():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_pipelined_and_generic_kernels_agree_bit_for_bit(oracle):
-    """Both kernels run the same arithmetic in the same order: identical output words, for even and odd
-    block counts (odd: the generic kernel serves both objects) and across two calls (overlap carried)."""
+def test_pipelined_and_generic_kernels_agree(oracle):
+    """The pipelined build (FMA-form inverse butterflies) and the generic kernel against the oracle and against
+    each other, for even and odd block counts (odd: the generic kernel serves both objects, so those are
+    bit-identical) and across two calls (overlap carried)."""
     import ctypes as C
     import cutesdr_amd as ca
     L = ca.lib()
@@ -170,12 +171,17 @@ def test_pipelined_and_generic_kernels_agree_bit_for_bit(oracle):
     for nb in (1, 2, 5, 8):
         x = (3000.0 * (rng.standard_normal((Cn, nb * n // 2)) + 1j * rng.standard_normal((Cn, nb * n // 2)))).astype(np.complex64)
         outs = []
-        for v in (0, 5):
+        for v in (0, 2):
             b = ca.FastFirBatch(Cn, n)
             b.setup(-5000, 5000, 0, 62500.0)
             assert L.csdr__fastfir_set_variant(b.h, v) == 0
             outs.append(np.concatenate([b.process(x), b.process(x[:, ::-1].copy())], axis=1))
-        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), nb
-        ff = oracle.CFastFIR(n); ff.SetupParameters(-5000, 5000, 0, 62500.0)
-        ref = np.concatenate([ff.ProcessData(x[0].astype(np.complex128)), ff.ProcessData(x[0, ::-1].astype(np.complex128))])
-        assert np.abs(outs[1][0] - ref).max() <= 2e-5 * np.abs(x).max()
+        tol = TOL * np.abs(x).max()
+        if nb & 1:
+            assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), nb
+        assert np.abs(outs[0] - outs[1]).max() <= tol, nb
+        for c in range(Cn):
+            ff = oracle.CFastFIR(n); ff.SetupParameters(-5000, 5000, 0, 62500.0)
+            ref = np.concatenate([ff.ProcessData(x[c].astype(np.complex128)), ff.ProcessData(x[c, ::-1].astype(np.complex128))])
+            for o in outs:
+                assert np.abs(o[c] - ref).max() <= tol, (nb, c)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of the K1 builds on the C3 workload in ONE process, interleaved rounds (the methodology
-rule for perf deltas): variant 0 = fastfir_os_kernel, 1 = 16-wave, 2 = software-pipelined build.
+rule for perf deltas): variant 0 = fastfir_os_kernel (generic), 2 = software-pipelined build.
 Also checks that every variant reproduces variant 0's output.  usage: ab_fastfir.py [variants] [rounds]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -32,7 +32,7 @@ def run():
     L.csdr__fastfir_set_variant.argtypes = [C.c_void_p, C.c_int]
     L.csdr__dbg_fastfir_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     ff = ca.FastFirBatch(Cn, 16384); ff.setup(-5000, 5000, 0, 62500.0)
-    assert L.csdr__fastfir_set_variant(ff.h, int(os.environ.get("K1_VARIANT", "2"))) == 0
+    assert L.csdr__fastfir_set_variant(ff.h, int("2")) == 0
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(50): ff.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T, st)
     assert L.csdr__dbg_fastfir_stage(ff.h, 0, C.c_void_p(dbg.data_ptr())) == 0
