@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: BASELINE.json config C3, 256 batched channels through the
-16384-pt CFastFIR overlap-save on one MI355X (the HBM-roofline config the metric is quoted on).
-One "step" = one pass of 256 channels x 2^19 complex samples (64 hops each) through the filter,
-inputs and outputs resident in HBM.  With --gpus N every rank owns its own 256 channels (channels
-shard with no data-path collective: weak scaling); the only torch.distributed calls are the barrier
-and the MAX-reduce of the elapsed time.
+"""bench.py -- headline benchmark of the MI355X CuteSDR dsp/ receive chain.
 
-Prints ONE JSON line on rank 0 (contract in the task statement).
+Workload c3 (default, the config BASELINE.json's metric is quoted on): 256 batched channels x 2^19 complex
+samples through the 16384-pt CFastFIR overlap-save on one MI355X, inputs and outputs resident in HBM.  One
+"step" = one pass of all channels through the filter.  The same run also reports, as secondary objects of the
+one JSON line: the distinct-filter variant of C3 (every channel its own H: +16 B/sample of filter traffic),
+the per-GPU share of config C4 (256 mixed AM/FM/USB receivers x 2^21 raw samples through the whole
+CDemodulator chain) and a post-timing parity spot check of the buffer that was just timed against the oracle.
+Workload c4 makes the chain the primary metric instead.
+
+Multi-GPU: channels are independent, so every rank owns its own channels (contiguous channel ranges, weak
+scaling) and the data path has no collective; torch.distributed carries the barrier, the MAX-reduce of the
+elapsed time and -- for the chain -- the optional gather of per-channel S-meter + audio to rank 0 (RCCL,
+timed separately, never inside `value`).  `--gpus N` without a launcher starts N rank processes itself
+(fresh children, spawned before this process touches torch or HIP); under torch.distributed.run the
+RANK/LOCAL_RANK/WORLD_SIZE environment is used as it is.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -25,6 +38,11 @@ FS = 62500.0
 ALG_BYTES_PER_SAMPLE = 16.0       # 8 B fp32 I/Q read + 8 B written
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRIC = "complex IQ MSamples/s through CFastFIR+demod chain; achieved HBM GB/s vs peak"
+PREWARM_S = 0.25                  # untimed, before the W warm-up steps: the first launches of a process run ~13 % slow
+K1_SOURCES = ("cutesdr_amd/csrc/fastfir2_kernels.hip", "cutesdr_amd/csrc/fastfir_kernels.hip",
+              "cutesdr_amd/csrc/fastfir_dev.hpp", "cutesdr_amd/csrc/fft_core.hpp", "cutesdr_amd/csrc/capi_fastfir.hip")
+C4_T = 1 << 21                    # raw samples per receiver and step of the chain workload
+C4_FS = 2e6
 
 
 # ---------------------------------------------------------------- distributed plumbing
@@ -33,6 +51,10 @@ def dist_init(backend=None):
     import torch.distributed as dist
     ctx = SimpleNamespace(rank=int(os.environ.get("RANK", "0")), world=int(os.environ.get("WORLD_SIZE", "1")),
                           local=int(os.environ.get("LOCAL_RANK", "0")), dist=dist, backend=backend)
+    if os.environ.get("CSDR_BENCH_ONE_GPU"):
+        # rehearsal of the multi-rank code on a one-GPU box (tests): every rank on cuda:0, collectives over gloo
+        ctx.local, backend = 0, "gloo"
+        ctx.backend = backend
     if ctx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
@@ -70,27 +92,105 @@ def dist_finish(ctx):
         ctx.dist.destroy_process_group()
 
 
-def result_line(ctx, channels, samples, steps, warmup, elapsed, kern_ms, traffic=None, cpu=None):
-    per_step = channels * samples                     # samples one rank filters per step
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """Start n rank processes of this script (one GPU each), relay rank 0's output, return the worst exit code.
+    Runs before anything in this process has imported torch or touched HIP: the children are fresh
+    interpreters, nothing is re-executed in place."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the one JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    rc = 0
+    deadline = time.time() + 3000
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:                          # a rank died: the others would wait for it forever
+                        q.terminate()
+        if time.time() > deadline:
+            for q in pending:
+                q.kill()
+            return 124
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------- result line
+def roofline_obj(achieved_gbs, kern_ms, kernel, alg_bytes, traffic):
+    return {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+            "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def result_line(ctx, channels, samples, steps, warmup, elapsed, kern_ms, traffic=None, cpu=None, workload="c3",
+                extra=None):
+    per_step = channels * samples                     # samples one rank processes per step
     value = per_step * steps * ctx.world / elapsed / 1e6
-    achieved = ALG_BYTES_PER_SAMPLE * per_step / (kern_ms * 1e-3) / 1e9
-    return {
+    if workload == "c3":
+        alg = ALG_BYTES_PER_SAMPLE * per_step
+        wl = ("C3: %d channels/GPU x 2^%d IQ samples, 16384-pt CFastFIR overlap-save (8193 taps, hop 8192), "
+              "shared -5..+5 kHz filter @62.5 kS/s" % (channels, samples.bit_length() - 1))
+        kernel = "csdr::fastfir_os2_kernel<14>"
+        cfg = {"workload": wl, "channels_per_gpu": channels, "samples_per_channel": samples, "fft_size": FFT_N}
+    else:
+        alg = (8.0 + 4.0 / 32.0) * per_step           # 8 B raw I/Q in + 4 B mono audio out per 32 raw samples (SURVEY 8d)
+        wl = ("C4 per-GPU share: %d mixed AM/FM/USB receivers/GPU x 2^%d raw IQ samples @2 MSPS through the whole "
+              "CDemodulator chain (downconvert, 2048-pt CFastFIR, S-meter, AGC, demodulator)"
+              % (channels, samples.bit_length() - 1))
+        kernel = "whole chain: every launch of csdr_demod_batch_process (downconv_kernel dominant)"
+        cfg = {"workload": wl, "channels_per_gpu": channels, "samples_per_channel": samples, "fft_size": 2048}
+    cfg["parallelism"] = "channels sharded x%d, no data-path collective" % ctx.world
+    cfg["prewarm_s"] = PREWARM_S
+    line = {
         "metric": METRIC, "value": round(value, 2), "unit": "MSamples/s",
         "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C3: %d channels/GPU x 2^%d IQ samples, 16384-pt CFastFIR overlap-save "
-                               "(8193 taps, hop 8192), shared -5..+5 kHz filter @62.5 kS/s"
-                               % (channels, samples.bit_length() - 1),
-                   "channels_per_gpu": channels, "samples_per_channel": samples, "fft_size": FFT_N,
-                   "parallelism": "channels sharded x%d, no collective" % ctx.world},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "csdr::fastfir_os_kernel<14, false>", "kernel_ms": round(kern_ms, 4),
-                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * per_step},
+        "dtype": "f32", "data": "synthetic", "config": cfg,
+        "roofline": roofline_obj(alg / (kern_ms * 1e-3) / 1e9, kern_ms, kernel, alg, traffic),
         "cpu_baseline": cpu,
     }
+    if extra:
+        line.update(extra)
+    return line
+
+
+def k1_source_hash():
+    h = hashlib.sha256()
+    for rel in K1_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the headline kernel from the committed PMC profile -- only if that profile was
+    taken on exactly these kernel sources (profiles/traffic_latest.json carries their hash); null otherwise."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        d = json.load(open(path))
+        if d.get("k1_source_sha16") == k1_source_hash():
+            return d.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 # ---------------------------------------------------------------- CPU baseline
@@ -154,53 +254,24 @@ def cpu_baseline(budget_s=18.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=100)   # the first dozens of launches run ~13 % slower (clock ramp)
-    ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU")
-    ap.add_argument("--blocks-per-wg", type=int, default=0)
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libcutesdr_mi has no CPU fallback)")
-    ctx = dist_init()
-    torch.cuda.set_device(ctx.local)
-
-    import cutesdr_amd as ca
-    C, T = args.channels, T_PER_CH
-    lo, _ = shard_channels(ctx, C * ctx.world)          # this rank's channels: lo .. lo+C-1
-    dev = torch.device("cuda", ctx.local)
-    g = torch.Generator(device=dev)
-    g.manual_seed(0xC0DE0000 + lo)
-    # synthetic IQ resident in HBM: noise at -20 dBFS of a 16-bit full scale
-    x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * 3276.7
-    y = torch.empty_like(x)
-    fir = ca.FastFirBatch(C, FFT_N, device=ctx.local)
-    fir.setup(-5000, 5000, 0, FS)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        fir.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T, stream, args.blocks_per_wg)
-
-    # Bring the GPU to its steady clocks before the contract's W warm-up steps: the first dozens of
-    # launches of a process run ~13 % slower (clock ramp), whatever W the caller passes.  Untimed.
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.25:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
+# ---------------------------------------------------------------- timing helpers
+def timed_steps(torch, ctx, step, steps, warmup, prewarm=True):
+    """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides; returns
+    (elapsed seconds, MAX over ranks; mean HIP-event duration of a step on this rank in ms)."""
+    if prewarm:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < PREWARM_S:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     dist_barrier(ctx)
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         ev[i][0].record()
         step()
         ev[i][1].record()
@@ -208,20 +279,279 @@ def main():
     dist_barrier(ctx)
     torch.cuda.synchronize()
     elapsed = dist_max(ctx, time.perf_counter() - t0)
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    return elapsed, sum(a.elapsed_time(b) for a, b in ev) / steps
 
+
+# ---------------------------------------------------------------- workloads
+class C3Workload:
+    """256 channels x 2^19 samples through the 16384-pt overlap-save filter, all resident in HBM."""
+
+    def __init__(self, torch, ca, ctx, channels, blocks_per_wg=0):
+        self.torch, self.ca, self.C, self.T = torch, ca, channels, T_PER_CH
+        lo, _ = shard_channels(ctx, channels * ctx.world)      # this rank's channels: lo .. lo+C-1
+        dev = torch.device("cuda", ctx.local)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0xC0DE0000 + lo)
+        # synthetic IQ resident in HBM: noise at -20 dBFS of a 16-bit full scale
+        self.x = torch.randn((self.C, self.T, 2), generator=g, device=dev, dtype=torch.float32) * 3276.7
+        self.y = torch.empty_like(self.x)
+        self.fir = ca.FastFirBatch(self.C, FFT_N, device=ctx.local)
+        self.fir.setup(-5000, 5000, 0, FS)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.bpw = blocks_per_wg
+
+    def step(self):
+        self.fir.process_ptr(self.x.data_ptr(), self.T, self.T, self.y.data_ptr(), self.T, self.stream, self.bpw)
+
+    def parity_check(self, nch=4):
+        """The buffer that was just timed against the fp64 oracle: the stream is periodic (the same input every
+        step), so the last step's output equals the oracle's second pass over the same samples."""
+        import numpy as np
+        from oracle import oracle as orc
+        self.torch.cuda.synchronize()
+        chans = sorted(set(int(c) for c in np.linspace(0, self.C - 1, nch)))
+        worst = 0.0
+        for c in chans:
+            xc = self.x[c].cpu().numpy().astype(np.float64)
+            xc = xc[:, 0] + 1j * xc[:, 1]
+            ff = orc.CFastFIR(FFT_N)
+            ff.SetupParameters(-5000, 5000, 0, FS)
+            ff.ProcessData(xc)
+            ref = ff.ProcessData(xc)
+            yc = self.y[c].cpu().numpy().astype(np.float64)
+            worst = max(worst, float(np.abs((yc[:, 0] + 1j * yc[:, 1]) - ref).max() / np.abs(xc).max()))
+        return {"channels": chans, "samples_each": self.T, "max_err_over_max_abs_x": worst, "tolerance": 2e-5,
+                "ok": bool(worst <= 2e-5)}
+
+    def distinct_filters(self, ctx, steps=100):
+        """Same launch with one H per channel (pass-bands staggered by 10 Hz): +16 B/sample of filter reads."""
+        torch = self.torch
+        fir = self.ca.FastFirBatch(self.C, FFT_N, device=ctx.local)
+        for c in range(self.C):
+            fir.setup(-5000 + 10 * (c % 32), 5000 + 10 * (c % 32), 0, FS, channel=c)
+        def step():
+            fir.process_ptr(self.x.data_ptr(), self.T, self.T, self.y.data_ptr(), self.T, self.stream, self.bpw)
+        for _ in range(30):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        n = self.C * self.T
+        return {"kernel_ms": round(ms, 4), "MSamples_per_s": round(n / ms / 1e3, 1),
+                "achieved_GBps_at_16B_per_sample": round(16.0 * n / ms / 1e6, 1),
+                "GBps_counting_the_H_reads": round(32.0 * n / ms / 1e6, 1),
+                "frac_at_16B_per_sample": round(16.0 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "note": "every channel its own filter: N*8 B of H per N/2-sample hop = +16 B/sample of filter reads (SURVEY "
+                        "8d); a channel's 128 KB of H is re-read by one workgroup for 64 consecutive hops, so after the "
+                        "first hop those reads are served by L2 / Infinity Cache, not HBM"}
+
+
+class C4Workload:
+    """Per-GPU share of BASELINE config C4: mixed AM / FM / USB receivers, each tuned to its own carrier in its
+    own 2 MSPS stream, through csdr_demod_batch (CDemodulator::ProcessData, dsp/demodulator.cpp:163-215)."""
+
+    def __init__(self, torch, ca, ctx, channels):
+        self.torch, self.ca, self.ctx, self.C, self.T = torch, ca, ctx, channels, C4_T
+        dev = torch.device("cuda", ctx.local)
+        lo, _ = shard_channels(ctx, channels * ctx.world)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0xC0DE0000 + lo)
+        A = 3276.7                                                # -20 dBFS carrier, AWGN -70 dBFS per component
+        C, T = self.C, self.T
+        x = torch.randn((C, T, 2), generator=g, device=dev, dtype=torch.float32) * (32767.0 * 10 ** (-70 / 20))
+        t = torch.arange(T, device=dev, dtype=torch.float64) / C4_FS
+        for c in range(C):
+            gc = lo + c                                           # global channel id: kind and carrier follow it
+            fc = 100e3 + 500.0 * (gc % 1024)
+            if gc % 3 == 0:                                       # AM 50 % / 1 kHz
+                ph = 2 * torch.pi * fc * t
+                amp = A * (1.0 + 0.5 * torch.sin(2 * torch.pi * 1000.0 * t))
+                x[c, :, 0] += (amp * torch.cos(ph)).float(); x[c, :, 1] += (amp * torch.sin(ph)).float()
+            elif gc % 3 == 1:                                     # FM +-3 kHz / 1 kHz
+                ph = 2 * torch.pi * fc * t + 3.0 * torch.sin(2 * torch.pi * 1000.0 * t)
+                x[c, :, 0] += (A * torch.cos(ph)).float(); x[c, :, 1] += (A * torch.sin(ph)).float()
+            else:                                                 # two-tone SSB
+                for off in (1200.0, 2340.0):
+                    ph = 2 * torch.pi * (fc + off) * t
+                    x[c, :, 0] += (0.5 * A * torch.cos(ph)).float(); x[c, :, 1] += (0.5 * A * torch.sin(ph)).float()
+        del t
+        self.x = x
+        base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                    FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
+                    AgcManualGain=30, AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+        modes = [(ca.DEMOD_AM, dict(HiCutmin=500, HiCutmax=10000, LowCutmax=-500, LowCutmin=-10000)),
+                 (ca.DEMOD_FM, dict()),
+                 (ca.DEMOD_USB, dict(HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200,
+                                     LowCutmin=0, Symetric=0))]
+        b = ca.DemodBatch(C, 2048, device=ctx.local)
+        b.set_input_rate(C4_FS)
+        for c in range(C):
+            m, kw = modes[(lo + c) % 3]
+            b.set_demod(c, m, ca.DemodInfo(**dict(base, **kw)))
+        b.commit()
+        for c in range(C):
+            b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)))
+        self.b = b
+        self.cap = T // 16 + 4096                                  # audio row capacity (highest output rate: /32)
+        self.aud = torch.zeros((C, self.cap), device=dev, dtype=torch.float32)
+        self.sm = torch.zeros((C,), device=dev, dtype=torch.float32)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self):
+        self.b.process_ptr(self.x.data_ptr(), self.T, self.T, self.aud.data_ptr(), self.cap, self.stream)
+
+    def gather(self, reps=5):
+        """Per-channel S-meter and audio of one step gathered to rank 0 over RCCL (SURVEY sections 5, 8e): the
+        only exchange the multi-channel configuration has.  Timed on its own, never part of `value`."""
+        torch, ctx = self.torch, self.ctx
+        n_aud = self.T // 32                                       # what every channel is guaranteed to have written
+        payload = torch.empty((self.C, 1 + n_aud), device=self.aud.device, dtype=torch.float32)
+        def pack():
+            self.b.smeter_all_ptr(self.sm.data_ptr(), None, self.stream)
+            payload[:, 0] = self.sm
+            payload[:, 1:] = self.aud[:, :n_aud]
+        pack()
+        torch.cuda.synchronize()
+        if ctx.world == 1:
+            return {"ms": None, "bytes_to_rank0": 0, "note": "single rank: nothing to gather",
+                    "smeter_db_first4": [round(float(v), 2) for v in self.sm[:4].cpu()]}
+        on_gpu = ctx.backend == "nccl"                            # (gloo rehearsal: through host memory)
+        wire = payload if on_gpu else payload.cpu()
+        dst = [torch.empty_like(wire) for _ in range(ctx.world)] if ctx.rank == 0 else None
+        ctx.dist.gather(wire, dst, dst=0)                          # warm (communicator setup)
+        torch.cuda.synchronize()
+        dist_barrier(ctx)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pack()
+            if not on_gpu:
+                wire.copy_(payload)
+            ctx.dist.gather(wire, dst, dst=0)
+        torch.cuda.synchronize()
+        dist_barrier(ctx)
+        ms = dist_max(ctx, time.perf_counter() - t0) / reps * 1e3
+        nbytes = payload.numel() * 4 * (ctx.world - 1)
+        return {"ms": round(ms, 3), "bytes_to_rank0": nbytes, "GBps_into_rank0": round(nbytes / ms / 1e6, 1),
+                "collective": "torch.distributed.gather (RCCL send/recv over xGMI), S-meter + %d audio samples "
+                              "per channel" % n_aud}
+
+    def summary(self, ctx, steps, warmup):
+        elapsed, ms = timed_steps(self.torch, ctx, self.step, steps, warmup, prewarm=False)
+        n = self.C * self.T
+        return {"channels_per_gpu": self.C, "raw_samples_per_channel": self.T, "steps": steps,
+                "ms_per_step": round(elapsed / steps * 1e3, 4), "event_ms_per_step": round(ms, 4),
+                "raw_input_MSamples_per_s_all_gpus": round(n * steps * ctx.world / elapsed / 1e6, 1),
+                "algorithmic_GBps_per_gpu": round((8.0 + 4.0 / 32.0) * n / ms / 1e6, 1),
+                "frac_of_hbm_peak": round((8.0 + 4.0 / 32.0) * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "gather": self.gather()}
+
+
+class StubWorkload:
+    """CPU stand-in for the tests of the multi-rank path (no GPU, gloo): sleeps instead of launching."""
+
+    def __init__(self, channels):
+        self.C, self.T = channels, 1 << 12
+
+    def step(self):
+        time.sleep(0.002)
+
+
+def run_stub(args):
+    ctx = dist_init(backend="gloo")
+    w = StubWorkload(args.channels)
+    lo, hi = shard_channels(ctx, args.channels * ctx.world)
+    for _ in range(args.warmup):
+        w.step()
+    dist_barrier(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.step()
+    dist_barrier(ctx)
+    elapsed = dist_max(ctx, time.perf_counter() - t0)
     if ctx.rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        cpu = cpu_baseline() if (ctx.world == 1 and not args.no_cpu) else None
-        print(json.dumps(result_line(ctx, C, T, args.steps, args.warmup, elapsed, kern_ms, traffic, cpu)), flush=True)
+        line = result_line(ctx, w.C, w.T, args.steps, args.warmup, elapsed, elapsed / args.steps * 1e3,
+                           extra={"stub": True, "rank0_channels": [lo, hi]})
+        print(json.dumps(line), flush=True)
     dist_finish(ctx)
 
 
+def run_rank(args):
+    # the chain forks its decimator-plan groups onto several streams; HIP's default of 4 hardware queues would
+    # serialise some of them (read when the runtime initialises, so before torch touches the GPU)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libcutesdr_mi has no CPU fallback)")
+    ctx = dist_init()
+    torch.cuda.set_device(ctx.local)
+    import cutesdr_amd as ca
+
+    extra = {}
+    if args.workload == "c3":
+        w = C3Workload(torch, ca, ctx, args.channels, args.blocks_per_wg)
+        elapsed, kern_ms = timed_steps(torch, ctx, w.step, args.steps, args.warmup)
+        if ctx.rank == 0 and not args.no_check:
+            extra["parity_checked"] = w.parity_check()
+        if ctx.rank == 0 and not args.no_secondary:
+            extra["distinct_filters"] = w.distinct_filters(ctx)
+        chans, samples = w.C, w.T
+        del w
+        torch.cuda.empty_cache()
+        if not args.no_secondary:
+            c4 = C4Workload(torch, ca, ctx, CHANNELS)
+            s = c4.summary(ctx, 30, 15)
+            if ctx.rank == 0:
+                extra["chain_c4"] = s
+            del c4
+    else:
+        w = C4Workload(torch, ca, ctx, args.channels)
+        elapsed, kern_ms = timed_steps(torch, ctx, w.step, args.steps, args.warmup)
+        g = w.gather()
+        if ctx.rank == 0:
+            extra["gather"] = g
+        chans, samples = w.C, w.T
+        del w
+
+    if ctx.rank == 0:
+        traffic = profiled_traffic() if args.workload == "c3" else None
+        cpu = cpu_baseline() if (ctx.world == 1 and not args.no_cpu) else None
+        print(json.dumps(result_line(ctx, chans, samples, args.steps, args.warmup, elapsed, kern_ms, traffic, cpu,
+                                     args.workload, extra)), flush=True)
+    dist_finish(ctx)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", choices=("c3", "c4"), default="c3")
+    ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU")
+    ap.add_argument("--blocks-per-wg", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-timing parity spot check")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the distinct-filter and chain measurements")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)     # tests: CPU stand-in workload, gloo
+    args = ap.parse_args(argv)
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves, before this process imports torch or touches the GPU
+        return spawn_ranks(args.gpus, argv)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and int(os.environ.get("RANK", "0")) == 0:
+        print("bench.py: --gpus %d but the launcher started %s ranks; using the launcher's" %
+              (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+    if args.stub:
+        run_stub(args)
+    else:
+        run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

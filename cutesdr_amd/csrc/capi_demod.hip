@@ -488,6 +488,18 @@ double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel)
     if (!b || channel < 0 || channel >= b->channels || b->core_of[channel] < 0) return 0.0;
     return b->cores[b->core_of[channel]]->pc.smeter_ave(b->row_of[channel]);
 }
+/* CSMeter::GetAve / GetPeak of every channel into device arrays indexed by channel (either may be NULL);
+ * reading the peak resets it, as GetPeak does (smeter.cpp:98-103).  Asynchronous on `stream`. */
+int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_peak, void *stream)
+{
+    if (!b || (!d_ave && !d_peak)) return fail(CSDR_EINVAL, "bad argument");
+    if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    for (size_t ki = 0; ki < b->cores.size(); ki++)
+        CSDR_HIP(smeter_collect_launch(b->cores[ki]->pc.d_chan, b->cores[ki]->rows, b->d_rows[ki], d_ave, d_peak,
+                                       (hipStream_t)stream));
+    return CSDR_OK;
+}
 /* d_in: [channels][in_stride] complex fp32; d_out: [channels][out_stride] fp32 mono audio.
  * Chunking: one call = one pass of the chain over n_per_channel samples (the host form uses
  * m_InBufLimit-sized passes; the decimator and filter are chunking independent, the squelch

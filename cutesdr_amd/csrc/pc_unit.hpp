@@ -25,6 +25,7 @@ struct PcUnit {
         if (d_dly) (void)hipFree(d_dly);
         if (d_mag) (void)hipFree(d_mag);
         if (d_scratch) (void)hipFree(d_scratch);
+        if (d_sm) (void)hipFree(d_sm);
     }
     int init(int dev, int nch)
     {
@@ -84,19 +85,29 @@ struct PcUnit {
         smeter_rate(h[c].sm, fs);
         return push(c);
     }
-    // CSMeter::GetPeak resets the peak (smeter.cpp:98-103)
+    // CSMeter::GetPeak resets the peak (smeter.cpp:98-103).  Read and reset on the device, one field: the rest of
+    // the channel state (AGC, PLL, filter memories) is never written back from a stale host copy.
+    double *d_sm = nullptr;              // scratch of the single-channel getters
+    int smeter_read(int c, bool want_peak, double *out)
+    {
+        CSDR_HIP(hipSetDevice(device));
+        CSDR_HIP(hipDeviceSynchronize());
+        if (!d_sm) CSDR_HIP(hipMalloc((void **)&d_sm, 2 * sizeof(double)));
+        CSDR_HIP(smeter_collect_launch(d_chan + c, 1, nullptr, want_peak ? nullptr : d_sm, want_peak ? d_sm + 1 : nullptr, nullptr));
+        double v[2] = {0, 0};
+        CSDR_HIP(hipMemcpy(v, d_sm, sizeof(v), hipMemcpyDeviceToHost));
+        *out = want_peak ? v[1] : v[0];
+        return CSDR_OK;
+    }
     double smeter_peak(int c)
     {
-        if (pull(c)) return 0.0;
-        const double x = h[c].sm.peak_mag;
-        h[c].sm.peak_mag = 0;
-        (void)push(c);
-        return x + 5.0;
+        double x = 0.0;
+        return smeter_read(c, true, &x) ? 0.0 : x;
     }
     double smeter_ave(int c)
     {
-        if (pull(c)) return 0.0;
-        return h[c].sm.ave_mag + 5.0;
+        double x = 0.0;
+        return smeter_read(c, false, &x) ? 0.0 : x;
     }
     int run(int flags, const float *d_in, long in_stride, float *d_out, long out_stride, int nbursts,
             int burst, hipStream_t stream, const int *d_out_rows = nullptr)

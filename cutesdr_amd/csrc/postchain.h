@@ -79,6 +79,8 @@ struct PcArgs {
 };
 
 hipError_t postchain_launch(const PcArgs &a, hipStream_t stream);
+hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, float *ave, float *peak, hipStream_t stream);
+hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, double *ave, double *peak, hipStream_t stream);
 hipError_t filter_leaf_launch(PcFir *fir, PcIir *iir, const float *in, float *out, int n, int op, hipStream_t stream);
 
 }  // namespace csdr

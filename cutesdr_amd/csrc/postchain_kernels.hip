@@ -1043,6 +1043,32 @@ hipError_t filter_leaf_launch(PcFir *fir, PcIir *iir, const float *in, float *ou
 
 // waves per channel: four when the channels alone cannot fill the chip, else one.
 // CSDR_POSTCHAIN_WAVES=1|4|8 overrides (measurements: 4 beats 8 on 256 channels, 3.8 vs 4.1 ms).
+// CSMeter::GetAve / GetPeak (dsp/smeter.cpp:98-112) of every channel of a unit at once, without moving the
+// channel state: ave[row] = average + 5 dB, peak[row] = peak + 5 dB and the peak is reset to 0 as GetPeak
+// does.  rows: optional output index of each channel.
+template <class T>
+__global__ void smeter_collect_kernel(PcChannel *chan, int channels, const int *rows, T *ave, T *peak)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= channels) return;
+    const int o = rows ? rows[c] : c;
+    if (ave) ave[o] = (T)(chan[c].sm.ave_mag + 5.0);
+    if (peak) {
+        peak[o] = (T)(chan[c].sm.peak_mag + 5.0);
+        chan[c].sm.peak_mag = 0.0;
+    }
+}
+hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, float *ave, float *peak, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smeter_collect_kernel<float>, dim3((channels + 255) / 256), dim3(256), 0, stream, chan, channels, rows, ave, peak);
+    return hipGetLastError();
+}
+hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, double *ave, double *peak, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smeter_collect_kernel<double>, dim3((channels + 255) / 256), dim3(256), 0, stream, chan, channels, rows, ave, peak);
+    return hipGetLastError();
+}
+
 template <int NW>
 static hipError_t pc_launch_nw(const PcArgs &a, hipStream_t stream)
 {

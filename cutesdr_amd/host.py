@@ -589,6 +589,20 @@ class DemodBatch(_Obj):
     def out_count(self, channel):
         return check(lib().csdr_demod_batch_out_count(self.h, channel))
 
+    def smeter_all_ptr(self, d_ave, d_peak=None, stream=None):
+        check(lib().csdr_demod_batch_get_smeter_all(self.h, C.c_void_p(d_ave) if d_ave else None,
+                                                    C.c_void_p(d_peak) if d_peak else None,
+                                                    C.c_void_p(stream) if stream else None), "get_smeter_all")
+
+    def smeter_all(self, peak=False):
+        """S-meter averages (and optionally peaks, which resets them) of every channel"""
+        d = DeviceBuffer(8 * self.channels, self.device)
+        self.smeter_all_ptr(d.ptr, d.ptr + 4 * self.channels if peak else None)
+        sync(self.device)
+        v = d.download(np.float32, 2 * self.channels)
+        d.free()
+        return (v[:self.channels], v[self.channels:]) if peak else v[:self.channels]
+
     def process_ptr(self, d_in, in_stride, n, d_out, out_stride, stream=None):
         check(lib().csdr_demod_batch_process(self.h, C.c_void_p(d_in), in_stride, n, C.c_void_p(d_out), out_stride,
                                              C.c_void_p(stream) if stream else None), "csdr_demod_batch_process")

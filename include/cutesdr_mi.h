@@ -247,6 +247,10 @@ int csdr_demod_batch_commit(csdr_demod_batch *b);
 int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq);
 double csdr_demod_batch_get_output_rate(csdr_demod_batch *b, int channel);
 double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel);
+/* CSMeter::GetAve / GetPeak (smeter.cpp:98-112) of every channel at once into device arrays [channels]
+ * (either may be NULL); reading the peaks resets them, as GetPeak does.  Asynchronous on `stream`: ordered
+ * behind the process calls issued on it.  What a multi-GPU host gathers from its ranks. */
+int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_peak, void *stream);
 /* d_in [channels][in_stride] complex fp32 -> d_out [channels][out_stride] fp32 mono audio */
 int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
                              int n_per_channel, float *d_out, long long out_stride, void *stream);

@@ -1,12 +1,66 @@
-"""The N>1 path of bench.py on the CPU: two gloo ranks shard the channels (no data-path
-collective), synchronise with a barrier and reduce the elapsed time with MAX, exactly the
-torch.distributed calls bench.py makes on RCCL."""
+"""The N>1 path of bench.py on the CPU.  (1) bench.py --gpus 2 with no launcher starts two rank processes
+itself (fresh children) and rank 0 prints ONE JSON line with n_gpus = 2; the ranks run a CPU stand-in
+workload over gloo, everything else -- sharding, barrier, MAX-reduce, result line -- is the code the GPU run
+uses.  (2) the same under torch.distributed.run, the way the driver launches it.  (3) the aggregation
+arithmetic on known numbers."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return env
+
+
+def _json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+
+
+def test_gpus_flag_spawns_the_ranks_itself():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "4",
+                        "--warmup", "1", "--channels", "1024"], capture_output=True, text=True, timeout=300,
+                       env=_clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1                                     # rank 0 only, one line
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["rank0_channels"] == [0, 1024]                 # contiguous channel ranges, 1024 per rank
+    # whole-job aggregate: both ranks' channels over the slowest rank's time
+    assert abs(line["value"] - 2 * 1024 * 4096 * 4 / (line["ms_per_step"] * 4e-3) / 1e6) / line["value"] < 1e-3
+    assert line["cpu_baseline"] is None and "roofline" in line
+
+
+def test_single_rank_default_does_not_spawn():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1
+
+
+def test_under_torch_distributed_run():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
 
 
 def test_two_rank_gloo_aggregation(tmp_path):
@@ -24,12 +78,11 @@ def test_two_rank_gloo_aggregation(tmp_path):
         "line = bench.result_line(ctx, channels=hi - lo, samples=1 << 12, steps=4, warmup=1, elapsed=tmax, kern_ms=1.0)\n"
         "if ctx.rank == 0: print(json.dumps({'tmax': tmax, 'range0': [lo, hi], 'line': line}))\n"
         "bench.dist_finish(ctx)\n" % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
-                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                       capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out = _json_lines(r.stdout)[-1]
     assert abs(out["tmax"] - 0.15) < 1e-9                      # MAX over ranks, not rank 0's own time
     assert out["range0"] == [0, 1024]                          # contiguous channel ranges per rank
     line = out["line"]
@@ -39,3 +92,28 @@ def test_two_rank_gloo_aggregation(tmp_path):
     for k in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype",
               "data", "config", "roofline"):
         assert k in line
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_rehearsed_on_one_gpu():
+    """The GPU code of the multi-rank path -- both workloads, the S-meter/audio gather, the single JSON line --
+    with two rank processes sharing cuda:0 and gloo in place of RCCL (CSDR_BENCH_ONE_GPU: a one-GPU box cannot
+    host two RCCL ranks).  Started by bench.py's own --gpus spawn path."""
+    env = dict(_clean_env(), CSDR_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["parity_checked"]["ok"]
+    g = line["chain_c4"]["gather"]
+    assert g["bytes_to_rank0"] == 256 * (1 + (1 << 21) // 32) * 4 and g["ms"] > 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "3",
+                        "--warmup", "2", "--no-cpu"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["n_gpus"] == 2 and "C4" in line["config"]["workload"] and line["gather"]["ms"] > 0
