@@ -108,6 +108,8 @@ struct ChainCore {
     {
         if (need <= cap) return CSDR_OK;
         need = (need + L + 1023) / 1024 * 1024;
+        // growing the staging (rare): the pending samples may still be in flight on a non-blocking stream
+        CSDR_HIP(hipDeviceSynchronize());
         float *ns = nullptr, *nf = nullptr, *na = nullptr;
         CSDR_HIP(hipMalloc((void **)&ns, (size_t)rows * need * 8));
         CSDR_HIP(hipMalloc((void **)&nf, (size_t)rows * need * 8));

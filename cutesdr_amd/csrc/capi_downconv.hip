@@ -15,6 +15,10 @@ struct csdr_downconvert_batch {
     int hist_stride;                       // samples per channel in each history half
     float *d_hist; int hist_cur;           // 2 x [channels][hist_stride] mixed samples
     DcChan *d_chan; int *d_list; float *d_amp;
+    // per-call NCO state and channel lists travel through pinned host memory (a ring of slots, one event each)
+    // so that a batch step only enqueues: copies from pageable memory would block the host on the stream
+    static constexpr int kSlots = 8;
+    unsigned char *h_pin; size_t slot_bytes; int slot; hipEvent_t slot_ev[kSlots]; bool slot_used[kSlots];
 };
 
 static int ensure_hist(csdr_downconvert_batch *b)
@@ -66,12 +70,17 @@ csdr_downconvert_batch *csdr_downconvert_batch_create(int device, int channels)
     b->plan_of.assign(channels, 0);
     b->hist_stride = 0; b->d_hist = nullptr; b->hist_cur = 0;
     b->d_chan = nullptr; b->d_list = nullptr; b->d_amp = nullptr;
+    b->h_pin = nullptr; b->slot = 0; b->slot_bytes = (sizeof(DcChan) + sizeof(int)) * (size_t)channels;
+    for (int i = 0; i < csdr_downconvert_batch::kSlots; i++) { b->slot_ev[i] = nullptr; b->slot_used[i] = false; }
     std::vector<float> amp(DC_AMP_N);
     dc_amp_table(amp.data(), DC_AMP_N);
     bool ok = hipMalloc((void **)&b->d_chan, sizeof(DcChan) * channels) == hipSuccess &&
               hipMalloc((void **)&b->d_list, sizeof(int) * channels) == hipSuccess &&
               hipMalloc((void **)&b->d_amp, sizeof(float) * DC_AMP_N) == hipSuccess &&
+              hipHostMalloc((void **)&b->h_pin, b->slot_bytes * csdr_downconvert_batch::kSlots, hipHostMallocDefault) == hipSuccess &&
               hipMemcpy(b->d_amp, amp.data(), sizeof(float) * DC_AMP_N, hipMemcpyHostToDevice) == hipSuccess;
+    for (int i = 0; ok && i < csdr_downconvert_batch::kSlots; i++)
+        ok = hipEventCreateWithFlags(&b->slot_ev[i], hipEventDisableTiming) == hipSuccess;
     if (!ok || ensure_hist(b) != CSDR_OK) {
         fail(CSDR_ENOMEM, "device allocation failed");
         csdr_downconvert_batch_destroy(b);
@@ -88,6 +97,8 @@ void csdr_downconvert_batch_destroy(csdr_downconvert_batch *b)
     if (b->d_chan) (void)hipFree(b->d_chan);
     if (b->d_list) (void)hipFree(b->d_list);
     if (b->d_amp) (void)hipFree(b->d_amp);
+    if (b->h_pin) (void)hipHostFree(b->h_pin);
+    for (hipEvent_t e : b->slot_ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -179,20 +190,24 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
                 return fail(CSDR_EINVAL, "n_per_channel (%d) must be a multiple of 2^%d for channel %d "
                             "(reference: InLength must be a multiple of 2^stages, downconvert.cpp:181-183)",
                             n_per_channel, b->plans[pi].nstages, i);
-    // NCO state of every channel at the start of this call
-    std::vector<DcChan> hc(b->channels);
+    // NCO state of every channel at the start of this call, in the next pinned slot (wait only if the copy
+    // that last used this slot, kSlots calls ago, has not been consumed yet)
+    const int slot = b->slot;
+    b->slot = (b->slot + 1) % csdr_downconvert_batch::kSlots;
+    if (b->slot_used[slot]) CSDR_HIP(hipEventSynchronize(b->slot_ev[slot]));
+    DcChan *hc = reinterpret_cast<DcChan *>(b->h_pin + (size_t)slot * b->slot_bytes);
+    int *all_lists = reinterpret_cast<int *>(hc + b->channels);
     for (int i = 0; i < b->channels; i++) { hc[i].phase = b->ch[i].phase; hc[i].inc = b->ch[i].inc; hc[i].age = b->ch[i].age; }
-    CSDR_HIP(hipMemcpyAsync(b->d_chan, hc.data(), sizeof(DcChan) * b->channels, hipMemcpyHostToDevice, s));
+    CSDR_HIP(hipMemcpyAsync(b->d_chan, hc, sizeof(DcChan) * b->channels, hipMemcpyHostToDevice, s));
     const size_t half = (size_t)b->channels * b->hist_stride * 2;
     std::vector<int> list;
     size_t list_off = 0;
-    std::vector<int> all_lists(b->channels);
     std::vector<DcArgs> launches;
     for (size_t pi = 0; pi < b->plans.size(); pi++) {
         list.clear();
         for (int i = 0; i < b->channels; i++) if (b->plan_of[i] == (int)pi) list.push_back(i);
         if (list.empty()) continue;
-        memcpy(all_lists.data() + list_off, list.data(), list.size() * sizeof(int));
+        memcpy(all_lists + list_off, list.data(), list.size() * sizeof(int));
         const DcPlan &p = b->plans[pi];
         DcArgs a;
         memset(&a, 0, sizeof(a));
@@ -217,13 +232,15 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         list_off += list.size();
         launches.push_back(a);
     }
-    CSDR_HIP(hipMemcpyAsync(b->d_list, all_lists.data(), sizeof(int) * b->channels, hipMemcpyHostToDevice, s));
+    CSDR_HIP(hipMemcpyAsync(b->d_list, all_lists, sizeof(int) * b->channels, hipMemcpyHostToDevice, s));
+    CSDR_HIP(hipEventRecord(b->slot_ev[slot], s));
+    b->slot_used[slot] = true;
     // a call shorter than a channel's warm-up keeps part of the old history: every row of the
     // next history half is fully rewritten by the kernel (tail copy + new samples)
     for (auto &la : launches) CSDR_HIP(downconv_launch(la, s));
     b->hist_cur ^= 1;
     for (int i = 0; i < b->channels; i++) {
-        b->ch[i].phase += b->ch[i].inc * (unsigned long long)n_per_channel;
+        b->ch[i].phase += hc[i].inc * (unsigned long long)n_per_channel;   // the increment the kernel was given
         b->ch[i].age += (unsigned long long)n_per_channel;
     }
     return CSDR_OK;

@@ -3,6 +3,9 @@
 #define AGCX_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#ifdef CSDR_DROPIN_QT
+#include <QMutex>
+#endif
 
 #define MAX_DELAY_BUF 2048
 

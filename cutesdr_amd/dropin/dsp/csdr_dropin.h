@@ -7,6 +7,13 @@
 #include <mutex>
 #include "cutesdr_mi.h"
 
+// The reference headers include <QMutex> where the class owns one (agc.h:14, downconvert.h:15, fastfir.h:17,
+// fft.h:19, fir.h:17, noiseproc.h:14) and host code may rely on that; CSDR_DROPIN_QT is set by datatypes.h
+// when Qt is on the include path.  The lock itself is a std::mutex either way (non-recursive, like QMutex):
+// every drop-in method that reaches the C ABI holds its object's lock, so a setter on the GUI thread and
+// ProcessData on the IQ thread never run inside one handle at the same time.
+#define CSDR_LOCK() std::lock_guard<std::mutex> csdr_guard_(m_Mutex)
+
 #ifndef CSDR_DEVICE
 #define CSDR_DEVICE csdr_dropin_device()
 #endif

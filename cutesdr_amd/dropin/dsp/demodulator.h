@@ -3,9 +3,18 @@
 // csdr_demod_* of libcutesdr_mi.
 #ifndef DEMODULATOR_H
 #define DEMODULATOR_H
-#include "dsp/datatypes.h"
+// the same headers the reference header re-exports (dsp/demodulator.h:11-18): host code includes only this one
+// and still names CIir, CFir, CAgc ... (interface/sdrinterface.h:15,178)
+#include "dsp/downconvert.h"
+#include "dsp/fastfir.h"
+#include "smeter.h"
+#include "dsp/agc.h"
+#include "dsp/amdemod.h"
+#include "dsp/samdemod.h"
+#include "dsp/fmdemod.h"
+#include "dsp/ssbdemod.h"
 #include "dsp/csdr_dropin.h"
-#if defined(QT_CORE_LIB) || defined(QT_VERSION)
+#ifdef CSDR_DROPIN_QT
 #include <QString>
 typedef QString csdr_label_t;
 #else
@@ -55,9 +64,9 @@ public:
 
     void SetInputSampleRate(TYPEREAL InputRate)
     { std::lock_guard<std::mutex> g(m_Mutex); csdr_dropin_count(csdr_demod_set_input_rate(m_h, InputRate), "CDemodulator::SetInputSampleRate"); }
-    double GetOutputRate() { return csdr_demod_get_output_rate(m_h); }
-    double GetSMeterPeak() { return csdr_demod_get_smeter_peak(m_h); }
-    double GetSMeterAve() { return csdr_demod_get_smeter_ave(m_h); }
+    double GetOutputRate() { CSDR_LOCK(); return csdr_demod_get_output_rate(m_h); }
+    double GetSMeterPeak() { CSDR_LOCK(); return csdr_demod_get_smeter_peak(m_h); }
+    double GetSMeterAve() { CSDR_LOCK(); return csdr_demod_get_smeter_ave(m_h); }
     void SetDemod(int Mode, tDemodInfo CurrentDemodInfo)
     {
         std::lock_guard<std::mutex> g(m_Mutex);
@@ -71,7 +80,7 @@ public:
         i.Symetric = CurrentDemodInfo.Symetric;
         csdr_dropin_count(csdr_demod_set_demod(m_h, Mode, &i), "CDemodulator::SetDemod");
     }
-    void SetDemodFreq(TYPEREAL Freq) { csdr_dropin_count(csdr_demod_set_freq(m_h, Freq), "CDemodulator::SetDemodFreq"); }
+    void SetDemodFreq(TYPEREAL Freq) { CSDR_LOCK(); csdr_dropin_count(csdr_demod_set_freq(m_h, Freq), "CDemodulator::SetDemodFreq"); }
     int ProcessData(int InLength, TYPECPX *pInData, TYPEREAL *pOutData)
     { std::lock_guard<std::mutex> g(m_Mutex); return csdr_dropin_count(csdr_demod_process_mono(m_h, InLength, &pInData->re, pOutData), "CDemodulator::ProcessData"); }
     int ProcessData(int InLength, TYPECPX *pInData, TYPECPX *pOutData)

@@ -3,6 +3,9 @@
 #define DOWNCONVERT_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#ifdef CSDR_DROPIN_QT
+#include <QMutex>
+#endif
 
 #define MAX_DECSTAGES 10
 
@@ -14,8 +17,8 @@ public:
     CDownConvert(const CDownConvert &) = delete;
     CDownConvert &operator=(const CDownConvert &) = delete;
 
-    void SetFrequency(TYPEREAL NcoFreq) { csdr_dropin_count(csdr_downconvert_set_frequency(m_h, NcoFreq), "CDownConvert::SetFrequency"); }
-    void SetCwOffset(TYPEREAL offset) { csdr_dropin_count(csdr_downconvert_set_cw_offset(m_h, offset), "CDownConvert::SetCwOffset"); }
+    void SetFrequency(TYPEREAL NcoFreq) { CSDR_LOCK(); csdr_dropin_count(csdr_downconvert_set_frequency(m_h, NcoFreq), "CDownConvert::SetFrequency"); }
+    void SetCwOffset(TYPEREAL offset) { CSDR_LOCK(); csdr_dropin_count(csdr_downconvert_set_cw_offset(m_h, offset), "CDownConvert::SetCwOffset"); }
     int ProcessData(int InLength, TYPECPX *pInData, TYPECPX *pOutData)
     {
         std::lock_guard<std::mutex> g(m_Mutex);

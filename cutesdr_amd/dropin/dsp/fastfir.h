@@ -4,6 +4,10 @@
 #define FASTFIR_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#include "dsp/fft.h"        // as the reference header does (dsp/fastfir.h:16)
+#ifdef CSDR_DROPIN_QT
+#include <QMutex>
+#endif
 
 class CFastFIR
 {

@@ -3,6 +3,9 @@
 #define FFT_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#ifdef CSDR_DROPIN_QT
+#include <QMutex>
+#endif
 
 #define MAX_FFT_SIZE 65536
 #define MIN_FFT_SIZE 512
@@ -34,8 +37,8 @@ public:
         std::lock_guard<std::mutex> g(m_Mutex);
         return csdr_dropin_count(csdr_fft_put_display(m_h, n, &InBuf->re), "CFft::PutInDisplayFFT");
     }
-    void FwdFFT(TYPECPX *pInOutBuf) { csdr_dropin_count(csdr_fft_fwd(m_h, &pInOutBuf->re), "CFft::FwdFFT"); }
-    void RevFFT(TYPECPX *pInOutBuf) { csdr_dropin_count(csdr_fft_rev(m_h, &pInOutBuf->re), "CFft::RevFFT"); }
+    void FwdFFT(TYPECPX *pInOutBuf) { CSDR_LOCK(); csdr_dropin_count(csdr_fft_fwd(m_h, &pInOutBuf->re), "CFft::FwdFFT"); }
+    void RevFFT(TYPECPX *pInOutBuf) { CSDR_LOCK(); csdr_dropin_count(csdr_fft_rev(m_h, &pInOutBuf->re), "CFft::RevFFT"); }
 
 private:
     csdr_fft *m_h;

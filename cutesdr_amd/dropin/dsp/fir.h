@@ -3,6 +3,9 @@
 #define FIR_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#ifdef CSDR_DROPIN_QT
+#include <QMutex>
+#endif
 
 #define MAX_NUMCOEF 75
 
@@ -19,7 +22,7 @@ public:
     { std::lock_guard<std::mutex> g(m_Mutex); return csdr_dropin_count(csdr_fir_init_lp(m_h, Scale, Astop, Fpass, Fstop, Fsamprate), "CFir::InitLPFilter"); }
     int InitHPFilter(TYPEREAL Scale, TYPEREAL Astop, TYPEREAL Fpass, TYPEREAL Fstop, TYPEREAL Fsamprate)
     { std::lock_guard<std::mutex> g(m_Mutex); return csdr_dropin_count(csdr_fir_init_hp(m_h, Scale, Astop, Fpass, Fstop, Fsamprate), "CFir::InitHPFilter"); }
-    void GenerateHBFilter(TYPEREAL FreqOffset) { csdr_dropin_count(csdr_fir_generate_hb(m_h, FreqOffset), "CFir::GenerateHBFilter"); }
+    void GenerateHBFilter(TYPEREAL FreqOffset) { CSDR_LOCK(); csdr_dropin_count(csdr_fir_generate_hb(m_h, FreqOffset), "CFir::GenerateHBFilter"); }
     void ProcessFilter(int InLength, TYPEREAL *InBuf, TYPEREAL *OutBuf)
     { std::lock_guard<std::mutex> g(m_Mutex); csdr_dropin_count(csdr_fir_process_real(m_h, InLength, InBuf, OutBuf), "CFir::ProcessFilter"); }
     void ProcessFilter(int InLength, TYPECPX *InBuf, TYPECPX *OutBuf)

@@ -3,6 +3,8 @@
 #define FMDEMOD_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#include "dsp/fir.h"        // as the reference header does (dsp/fmdemod.h:11-12)
+#include "dsp/iir.h"
 
 #define MAX_SQBUF_SIZE 16384
 
@@ -13,10 +15,11 @@ public:
     ~CFmDemod() { csdr_fmdemod_destroy(m_h); }
     CFmDemod(const CFmDemod &) = delete;
     CFmDemod &operator=(const CFmDemod &) = delete;
-    int ProcessData(int InLength, TYPEREAL FmBW, TYPECPX *pInData, TYPECPX *pOutData) { return csdr_dropin_count(csdr_fmdemod_process_stereo(m_h, InLength, FmBW, &pInData->re, &pOutData->re), "CFmDemod::ProcessData"); }
-    int ProcessData(int InLength, TYPEREAL FmBW, TYPECPX *pInData, TYPEREAL *pOutData) { return csdr_dropin_count(csdr_fmdemod_process_mono(m_h, InLength, FmBW, &pInData->re, pOutData), "CFmDemod::ProcessData"); }
-    void SetSquelch(int Value) { csdr_dropin_count(csdr_fmdemod_set_squelch(m_h, Value), "CFmDemod::SetSquelch"); }
+    int ProcessData(int InLength, TYPEREAL FmBW, TYPECPX *pInData, TYPECPX *pOutData) { CSDR_LOCK(); return csdr_dropin_count(csdr_fmdemod_process_stereo(m_h, InLength, FmBW, &pInData->re, &pOutData->re), "CFmDemod::ProcessData"); }
+    int ProcessData(int InLength, TYPEREAL FmBW, TYPECPX *pInData, TYPEREAL *pOutData) { CSDR_LOCK(); return csdr_dropin_count(csdr_fmdemod_process_mono(m_h, InLength, FmBW, &pInData->re, pOutData), "CFmDemod::ProcessData"); }
+    void SetSquelch(int Value) { CSDR_LOCK(); csdr_dropin_count(csdr_fmdemod_set_squelch(m_h, Value), "CFmDemod::SetSquelch"); }
 private:
     csdr_fmdemod *m_h;
+    std::mutex m_Mutex;
 };
 #endif  // FMDEMOD_H

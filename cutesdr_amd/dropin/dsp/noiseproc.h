@@ -3,6 +3,9 @@
 #define NOISEPROC_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#ifdef CSDR_DROPIN_QT
+#include <QMutex>
+#endif
 
 typedef struct _snproc
 {
@@ -19,10 +22,11 @@ public:
     CNoiseProc(const CNoiseProc &) = delete;
     CNoiseProc &operator=(const CNoiseProc &) = delete;
     void SetupBlanker(bool On, TYPEREAL Threshold, TYPEREAL Width, TYPEREAL SampleRate)
-    { csdr_dropin_count(csdr_noiseproc_setup(m_h, On, Threshold, Width, SampleRate), "CNoiseProc::SetupBlanker"); }
+    { CSDR_LOCK(); csdr_dropin_count(csdr_noiseproc_setup(m_h, On, Threshold, Width, SampleRate), "CNoiseProc::SetupBlanker"); }
     void ProcessBlanker(int InLength, TYPECPX *pInData, TYPECPX *pOutData)
-    { csdr_dropin_count(csdr_noiseproc_process(m_h, InLength, &pInData->re, &pOutData->re), "CNoiseProc::ProcessBlanker"); }
+    { CSDR_LOCK(); csdr_dropin_count(csdr_noiseproc_process(m_h, InLength, &pInData->re, &pOutData->re), "CNoiseProc::ProcessBlanker"); }
 private:
     csdr_noiseproc *m_h;
+    std::mutex m_Mutex;       // the reference locks m_Mutex in SetupBlanker and ProcessBlanker (noiseproc.cpp:80,123)
 };
 #endif  // NOISEPROC_H

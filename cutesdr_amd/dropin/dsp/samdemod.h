@@ -3,6 +3,7 @@
 #define SAMDEMOD_H
 #include "dsp/datatypes.h"
 #include "dsp/csdr_dropin.h"
+#include "dsp/fir.h"        // as the reference header does (dsp/samdemod.h:11)
 
 class CSamDemod
 {
@@ -11,9 +12,10 @@ public:
     ~CSamDemod() { csdr_samdemod_destroy(m_h); }
     CSamDemod(const CSamDemod &) = delete;
     CSamDemod &operator=(const CSamDemod &) = delete;
-    int ProcessData(int InLength, TYPECPX *pInData, TYPEREAL *pOutData) { return csdr_dropin_count(csdr_samdemod_process_mono(m_h, InLength, &pInData->re, pOutData), "CSamDemod::ProcessData"); }
-    int ProcessData(int InLength, TYPECPX *pInData, TYPECPX *pOutData) { return csdr_dropin_count(csdr_samdemod_process_stereo(m_h, InLength, &pInData->re, &pOutData->re), "CSamDemod::ProcessData"); }
+    int ProcessData(int InLength, TYPECPX *pInData, TYPEREAL *pOutData) { CSDR_LOCK(); return csdr_dropin_count(csdr_samdemod_process_mono(m_h, InLength, &pInData->re, pOutData), "CSamDemod::ProcessData"); }
+    int ProcessData(int InLength, TYPECPX *pInData, TYPECPX *pOutData) { CSDR_LOCK(); return csdr_dropin_count(csdr_samdemod_process_stereo(m_h, InLength, &pInData->re, &pOutData->re), "CSamDemod::ProcessData"); }
 private:
     csdr_samdemod *m_h;
+    std::mutex m_Mutex;
 };
 #endif  // SAMDEMOD_H

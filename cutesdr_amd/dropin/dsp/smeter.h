@@ -12,10 +12,11 @@ public:
     CSMeter(const CSMeter &) = delete;
     CSMeter &operator=(const CSMeter &) = delete;
     void ProcessData(int length, TYPECPX *pInData, TYPEREAL SampleRate)
-    { csdr_dropin_count(csdr_smeter_process(m_h, length, &pInData->re, SampleRate), "CSMeter::ProcessData"); }
-    TYPEREAL GetPeak() { return csdr_smeter_get_peak(m_h); }
-    TYPEREAL GetAve() { return csdr_smeter_get_ave(m_h); }
+    { CSDR_LOCK(); csdr_dropin_count(csdr_smeter_process(m_h, length, &pInData->re, SampleRate), "CSMeter::ProcessData"); }
+    TYPEREAL GetPeak() { CSDR_LOCK(); return csdr_smeter_get_peak(m_h); }
+    TYPEREAL GetAve() { CSDR_LOCK(); return csdr_smeter_get_ave(m_h); }
 private:
     csdr_smeter *m_h;
+    std::mutex m_Mutex;
 };
 #endif  // SMETER_H

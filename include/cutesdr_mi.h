@@ -18,9 +18,13 @@
  *  - the library never falls back to a CPU path: without a usable GPU every create() fails;
  *  - batch process calls only enqueue work on `stream` (NULL = the default stream) and return; the
  *    caller synchronises.  Setters, getters and the host entry points synchronise the device;
- *  - a handle is not locked internally: one thread at a time per handle (the drop-in C++ classes
- *    hold the per-object lock the reference's QMutex members provide); different handles are
- *    independent.
+ *  - threading: a handle is not locked internally -- ONE thread at a time per handle, setters and getters
+ *    included.  A setter uploads parameters or state with device copies and a getter may read and reset
+ *    device state (csdr_*_get_smeter_peak); issued while a process call of the same handle is running on
+ *    another thread they would race with it.  The drop-in C++ classes (cutesdr_amd/dropin/dsp/) provide the
+ *    guarantee the reference's QMutex members give its host: every method that reaches this ABI holds the
+ *    object's lock, so GUI-thread setters and the IQ thread's ProcessData serialise per object.  Different
+ *    handles are independent and may be used from different threads at the same time.
  */
 #ifndef CUTESDR_MI_H
 #define CUTESDR_MI_H

@@ -29,6 +29,51 @@ def test_dropin_headers_compile_and_link_with_gpp():
     assert os.path.exists(build_exe())
 
 
+def test_host_translation_unit_compiles_with_only_the_headers_the_host_includes(tmp_path):
+    """interface/sdrinterface.h includes dsp/fft.h, dsp/demodulator.h and dsp/noiseproc.h only and declares
+    CFft, CDemodulator, CNoiseProc and CIir members: the drop-in headers must re-export what the reference's
+    do (dsp/demodulator.h:11-18, dsp/fmdemod.h:10-12)."""
+    src = os.path.join(ROOT, "tests", "cpp", "host_includes.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-Wno-unused-variable", "-c",
+                           "-I", os.path.join(ROOT, "cutesdr_amd", "dropin"), "-I", os.path.join(ROOT, "include"),
+                           src, "-o", str(tmp_path / "host_includes.o")])
+
+
+def test_every_dropin_header_compiles_on_its_own(tmp_path):
+    d = os.path.join(ROOT, "cutesdr_amd", "dropin", "dsp")
+    for h in sorted(os.listdir(d)):
+        tu = tmp_path / ("tu_" + h.replace(".", "_") + ".cpp")
+        tu.write_text('#include "dsp/%s"\nint f_%s() { return 0; }\n' % (h, h.replace(".", "_")))
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-c", "-I", os.path.join(ROOT, "cutesdr_amd", "dropin"),
+                               "-I", os.path.join(ROOT, "include"), str(tu), "-o", str(tu) + ".o"])
+
+
+def test_every_dropin_method_that_reaches_the_c_abi_holds_the_object_lock():
+    """The reference serialises GUI-thread setters against the IQ thread's ProcessData with per-object
+    QMutexes; handles of the C ABI are not locked internally, so each drop-in method must lock."""
+    import re
+    d = os.path.join(ROOT, "cutesdr_amd", "dropin", "dsp")
+    bad = []
+    for h in sorted(os.listdir(d)):
+        if h in ("csdr_dropin.h", "datatypes.h", "ssbdemod.h"):      # CSsbDemod is stateless: no handle
+            continue
+        txt = open(os.path.join(d, h)).read()
+        body = txt[txt.index("class "):]
+        # member functions: "name(args) {" or "name(args)\n    {" ... up to the matching brace
+        for m in re.finditer(r"\n    [^\n(]*?\b(\w+)\(([^)]*)\)\s*(?::[^{]*)?\{", body):
+            name = m.group(1)
+            i, depth = m.end(), 1
+            while depth:
+                depth += {"{": 1, "}": -1}.get(body[i], 0)
+                i += 1
+            code = body[m.end():i]
+            if name.startswith("C") or name.startswith("~C") or name == "operator":
+                continue                                              # constructors / destructor
+            if "csdr_" in code and "CSDR_LOCK()" not in code and "lock_guard" not in code:
+                bad.append("%s::%s" % (h, name))
+    assert not bad, bad
+
+
 def test_dropin_degrades_to_zero_samples_without_gpu(tmp_path):
     from cutesdr_amd import _capi
     if _capi.lib().csdr_device_count() > 0:
