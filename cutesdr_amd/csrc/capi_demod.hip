@@ -506,8 +506,8 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
  * Chunking: one call = one pass of the chain over n_per_channel samples (the host form uses
  * m_InBufLimit-sized passes; the decimator and filter are chunking independent, the squelch
  * decision is taken once per FastFIR hop either way).  Asynchronous. */
-int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
-                             float *d_out, long long out_stride, void *stream)
+static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                           float *d_out, long long out_stride, void *stream, bool stereo)
 {
     if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad argument");
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
@@ -521,7 +521,7 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
         hipStream_t st = forked ? b->streams[ki] : caller;
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
         const int rc = b->cores[ki]->step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride,
-                                          b->d_rows[ki], false, st,
+                                          b->d_rows[ki], stereo, st,
                                           forked && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr,
                                           forked ? b->dc_done[ki] : nullptr);
         if (rc < 0 && !err) err = rc;
@@ -532,6 +532,14 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
     }
     return err ? err : CSDR_OK;
 }
+int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                             float *d_out, long long out_stride, void *stream)
+{ return demod_batch_run(b, d_in, in_stride, n_per_channel, d_out, out_stride, stream, false); }
+/* the stereo overload of CDemodulator::ProcessData (demodulator.cpp:221-273) for every channel:
+ * d_out_iq [channels][out_stride] complex fp32 (out_stride in complex samples) */
+int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                                    float *d_out_iq, long long out_stride, void *stream)
+{ return demod_batch_run(b, d_in, in_stride, n_per_channel, d_out_iq, out_stride, stream, true); }
 int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets, int npackets, int pkt_len,
                                      struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride,
                                      void *stream)

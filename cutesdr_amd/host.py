@@ -623,15 +623,19 @@ class DemodBatch(_Obj):
         flat = dout.download(np.float32, self.channels * cap).reshape(self.channels, cap)
         return [flat[c, :check(lib().csdr_demod_batch_out_count(self.h, c))].copy() for c in range(self.channels)]
 
-    def process(self, x):
+    def process(self, x, stereo=False):
+        """x complex [channels, T] -> list of audio rows (float32 mono, or complex64 with stereo=True)"""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         T = x.shape[1]
+        cap = T + self.n
+        w = 8 if stereo else 4
         din = DeviceBuffer(x.nbytes, self.device)
-        dout = DeviceBuffer(4 * self.channels * (T + self.n), self.device)
+        dout = DeviceBuffer(w * self.channels * cap, self.device)
         din.upload(x)
-        self.process_ptr(din.ptr, T, T, dout.ptr, T + self.n)
+        fn = lib().csdr_demod_batch_process_stereo if stereo else lib().csdr_demod_batch_process
+        check(fn(self.h, C.c_void_p(din.ptr), T, T, C.c_void_p(dout.ptr), cap, None), "csdr_demod_batch_process")
         sync(self.device)
-        y = dout.download(np.float32, self.channels * (T + self.n)).reshape(self.channels, T + self.n)
+        y = dout.download(np.complex64 if stereo else np.float32, self.channels * cap).reshape(self.channels, cap)
         din.free(); dout.free()
         return [y[c, :self.out_count(c)].copy() for c in range(self.channels)]
 

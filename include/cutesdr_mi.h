@@ -258,6 +258,11 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
 /* d_in [channels][in_stride] complex fp32 -> d_out [channels][out_stride] fp32 mono audio */
 int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
                              int n_per_channel, float *d_out, long long out_stride, void *stream);
+/* the stereo overload (dsp/demodulator.cpp:221-273: AM/FM duplicate the audio into both halves, SAM splits the
+ * sidebands, SSB/CW copy the filtered I/Q) for every channel: d_out_iq [channels][out_stride] complex fp32,
+ * out_stride in complex samples */
+int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long long in_stride,
+                                    int n_per_channel, float *d_out_iq, long long out_stride, void *stream);
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
 /* The same pass fed with the datagrams as they arrived (interface/netiobase.cpp:479-527):
  * d_packets [channels][npackets][pkt_len] bytes on the device, pkt_len 1028 (16 bit) or 1444 (24 bit).
