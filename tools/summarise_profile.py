@@ -28,14 +28,26 @@ bench = None
 for line in open(os.path.join(out, "bench_trace.log")):
     if line.startswith("{"):
         bench = json.loads(line)
-doc = {"tag": tag, "command": "python3 bench.py --no-cpu (kernel-trace run); --steps 5 --warmup 1 for the PMC passes",
+sys.path.insert(0, root)
+import bench as benchmod
+doc = {"tag": tag, "command": "python3 bench.py --no-cpu --no-check --no-secondary (kernel-trace run); the same with --steps 5 --warmup 1 for every PMC pass",
+       "k1_source_sha16": benchmod.k1_source_hash(),
        "bench_line_under_profiler": bench, "pmc_mean_per_launch": summary,
        "notes": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced "
                 "stream's bytes (MI355X_MICROARCH.md, HBM) so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024."}
 for k, cs in summary.items():
-    if "fastfir_os_kernel<14, false>" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+    if "fastfir_os2_kernel<14>" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         hbm = (2 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024
         doc["hbm_bytes_per_launch"] = hbm
-        json.dump({"hbm_bytes_per_launch": hbm, "source": tag}, open(os.path.join(prof, "traffic_latest.json"), "w"))
+        doc["hbm_bytes_over_algorithmic"] = hbm / (16.0 * 256 * (1 << 19))
+        json.dump({"hbm_bytes_per_launch": hbm, "source": tag, "k1_source_sha16": benchmod.k1_source_hash(),
+                   "kernel": k}, open(os.path.join(prof, "traffic_latest.json"), "w"))
+        if "GRBM_GUI_ACTIVE" in cs:
+            doc["grbm_gui_active_per_launch_sum_over_8_xcds"] = cs["GRBM_GUI_ACTIVE"]["mean"]
+    if "fastfir_os2_kernel<14>" in k and "SQ_WAVE_CYCLES" in cs:
+        wc = cs["SQ_WAVE_CYCLES"]["mean"]
+        doc["sq_shares_of_wave_cycles"] = {c: round(cs[c]["mean"] / wc, 4) for c in cs if c.startswith("SQ_") and c != "SQ_WAVE_CYCLES" and c != "SQ_WAVES"}
+        if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_ACTIVE_INST_LDS" in cs:
+            doc["lds_bank_conflict_over_lds_active"] = round(cs["SQ_LDS_BANK_CONFLICT"]["mean"] / cs["SQ_ACTIVE_INST_LDS"]["mean"], 4)
 json.dump(doc, open(os.path.join(prof, tag + "_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in doc.items() if k != "pmc_mean_per_launch"})[:600])
