@@ -396,6 +396,8 @@ class C4Workload:
         b.commit()
         for c in range(C):
             b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)))
+        if not os.environ.get("CSDR_BENCH_STRICT_CHAIN"):
+            b.set_pipelined(True)        # streaming host: the post-chain of step k overlaps the down-converter of step k+1
         self.b = b
         self.cap = T // 16 + 4096                                  # audio row capacity (highest output rate: /32)
         self.aud = torch.zeros((C, self.cap), device=dev, dtype=torch.float32)

@@ -18,12 +18,14 @@ extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, c
 
 namespace {
 
-// move the not-yet-filtered tail of every row to the front of the staging buffer
-__global__ void shift_rows_kernel(float *buf, long stride, int src_off, int count)
+// move the not-yet-filtered tail of every row to the front of the staging buffer (dst == src) or of the other
+// staging buffer (pipelined mode)
+__global__ void shift_rows_kernel(float *dst, const float *src, long stride, int src_off, int count)
 {
-    float2 *row = reinterpret_cast<float2 *>(buf) + (long)blockIdx.x * stride;
+    float2 *drow = reinterpret_cast<float2 *>(dst) + (long)blockIdx.x * stride;
+    const float2 *srow = reinterpret_cast<const float2 *>(src) + (long)blockIdx.x * stride;
     // src_off >= count whenever at least one hop was consumed, so the ranges do not overlap
-    for (int i = threadIdx.x; i < count; i += blockDim.x) row[i] = row[src_off + i];
+    for (int i = threadIdx.x; i < count; i += blockDim.x) drow[i] = srow[src_off + i];
 }
 
 // `rows` channels that share one decimator plan: staging, pending counts, the three stage objects
@@ -33,7 +35,19 @@ struct ChainCore {
     csdr_fastfir_batch *ff = nullptr;
     PcUnit pc;
     float *d_stage = nullptr, *d_filt = nullptr, *d_agc = nullptr;
-    long cap = 0;
+    // Pipelined mode (csdr_demod_batch_set_pipelined): three stages on three streams -- down-converter on the
+    // group's stream, filter (+ staging shift) on s_fir, post-chain on s_post -- with the staging and the filter
+    // output ping-ponging between two buffers each, so that stage i of call k+1 never waits for stage i+1 of
+    // call k: the down-converters of successive calls run back to back.
+    float *d_stage2 = nullptr, *d_filt2 = nullptr;
+    long cap = 0;                                        // capacity of every staging row (complex samples)
+    hipStream_t s_fir = nullptr, s_post = nullptr;
+    hipEvent_t ev_dc = nullptr;                          // down-converter of the current call done
+    hipEvent_t ev_stage_free[2] = {nullptr, nullptr};    // filter + shift have finished with staging buffer i
+    hipEvent_t ev_fir[2] = {nullptr, nullptr};           // filter output buffer i written
+    hipEvent_t ev_post[2] = {nullptr, nullptr};          // post-chain has finished with filter output buffer i
+    bool stage_busy[2] = {false, false}, post_pending[2] = {false, false};
+    int stage_cur = 0, filt_cur = 0, last_post = -1;
     // long calls run S-meter | AGC | demodulator as a pipeline of launches over burst groups
     hipStream_t s_dem = nullptr, s_sm = nullptr;
     hipEvent_t ev_fork = nullptr, ev_dem = nullptr, ev_sm = nullptr, ev_agc[8] = {};                       // staging capacity per row (complex samples)
@@ -47,6 +61,14 @@ struct ChainCore {
         if (d_stage) (void)hipFree(d_stage);
         if (d_filt) (void)hipFree(d_filt);
         if (d_agc) (void)hipFree(d_agc);
+        if (d_filt2) (void)hipFree(d_filt2);
+        if (d_stage2) (void)hipFree(d_stage2);
+        if (s_post) (void)hipStreamDestroy(s_post);
+        if (s_fir) (void)hipStreamDestroy(s_fir);
+        if (ev_dc) (void)hipEventDestroy(ev_dc);
+        for (hipEvent_t e : ev_stage_free) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_fir) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_post) if (e) (void)hipEventDestroy(e);
         if (s_dem) (void)hipStreamDestroy(s_dem);
         if (s_sm) (void)hipStreamDestroy(s_sm);
         for (hipEvent_t e : {ev_fork, ev_dem, ev_sm}) if (e) (void)hipEventDestroy(e);
@@ -96,6 +118,25 @@ struct ChainCore {
         CSDR_HIP(hipStreamWaitEvent(s, ev_sm, 0));
         return CSDR_OK;
     }
+    int pipelined_init()
+    {
+        if (s_post) return CSDR_OK;
+        CSDR_HIP(hipDeviceSynchronize());
+        int pr_lo = 0, pr_hi = 0;                        // the post-chain is the long pole of a call: highest priority
+        CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        CSDR_HIP(hipStreamCreateWithPriority(&s_post, hipStreamNonBlocking, pr_hi));
+        CSDR_HIP(hipStreamCreateWithPriority(&s_fir, hipStreamNonBlocking, pr_hi));
+        CSDR_HIP(hipEventCreateWithFlags(&ev_dc, hipEventDisableTiming));
+        for (auto &e : ev_stage_free) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : ev_fir) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : ev_post) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (cap > 0) {
+            if (!d_filt2) CSDR_HIP(hipMalloc((void **)&d_filt2, (size_t)rows * cap * 8));
+            if (!d_stage2) CSDR_HIP(hipMalloc((void **)&d_stage2, (size_t)rows * cap * 8));
+        }
+        stage_cur = 0;                                   // the pending samples sit in d_stage
+        return CSDR_OK;
+    }
     int init(int dev, int nrows, int n)
     {
         device = dev; rows = nrows; fft_n = n; L = n / 2;
@@ -110,17 +151,22 @@ struct ChainCore {
         need = (need + L + 1023) / 1024 * 1024;
         // growing the staging (rare): the pending samples may still be in flight on a non-blocking stream
         CSDR_HIP(hipDeviceSynchronize());
-        float *ns = nullptr, *nf = nullptr, *na = nullptr;
+        float *ns = nullptr, *nf = nullptr, *na = nullptr, *nf2 = nullptr, *ns2 = nullptr;
         CSDR_HIP(hipMalloc((void **)&ns, (size_t)rows * need * 8));
         CSDR_HIP(hipMalloc((void **)&nf, (size_t)rows * need * 8));
         CSDR_HIP(hipMalloc((void **)&na, (size_t)rows * need * 8));
-        if (d_stage && pending > 0)
-            CSDR_HIP(hipMemcpy2D(ns, (size_t)need * 8, d_stage, (size_t)cap * 8, (size_t)pending * 8, rows,
+        if (s_post) {
+            CSDR_HIP(hipMalloc((void **)&nf2, (size_t)rows * need * 8));
+            CSDR_HIP(hipMalloc((void **)&ns2, (size_t)rows * need * 8));
+        }
+        const float *cur = stage_cur ? d_stage2 : d_stage;     // where the pending samples sit
+        if (cur && pending > 0)
+            CSDR_HIP(hipMemcpy2D(ns, (size_t)need * 8, cur, (size_t)cap * 8, (size_t)pending * 8, rows,
                                  hipMemcpyDeviceToDevice));
-        if (d_stage) (void)hipFree(d_stage);
-        if (d_filt) (void)hipFree(d_filt);
-        if (d_agc) (void)hipFree(d_agc);
-        d_stage = ns; d_filt = nf; d_agc = na; cap = need;
+        for (float *p : {d_stage, d_filt, d_agc, d_filt2, d_stage2}) if (p) (void)hipFree(p);
+        d_stage = ns; d_filt = nf; d_agc = na; d_filt2 = nf2; d_stage2 = ns2; cap = need;
+        stage_cur = 0;
+        stage_busy[0] = stage_busy[1] = post_pending[0] = post_pending[1] = false;
         return CSDR_OK;
     }
     // one pass of the chain over n input samples per row (demodulator.cpp:172-207); returns the
@@ -128,6 +174,7 @@ struct ChainCore {
     int step(const float *d_in, long in_stride, const int *d_in_rows, int n, float *d_out, long out_stride,
              const int *d_out_rows, bool stereo, hipStream_t s, hipEvent_t dc_after = nullptr, hipEvent_t dc_done = nullptr)
     {
+        if (s_post) return fail(CSDR_ESTATE, "pipelined objects take step_pipelined()");
         const int m = csdr_downconvert_batch_out_count(dc, 0, n);
         if (m < 0) return m;
         int rc = ensure((long)pending + m);
@@ -141,14 +188,17 @@ struct ChainCore {
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
         const int total = pending + m, nb = total / L;
         last_out = 0;
+        last_post = -1;
         if (nb > 0) {
             rc = csdr_fastfir_batch_process(ff, d_stage, cap, nb * L, d_filt, cap, s, 0);
             if (rc) return rc;
             rc = post(d_filt, d_out, out_stride, d_out_rows, stereo, nb, s);
             if (rc) return rc;
+        }
+        if (nb > 0) {
             const int rest = total - nb * L;
             if (rest > 0) {
-                hipLaunchKernelGGL(shift_rows_kernel, dim3(rows), dim3(256), 0, s, d_stage, cap, nb * L, rest);
+                hipLaunchKernelGGL(shift_rows_kernel, dim3(rows), dim3(256), 0, s, d_stage, d_stage, cap, nb * L, rest);
                 CSDR_HIP(hipGetLastError());
             }
             pending = rest;
@@ -156,6 +206,53 @@ struct ChainCore {
         } else {
             pending = total;
         }
+        return last_out;
+    }
+    // The same pass in pipelined mode: s = the group's stream (down-converter only).
+    int step_pipelined(const float *d_in, long in_stride, const int *d_in_rows, int n, float *d_out, long out_stride,
+                       const int *d_out_rows, bool stereo, hipStream_t s, hipEvent_t dc_after, hipEvent_t dc_done)
+    {
+        const int m = csdr_downconvert_batch_out_count(dc, 0, n);
+        if (m < 0) return m;
+        int rc = ensure((long)pending + m);
+        if (rc) return rc;
+        const int sc = stage_cur;
+        float *stage = sc ? d_stage2 : d_stage, *other = sc ? d_stage : d_stage2;
+        if (dc_after) CSDR_HIP(hipStreamWaitEvent(s, dc_after, 0));
+        // the filter + shift of the call that last used this staging buffer must have finished with it
+        if (stage_busy[sc]) { CSDR_HIP(hipStreamWaitEvent(s, ev_stage_free[sc], 0)); stage_busy[sc] = false; }
+        rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, stage + 2 * (size_t)pending, cap, s);
+        if (rc) return rc;
+        CSDR_HIP(hipEventRecord(ev_dc, s));
+        if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
+        const int total = pending + m, nb = total / L;
+        last_out = 0;
+        last_post = -1;
+        if (nb == 0) { pending = total; return 0; }      // not a hop yet: the next call appends to the same buffer
+        const int fc = filt_cur;
+        filt_cur ^= 1;
+        float *fb = fc ? d_filt2 : d_filt;
+        CSDR_HIP(hipStreamWaitEvent(s_fir, ev_dc, 0));
+        if (post_pending[fc]) CSDR_HIP(hipStreamWaitEvent(s_fir, ev_post[fc], 0));
+        rc = csdr_fastfir_batch_process(ff, stage, cap, nb * L, fb, cap, s_fir, 0);
+        if (rc) return rc;
+        CSDR_HIP(hipEventRecord(ev_fir[fc], s_fir));
+        const int rest = total - nb * L;
+        if (rest > 0) {                                   // the tail moves to the front of the OTHER staging buffer
+            hipLaunchKernelGGL(shift_rows_kernel, dim3(rows), dim3(256), 0, s_fir, other, stage, cap, nb * L, rest);
+            CSDR_HIP(hipGetLastError());
+        }
+        CSDR_HIP(hipEventRecord(ev_stage_free[sc], s_fir));
+        stage_busy[sc] = true;
+        stage_cur ^= 1;
+        pending = rest;
+        CSDR_HIP(hipStreamWaitEvent(s_post, ev_fir[fc], 0));
+        rc = post(fb, d_out, out_stride, d_out_rows, stereo, nb, s_post);
+        if (rc) return rc;
+        CSDR_HIP(hipEventRecord(ev_post[fc], s_post));
+        post_pending[fc] = true;
+        last_post = fc;
+        last_out = nb * L;
         return last_out;
     }
 };
@@ -253,6 +350,9 @@ struct csdr_demod_batch {
     std::vector<int> order;                           // cores, heaviest post-chain first
     std::vector<hipEvent_t> dc_done;                  // core -> its down-converter has been issued and finished
     hipEvent_t fork = nullptr;
+    bool pipelined = false;                           // csdr_demod_batch_set_pipelined
+    std::vector<int> prev_post;                       // pipelined: per core, the post-chain event of the previous call
+    std::vector<char> prev_join;                      // pipelined: per core, joins[] of the previous call not yet waited for
     float *d_raw = nullptr, *d_blank = nullptr;      // unpacked / blanked input of process_packets
     long raw_cap = 0;
     ~csdr_demod_batch()
@@ -472,6 +572,46 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
     }
     return CSDR_OK;
 }
+/* Pipelined mode.  on != 0: a process call only enqueues on internal streams; in the caller's stream order the
+ * INPUT buffer of call k has been consumed and the OUTPUT rows of call k-1 are complete after process call k+1
+ * (everything after csdr_demod_batch_flush).  Results are identical to the strict mode. */
+int csdr_demod_batch_set_pipelined(csdr_demod_batch *b, int on)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    if (on && b->streams.empty()) {                    // a single plan group normally runs on the caller's stream
+        CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+        b->streams.resize(b->cores.size());
+        for (size_t ki = 0; ki < b->cores.size(); ki++) {
+            CSDR_HIP(hipStreamCreateWithFlags(&b->streams[ki], hipStreamNonBlocking));
+            hipEvent_t ev;
+            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->joins.push_back(ev);
+            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->dc_done.push_back(ev);
+        }
+    }
+    if (on) for (auto *k : b->cores) { int rc = k->pipelined_init(); if (rc) return rc; }
+    b->prev_post.assign(b->cores.size(), -1);
+    b->prev_join.assign(b->cores.size(), 0);
+    b->pipelined = on != 0;
+    return CSDR_OK;
+}
+/* stream-orders the caller's stream behind everything the batch has in flight (pipelined mode: the post-chain
+ * of the last call) */
+int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    for (size_t ki = 0; ki < b->prev_post.size(); ki++) {
+        if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
+        if (b->prev_post[ki] >= 0) {
+            CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->cores[ki]->ev_post[b->prev_post[ki]], 0));
+            b->prev_post[ki] = -1;
+        }
+    }
+    return CSDR_OK;
+}
 int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq)
 {
     if (!b || channel < 0 || channel >= b->channels) return fail(CSDR_EINVAL, "bad argument");
@@ -490,6 +630,7 @@ double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel)
     if (!b || channel < 0 || channel >= b->channels || b->core_of[channel] < 0) return 0.0;
     return b->cores[b->core_of[channel]]->pc.smeter_ave(b->row_of[channel]);
 }
+extern "C" int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream);
 /* CSMeter::GetAve / GetPeak of every channel into device arrays indexed by channel (either may be NULL);
  * reading the peak resets it, as GetPeak does (smeter.cpp:98-103).  Asynchronous on `stream`. */
 int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_peak, void *stream)
@@ -497,6 +638,8 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
     if (!b || (!d_ave && !d_peak)) return fail(CSDR_EINVAL, "bad argument");
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
     if (!device_ok(b->device)) return CSDR_EHIP;
+    int rcf = csdr_demod_batch_flush(b, stream);         // pipelined mode: behind the last call's post-chain
+    if (rcf) return rcf;
     for (size_t ki = 0; ki < b->cores.size(); ki++)
         CSDR_HIP(smeter_collect_launch(b->cores[ki]->pc.d_chan, b->cores[ki]->rows, b->d_rows[ki], d_ave, d_peak,
                                        (hipStream_t)stream));
@@ -513,21 +656,41 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t caller = (hipStream_t)stream;
-    const bool forked = b->cores.size() > 1;
+    const bool forked = b->cores.size() > 1 || b->pipelined;
     if (forked) CSDR_HIP(hipEventRecord(b->fork, caller));
     int err = 0;
     for (size_t oi = 0; oi < b->cores.size(); oi++) {
         const size_t ki = (size_t)b->order[oi];
+        ChainCore &k = *b->cores[ki];
         hipStream_t st = forked ? b->streams[ki] : caller;
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
-        const int rc = b->cores[ki]->step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride,
-                                          b->d_rows[ki], stereo, st,
-                                          forked && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr,
-                                          forked ? b->dc_done[ki] : nullptr);
+        // pipelined: the caller's stream catches up with the PREVIOUS call only now, behind this call's fork
+        // event, so that this call's down-converter is not held back by it: previous input consumed, output
+        // rows of the call before that complete
+        if (b->pipelined) {
+            if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent(caller, b->joins[ki], 0)); b->prev_join[ki] = 0; }
+            if (b->prev_post[ki] >= 0) { CSDR_HIP(hipStreamWaitEvent(caller, k.ev_post[b->prev_post[ki]], 0)); b->prev_post[ki] = -1; }
+        }
+        // strict mode: the groups' down-converters run one after the other (each fills the chip on its own) and
+        // what follows a group's down-converter overlaps the next group's; pipelined mode: all at once, the
+        // overlap comes from the next call
+        int rc;
+        if (k.s_post)
+            rc = k.step_pipelined(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_rows[ki], stereo,
+                                  st, !b->pipelined && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, b->dc_done[ki]);
+        else
+            rc = k.step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_rows[ki], stereo, st,
+                        forked && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, forked ? b->dc_done[ki] : nullptr);
         if (rc < 0 && !err) err = rc;
         if (forked) {                                   // join even after an error: the caller's stream stays ordered
-            CSDR_HIP(hipEventRecord(b->joins[ki], st));
-            CSDR_HIP(hipStreamWaitEvent(caller, b->joins[ki], 0));
+            CSDR_HIP(hipEventRecord(b->joins[ki], st));  // the input has been consumed (+ filter and shift, strict mode)
+            if (b->pipelined) {                          // joined by the next call / flush
+                b->prev_join[ki] = 1;
+                b->prev_post[ki] = k.last_post;
+            } else {
+                CSDR_HIP(hipStreamWaitEvent(caller, b->joins[ki], 0));
+                if (k.last_post >= 0) CSDR_HIP(hipStreamWaitEvent(caller, k.ev_post[k.last_post], 0));
+            }
         }
     }
     return err ? err : CSDR_OK;

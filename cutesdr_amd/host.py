@@ -589,6 +589,12 @@ class DemodBatch(_Obj):
     def out_count(self, channel):
         return check(lib().csdr_demod_batch_out_count(self.h, channel))
 
+    def set_pipelined(self, on=True):
+        check(lib().csdr_demod_batch_set_pipelined(self.h, int(on)), "set_pipelined")
+
+    def flush(self, stream=None):
+        check(lib().csdr_demod_batch_flush(self.h, C.c_void_p(stream) if stream else None), "flush")
+
     def smeter_all_ptr(self, d_ave, d_peak=None, stream=None):
         check(lib().csdr_demod_batch_get_smeter_all(self.h, C.c_void_p(d_ave) if d_ave else None,
                                                     C.c_void_p(d_peak) if d_peak else None,

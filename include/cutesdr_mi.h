@@ -258,6 +258,13 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
 /* d_in [channels][in_stride] complex fp32 -> d_out [channels][out_stride] fp32 mono audio */
 int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
                              int n_per_channel, float *d_out, long long out_stride, void *stream);
+/* Pipelined mode for streaming hosts (off by default).  on != 0: the three stages of a call (down-converter |
+ * filter | S-meter, AGC, demodulator) run on internal streams and overlap the neighbouring calls' other stages; a
+ * process call only enqueues.  In the caller's stream order, after process call k+1 the INPUT buffer of call k has
+ * been consumed and the OUTPUT rows of call k-1 are complete; after csdr_demod_batch_flush everything issued so
+ * far is complete.  Same results as the strict mode, word for word. */
+int csdr_demod_batch_set_pipelined(csdr_demod_batch *b, int on);
+int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream);
 /* the stereo overload (dsp/demodulator.cpp:221-273: AM/FM duplicate the audio into both halves, SAM splits the
  * sidebands, SSB/CW copy the filtered I/Q) for every channel: d_out_iq [channels][out_stride] complex fp32,
  * out_stride in complex samples */

@@ -231,3 +231,44 @@ def test_c4_shard_256_mixed_receivers_distinct_streams(oracle):
     assert errs[~fm].max() <= 2e-5, (int(np.argmax(errs * ~fm)), errs[~fm].max())
     assert errs[fm].max() <= 3e-5, (int(np.argmax(errs * fm)), errs[fm].max())
     assert dsm.max() <= 0.02
+
+
+def test_pipelined_mode_gives_the_strict_mode_results():
+    """csdr_demod_batch_set_pipelined: the post-chain of call k overlaps the down-converter of call k+1 on
+    internal streams; four calls issued back to back without any host synchronisation, one flush at the end --
+    every output word equals the strict mode's."""
+    import cutesdr_amd as ca
+    C, fs, n, calls = 12, 2e6, 19968 * 8, 4
+    names = ["AM", "FM", "USB", "SAM"]
+    x = np.stack([chain_input(names[c % 4], calls * n, fs) * np.exp(2j * np.pi * 700.0 * c * np.arange(calls * n) / fs)
+                  for c in range(C)]).astype(np.complex64)
+    outs = []
+    for pipelined in (False, True):
+        b = ca.DemodBatch(C, 2048)
+        b.set_input_rate(fs)
+        for c in range(C):
+            m, kw = MODES[names[c % 4]]
+            b.set_demod(c, m, info(ca, **kw))
+        b.commit()
+        for c in range(C):
+            b.set_freq(c, -100e3 - 700.0 * c)
+        if pipelined:
+            b.set_pipelined(True)
+        cap = n // 8
+        din = ca.DeviceBuffer(x.nbytes)
+        dout = ca.DeviceBuffer(4 * C * cap * calls)
+        din.upload(x)
+        counts = []
+        for k in range(calls):                                # no synchronisation between the calls
+            b.process_ptr(din.ptr + 8 * k * n, calls * n, n, dout.ptr + 4 * C * cap * k, cap)
+            counts.append([b.out_count(c) for c in range(C)])
+        b.flush()
+        ca.sync()
+        y = dout.download(np.float32, C * cap * calls).reshape(calls, C, cap)
+        outs.append([[y[k, c, :counts[k][c]].copy() for c in range(C)] for k in range(calls)])
+        sm = b.smeter_all()
+        outs[-1].append(sm)
+    for k in range(calls):
+        for c in range(C):
+            assert np.array_equal(outs[0][k][c].view(np.uint32), outs[1][k][c].view(np.uint32)), (k, c)
+    assert np.array_equal(outs[0][calls], outs[1][calls])
