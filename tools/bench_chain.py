@@ -131,6 +131,24 @@ ms = e0.elapsed_time(e1) / 30
 out["chain_ms"] = round(ms, 3)
 out["chain_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["chain_alg_GBps"] = round(C * T * (8 + 4 / 32) / ms / 1e6, 1)
+# the same chain fed with 24-bit datagrams: unpack kernel, optional blanker, chain
+npk = (T // 240) // 8 * 8          # 240 * 8 = 1920 = 64 * 30: a multiple of the largest decimation
+Tp = npk * 240
+pk = torch.randint(0, 256, (C, npk, 1444), device=dev, dtype=torch.uint8)
+nbk = ca.NoiseProcBatch(C); nbk.setup(True, 50.0, 2.0, 2e6)
+import ctypes as _C
+def chain_pk(nb):
+    rc = ca.lib().csdr_demod_batch_process_packets(b.h, pk.data_ptr(), npk, 1444, nb.h if nb is not None else None,
+                                                   aud.data_ptr(), T // 16 + 4096, stream)
+    assert rc == 0, ca._capi.last_error()
+for name, nb in (("packets_chain_ms", None), ("packets_blanker_chain_ms", nbk)):
+    for _ in range(10): chain_pk(nb)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(30): chain_pk(nb)
+    e1.record(); torch.cuda.synchronize()
+    out[name] = round(e0.elapsed_time(e1) / 30, 3)
+out["packets_samples_per_channel"] = Tp
 out["channels"] = C
 out["hw_queues"] = os.environ["GPU_MAX_HW_QUEUES"]
 print(json.dumps(out))
