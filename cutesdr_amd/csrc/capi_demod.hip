@@ -14,7 +14,9 @@ using namespace csdr;
 
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
-                                                    long long out_stride, void *stream);
+                                                    long long out_stride, void *stream, const void *d_packets, int pkt_len);
+extern "C" int csdr__noiseproc_batch_process_packets(struct csdr_noiseproc_batch *b, const void *d_packets, int npackets,
+                                                     int pkt_len, float *d_out, long long out_stride, void *stream);
 
 namespace {
 
@@ -51,6 +53,7 @@ struct ChainCore {
     // long calls run S-meter | AGC | demodulator as a pipeline of launches over burst groups
     hipStream_t s_dem = nullptr, s_sm = nullptr;
     hipEvent_t ev_fork = nullptr, ev_dem = nullptr, ev_sm = nullptr, ev_agc[8] = {};                       // staging capacity per row (complex samples)
+    const void *pk = nullptr; int pk_len = 0;   // this call's input as datagrams (csdr_demod_batch_process_packets)
     int pending = 0;                    // decimated samples waiting for a full hop (same in every row)
     int last_out = 0;
 
@@ -183,7 +186,7 @@ struct ChainCore {
         // what follows a group's down-converter overlaps with the next group's
         if (dc_after) CSDR_HIP(hipStreamWaitEvent(s, dc_after, 0));
         rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, d_stage + 2 * (size_t)pending,
-                                                  cap, s);
+                                                  cap, s, pk, pk_len);
         if (rc) return rc;
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
         const int total = pending + m, nb = total / L;
@@ -221,7 +224,8 @@ struct ChainCore {
         if (dc_after) CSDR_HIP(hipStreamWaitEvent(s, dc_after, 0));
         // the filter + shift of the call that last used this staging buffer must have finished with it
         if (stage_busy[sc]) { CSDR_HIP(hipStreamWaitEvent(s, ev_stage_free[sc], 0)); stage_busy[sc] = false; }
-        rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, stage + 2 * (size_t)pending, cap, s);
+        rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, stage + 2 * (size_t)pending, cap, s,
+                                                  pk, pk_len);
         if (rc) return rc;
         CSDR_HIP(hipEventRecord(ev_dc, s));
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
@@ -353,13 +357,12 @@ struct csdr_demod_batch {
     bool pipelined = false;                           // csdr_demod_batch_set_pipelined
     std::vector<int> prev_post;                       // pipelined: per core, the post-chain event of the previous call
     std::vector<char> prev_join;                      // pipelined: per core, joins[] of the previous call not yet waited for
-    float *d_raw = nullptr, *d_blank = nullptr;      // unpacked / blanked input of process_packets
+    float *d_blank = nullptr;                         // blanked input of process_packets
     long raw_cap = 0;
     ~csdr_demod_batch()
     {
         for (auto *k : cores) delete k;
         for (auto *p : d_rows) if (p) (void)hipFree(p);
-        if (d_raw) (void)hipFree(d_raw);
         if (d_blank) (void)hipFree(d_blank);
         for (auto st : streams) (void)hipStreamDestroy(st);
         for (auto ev : joins) (void)hipEventDestroy(ev);
@@ -650,9 +653,10 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
  * m_InBufLimit-sized passes; the decimator and filter are chunking independent, the squelch
  * decision is taken once per FastFIR hop either way).  Asynchronous. */
 static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
-                           float *d_out, long long out_stride, void *stream, bool stereo)
+                           float *d_out, long long out_stride, void *stream, bool stereo,
+                           const void *d_packets = nullptr, int pkt_len = 0)
 {
-    if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad argument");
+    if (!b || (!d_in && !d_packets) || !d_out) return fail(CSDR_EINVAL, "bad argument");
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t caller = (hipStream_t)stream;
@@ -662,6 +666,7 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
     for (size_t oi = 0; oi < b->cores.size(); oi++) {
         const size_t ki = (size_t)b->order[oi];
         ChainCore &k = *b->cores[ki];
+        k.pk = d_packets; k.pk_len = pkt_len;            // this call's input as datagrams, or nullptr
         hipStream_t st = forked ? b->streams[ki] : caller;
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
         // pipelined: the caller's stream catches up with the PREVIOUS call only now, behind this call's fork
@@ -713,23 +718,19 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     if (npackets == 0) return CSDR_OK;
     if (!device_ok(b->device)) return CSDR_EHIP;
     const long n = (long)npackets * (pkt_len == 1444 ? 240 : 256);
+    if (!nb)        // the down-converter decodes the datagrams in its own loads: no unpacked copy, no extra pass
+        return demod_batch_run(b, nullptr, 0, (int)n, d_out, out_stride, stream, false, d_packets, pkt_len);
+    // with the blanker: it decodes the datagrams in ITS loads and leaves blanked fp32 samples for the chain
     if (n > b->raw_cap) {
-        if (b->d_raw) (void)hipFree(b->d_raw);
+        CSDR_HIP(hipDeviceSynchronize());
         if (b->d_blank) (void)hipFree(b->d_blank);
-        b->d_raw = b->d_blank = nullptr; b->raw_cap = 0;
-        CSDR_HIP(hipMalloc((void **)&b->d_raw, (size_t)b->channels * n * 8));
+        b->d_blank = nullptr; b->raw_cap = 0;
         CSDR_HIP(hipMalloc((void **)&b->d_blank, (size_t)b->channels * n * 8));
         b->raw_cap = n;
     }
-    int rc = csdr_ingest_unpack(b->device, d_packets, b->channels, npackets, pkt_len, b->d_raw, b->raw_cap, nullptr, stream);
+    int rc = csdr__noiseproc_batch_process_packets(nb, d_packets, npackets, pkt_len, b->d_blank, b->raw_cap, stream);
     if (rc < 0) return rc;
-    const float *src = b->d_raw;
-    if (nb) {
-        rc = csdr_noiseproc_batch_process(nb, b->d_raw, b->raw_cap, (int)n, b->d_blank, b->raw_cap, stream);
-        if (rc < 0) return rc;
-        src = b->d_blank;
-    }
-    return csdr_demod_batch_process(b, src, b->raw_cap, (int)n, d_out, out_stride, stream);
+    return demod_batch_run(b, b->d_blank, b->raw_cap, (int)n, d_out, out_stride, stream, false);
 }
 /* audio samples channel `channel` received in the last process call */
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel)

@@ -55,7 +55,7 @@ static int find_plan(csdr_downconvert_batch *b, double in_rate, double max_bw)
 
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
-                                                    long long out_stride, void *stream);
+                                                    long long out_stride, void *stream, const void *d_packets, int pkt_len);
 
 extern "C" {
 
@@ -170,18 +170,28 @@ int csdr_downconvert_batch_out_count(csdr_downconvert_batch *b, int channel, int
 int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                    int n_per_channel, float *d_out, long long out_stride, void *stream)
 {
-    return csdr__downconvert_batch_process_rows(b, d_in, in_stride, nullptr, n_per_channel, d_out, out_stride, stream);
+    return csdr__downconvert_batch_process_rows(b, d_in, in_stride, nullptr, n_per_channel, d_out, out_stride, stream, nullptr, 0);
 }
 
-/* internal (not in the public header): input row of channel c is in_rows[c] (device array) */
+/* internal (not in the public header): input row of channel c is in_rows[c] (device array); with d_packets the
+ * samples are read from datagrams ([rows][n_per_channel / per][pkt_len] bytes, wire_format.hpp) instead of d_in */
 int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                          const int *d_in_rows, int n_per_channel, float *d_out,
-                                         long long out_stride, void *stream)
+                                         long long out_stride, void *stream, const void *d_packets, int pkt_len)
 {
-    if (!b || !d_in || !d_out) return fail(CSDR_EINVAL, "bad handle or null buffer");
+    if (!b || (!d_in && !d_packets) || !d_out) return fail(CSDR_EINVAL, "bad handle or null buffer");
     if (n_per_channel <= 0 || (n_per_channel & 1)) return fail(CSDR_EINVAL, "n_per_channel must be even and > 0");
-    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 7) || (in_stride & 1) || in_stride < n_per_channel)
-        return fail(CSDR_EINVAL, "input must be 16-byte aligned (output 8), input stride even and >= n");
+    WireIn wire{nullptr, 0, 0, 0};
+    if (d_packets) {
+        if (pkt_len != 1028 && pkt_len != 1444) return fail(CSDR_EINVAL, "packet length %d", pkt_len);
+        wire.per = pkt_len == 1444 ? 240 : 256;
+        if (n_per_channel % wire.per || ((uintptr_t)d_packets & 3)) return fail(CSDR_EINVAL, "whole, 4-byte aligned datagrams");
+        wire.pk = (const unsigned char *)d_packets; wire.pkt_len = pkt_len;
+        wire.chan_stride = (long)(n_per_channel / wire.per) * pkt_len;
+        if (wire.chan_stride >= (1l << 31)) return fail(CSDR_EINVAL, "a channel's datagrams of one call must stay below 2 GiB");
+    } else if (((uintptr_t)d_in & 15) || (in_stride & 1) || in_stride < n_per_channel)
+        return fail(CSDR_EINVAL, "input must be 16-byte aligned, input stride even and >= n");
+    if ((uintptr_t)d_out & 7) return fail(CSDR_EINVAL, "output must be 8-byte aligned");
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t s = (hipStream_t)stream;
     for (size_t pi = 0; pi < b->plans.size(); pi++)
@@ -211,7 +221,7 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         const DcPlan &p = b->plans[pi];
         DcArgs a;
         memset(&a, 0, sizeof(a));
-        a.in = (const dc_v2f *)d_in; a.in_stride = in_stride;
+        a.in = (const dc_v2f *)d_in; a.in_stride = in_stride; a.wire = wire;
         a.out = (dc_v2f *)d_out; a.out_stride = out_stride;
         a.hist = (const dc_v2f *)(b->d_hist + b->hist_cur * half);
         a.hist_next = (dc_v2f *)(b->d_hist + (b->hist_cur ^ 1) * half);

@@ -84,16 +84,36 @@ int csdr_noiseproc_batch_setup(csdr_noiseproc_batch *b, int channel, int on, dou
     }
     return CSDR_OK;
 }
+static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const WireIn &wire, int n_per_channel,
+                  float *d_out, long long out_stride, void *stream);
 int csdr_noiseproc_batch_process(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, int n_per_channel,
                                  float *d_out, long long out_stride, void *stream)
 {
     if (!b || !d_in || !d_out || n_per_channel < 0) return fail(CSDR_EINVAL, "bad argument");
     if (d_in == d_out) return fail(CSDR_EINVAL, "the device form reads samples behind the write position: "
                                    "d_out must not alias d_in");
+    return nb_run(b, d_in, in_stride, WireIn{nullptr, 0, 0, 0}, n_per_channel, d_out, out_stride, stream);
+}
+/* internal (not in the public header): the same pass reading the samples straight from datagrams
+ * ([channels][npackets][pkt_len] bytes, interface/netiobase.cpp:479-527) -- no unpacked copy in between */
+int csdr__noiseproc_batch_process_packets(csdr_noiseproc_batch *b, const void *d_packets, int npackets, int pkt_len,
+                                          float *d_out, long long out_stride, void *stream)
+{
+    if (!b || !d_packets || !d_out || npackets < 0) return fail(CSDR_EINVAL, "bad argument");
+    if (pkt_len != 1028 && pkt_len != 1444) return fail(CSDR_EINVAL, "packet length %d", pkt_len);
+    const int per = pkt_len == 1444 ? 240 : 256;
+    if ((long)npackets * pkt_len >= (1l << 31)) return fail(CSDR_EINVAL, "a channel's datagrams of one call must stay below 2 GiB");
+    return nb_run(b, nullptr, 0, WireIn{(const unsigned char *)d_packets, (long)npackets * pkt_len, pkt_len, per},
+                  npackets * per, d_out, out_stride, stream);
+}
+static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const WireIn &wire, int n_per_channel,
+                  float *d_out, long long out_stride, void *stream)
+{
     if (n_per_channel == 0) return CSDR_OK;
     if (!device_ok(b->device)) return CSDR_EHIP;
     const size_t half = (size_t)b->channels * NB_HIST * 2;
     NbArgs a;
+    a.wire = wire;
     a.chan = b->d_chan + (size_t)b->cur * b->channels; a.chan_next = b->d_chan + (size_t)(b->cur ^ 1) * b->channels; a.in = d_in; a.in_stride = in_stride; a.out = d_out; a.out_stride = out_stride;
     a.hist = b->d_hist + b->cur * half; a.hist_next = b->d_hist + (b->cur ^ 1) * half;
     a.channels = b->channels; a.n = n_per_channel;

@@ -1,6 +1,7 @@
 // downconv_kernels.h -- launch interface of the NCO + decimator cascade kernel (internal).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wire_format.hpp"
 
 namespace csdr {
 
@@ -27,7 +28,8 @@ struct DcChan {                      // per-channel NCO state at the start of th
 };
 
 struct DcArgs {
-    const dc_v2f *in;  long in_stride;       // raw IQ [channels][in_stride]
+    const dc_v2f *in;  long in_stride;       // raw IQ [channels][in_stride]; unused when wire.pk is set
+    WireIn wire;                             // optional: the call's samples as datagrams (wire_format.hpp)
     dc_v2f *out;       long out_stride;      // [channels][out_stride], n_in >> nstages valid
     const dc_v2f *hist; dc_v2f *hist_next;   // [channels][hist_stride], first W valid: mixed samples, ping-pong
     long hist_stride;

@@ -143,7 +143,9 @@ void downconv_kernel(DcArgs a)
     v2f p0 = {1.f, 0.f}, p1 = {1.f, 0.f};
     int anchor_rows = 0;                                 // rows until the phasors are re-anchored
 
-    const v2f *in = a.in + (long)(a.in_rows ? a.in_rows[ch] : ch) * a.in_stride;
+    const long in_row = a.in_rows ? a.in_rows[ch] : ch;
+    const v2f *in = a.in + in_row * a.in_stride;
+    const unsigned char *pk = a.wire.pk ? a.wire.pk + in_row * a.wire.chan_stride : nullptr;   // datagram input
     v2f *out = a.out + (long)ch * a.out_stride;
     const v2f *hist = a.hist + (long)ch * a.hist_stride;
     v2f *hist_next = a.hist_next + (long)ch * a.hist_stride;
@@ -167,10 +169,23 @@ void downconv_kernel(DcArgs a)
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int i = r * DC_ROW + 2 * t;
-            if (i < m) raw[r] = *reinterpret_cast<const v4f *>(in + p + i);
+            if (i < m) {
+                if (pk) {
+                    const wf4 w = wire_pair_fetch(pk, a.wire.pkt_len, p + i);          // raw words; p + i is even
+                    raw[r] = v4f{w.x, w.y, w.z, w.w};
+                } else {
+                    raw[r] = *reinterpret_cast<const v4f *>(in + p + i);
+                }
+            }
         }
     };
 
+    // datagram input: the prefetched words are decoded where they are consumed
+    auto unwire = [&](v4f r) -> v4f {
+        if (!pk) return r;
+        const wf4 w = wire_pair_decode(wf4{r.x, r.y, r.z, r.w}, a.wire.pkt_len);
+        return v4f{w.x, w.y, w.z, w.w};
+    };
     // pos: index of the tile's first sample in this call's input (negative inside the warm-up)
     long pos = seg_start - a.W;
 #ifdef DC_PROFILE
@@ -211,7 +226,7 @@ void downconv_kernel(DcArgs a)
                 v2f *e = r0 + t, *o = r0o + t;
 #pragma unroll
                 for (int row = 0; row < NR; row++) {
-                    const v4f v = raw[row];
+                    const v4f v = unwire(raw[row]);
                     e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
                     o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
                     p0 = cmul(p0, rowstep);
@@ -223,7 +238,7 @@ void downconv_kernel(DcArgs a)
                 const int i = row * DC_ROW + 2 * t;
                 const long gi = pos + i;                       // sample index within the call
                 if (i < n) {
-                    const v4f v = raw[row];
+                    const v4f v = unwire(raw[row]);
                     v2f x0 = cmul(v2f{v.x, v.y}, p0), x1 = cmul(v2f{v.z, v.w}, p1);
                     const unsigned long long age = cs.age + (unsigned long long)gi;
                     if (age + 1 < DC_AMP_N) {                   // start-up envelope (the phasors carry a_inf)

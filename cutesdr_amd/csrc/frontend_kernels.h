@@ -2,6 +2,7 @@
 // (SURVEY 8(f) rows f1, f2): noise blanker, wire-format unpack, DC (NCO spur) estimate.  Internal.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wire_format.hpp"
 
 namespace csdr {
 
@@ -18,7 +19,8 @@ struct NbChan {                         // CNoiseProc state (dsp/noiseproc.h:36-
 struct NbArgs {
     const NbChan *chan;                 // [channels] state at the start of the call
     NbChan *chan_next;                  // [channels] state after it (ping-pong, like the history)
-    const float *in;  long in_stride;   // complex fp32 [channels][in_stride]
+    const float *in;  long in_stride;   // complex fp32 [channels][in_stride]; unused when wire.pk is set
+    WireIn wire;                        // optional: the call's samples as datagrams (wire_format.hpp)
     float *out;       long out_stride;  // complex fp32 [channels][out_stride]; may alias `in` only if hist is kept
     const float *hist; float *hist_next;    // [channels][NB_HIST] complex: the last NB_HIST inputs, ping-pong
     int channels, n;

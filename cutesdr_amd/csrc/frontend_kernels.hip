@@ -47,7 +47,11 @@ void noiseblank_kernel(NbArgs a)
     const f2 *hist = reinterpret_cast<const f2 *>(a.hist) + (long)ch * NB_HIST;
     f2 *hist_next = reinterpret_cast<f2 *>(a.hist_next) + (long)ch * NB_HIST;
     const int n = a.n;
-    auto X = [&](long i) -> f2 { return i >= 0 ? in[i] : hist[NB_HIST + i]; };   // i >= -NB_HIST
+    // sample i of the call: from the float rows or decoded from the datagrams as they arrived
+    const unsigned char *pk = a.wire.pk ? a.wire.pk + (long)ch * a.wire.chan_stride : nullptr;
+    const int pkt_len = a.wire.pkt_len;
+    auto IN = [&](long i) -> f2 { return pk ? wire_sample(pk, pkt_len, i) : in[i]; };
+    auto X = [&](long i) -> f2 { return i >= 0 ? IN(i) : hist[NB_HIST + i]; };   // i >= -NB_HIST
     // this workgroup's segment [seg_a, seg_b) of the call
     const long seg_a = (long)seg * a.seg_len;
     const long seg_b = seg_a + a.seg_len < n ? seg_a + a.seg_len : n;
@@ -81,7 +85,7 @@ void noiseblank_kernel(NbArgs a)
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 const long i = b0 + (long)t * NB_PER + k;
-                if (i < seg_b) { nx[k] = in[i]; nxo[k] = X(i - M1); nxd[k] = X(i - D1); }
+                if (i < seg_b) { nx[k] = IN(i); nxo[k] = X(i - M1); nxd[k] = X(i - D1); }
             }
         };
         fetch(first);
@@ -151,8 +155,8 @@ void noiseblank_kernel(NbArgs a)
     } else {
         if (t == 0 && last_seg) a.chan_next[ch] = C;
     }
-    if (!C.on && a.out != a.in) {
-        for (long i = seg_a + t; i < seg_b; i += NB_T) out[i] = in[i];  // off: the data passes through (:125-129)
+    if (!C.on && (pk || a.out != a.in)) {
+        for (long i = seg_a + t; i < seg_b; i += NB_T) out[i] = IN(i);  // off: the data passes through (:125-129)
     }
     // the last NB_HIST inputs of [history | this call] are the next call's history
     if (last_seg)

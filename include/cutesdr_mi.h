@@ -272,11 +272,12 @@ int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long
                                     int n_per_channel, float *d_out_iq, long long out_stride, void *stream);
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
 /* The same pass fed with the datagrams as they arrived (interface/netiobase.cpp:479-527):
- * d_packets [channels][npackets][pkt_len] bytes on the device, pkt_len 1028 (16 bit) or 1444 (24 bit).
- * Unpacks to complex fp32, runs the optional blanker (what CSdrInterface::ProcessIQData does in
- * place before the chain, sdrinterface.cpp:884; nb may be NULL, it must have as many channels),
- * then csdr_demod_batch_process.  npackets * samples-per-packet must be a multiple of the largest
- * decimation in use.  Forward declaration: csdr_noiseproc_batch is defined further down. */
+ * d_packets [channels][npackets][pkt_len] bytes on the device, 4-byte aligned, pkt_len 1028 (16 bit) or 1444
+ * (24 bit).  No unpack pass: the first kernel at input rate decodes the datagrams in its own loads -- the
+ * down-converter, or the blanker when nb is given (what CSdrInterface::ProcessIQData runs in place before the
+ * chain, sdrinterface.cpp:884; nb may be NULL, it must have as many channels).  npackets * samples-per-packet
+ * must be a multiple of the largest decimation in use.  Forward declaration: csdr_noiseproc_batch is defined
+ * further down. */
 struct csdr_noiseproc_batch;
 int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets, int npackets, int pkt_len,
                                      struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride,

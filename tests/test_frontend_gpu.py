@@ -121,8 +121,9 @@ def _pack24(x):
 @pytest.mark.parametrize("pkt_len", [1028, 1444])
 def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
     """Datagrams -> [blanker ->] down-converter -> FastFIR -> AGC -> demodulator on the device
-    (csdr_demod_batch_process_packets: unpack kernel, optional blanker, chain) against the oracle's composition
-    of the same steps, for both wire formats."""
+    (csdr_demod_batch_process_packets) against the oracle's composition of the same steps.  No unpack pass
+    runs: the first input-rate kernel decodes the datagrams in its loads (wire_format.hpp) -- the blanker when it
+    is on, the down-converter otherwise."""
     import cutesdr_amd as ca
     from util_signals import fm_carrier, am_carrier, FULL_SCALE
     import test_postchain_gpu as T
@@ -158,3 +159,41 @@ def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
             assert len(got[c]) == len(want) > 0, c
             if call == 1:                                     # second call: start-up long gone (FM: see test_chain_parity_gpu)
                 assert np.abs(got[c] - want).max() <= 3e-5 * FULL_SCALE, c
+
+
+@pytest.mark.parametrize("pkt_len", [1028, 1444])
+def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len):
+    """The blanker kernel fed with datagrams (three decoded loads per sample: new, leaving the window, delayed)
+    against the oracle blanker on the oracle's unpacked samples: outputs are zeros or delayed copies of exactly
+    representable inputs, so every word must match, ragged calls included."""
+    import ctypes as C_
+    import cutesdr_amd as ca
+    L = ca.lib()
+    L.csdr__noiseproc_batch_process_packets.restype = C_.c_int
+    L.csdr__noiseproc_batch_process_packets.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_int, C_.c_int, C_.c_void_p,
+                                                        C_.c_longlong, C_.c_void_p]
+    per = 240 if pkt_len == 1444 else 256
+    fs, Cn = 2e6, 3
+    rng = np.random.default_rng(11)
+    counts = [3, 130, 1, 300, 77]                              # datagrams per call
+    tot = sum(counts) * per
+    x = [1500.0 * (rng.standard_normal(tot) + 1j * rng.standard_normal(tot)) for _ in range(Cn)]
+    for xc in x:
+        xc[rng.random(tot) < 2e-4] += 25000.0
+    raw = np.stack([(_pack24 if pkt_len == 1444 else _pack16)(xc) for xc in x])
+    nb = ca.NoiseProcBatch(Cn); nb.setup(True, 25.0, 20.0, fs)
+    refs = []
+    for c in range(Cn):
+        q = oracle.CNoiseProc(); q.SetupBlanker(True, 25.0, 20.0, fs); refs.append(q)
+    k0 = 0
+    for npk in counts:
+        part = np.ascontiguousarray(raw[:, k0:k0 + npk])
+        k0 += npk
+        dp, do = ca.DeviceBuffer(part.nbytes), ca.DeviceBuffer(Cn * npk * per * 8)
+        dp.upload(part)
+        assert L.csdr__noiseproc_batch_process_packets(nb.h, C_.c_void_p(dp.ptr), npk, pkt_len, C_.c_void_p(do.ptr), npk * per, None) == 0
+        ca.sync()
+        got = do.download(np.complex64, Cn * npk * per).reshape(Cn, npk * per)
+        for c in range(Cn):
+            want = refs[c].ProcessBlanker(oracle.unpack_packets(part[c], pkt_len))
+            assert np.array_equal(got[c], want.astype(np.complex64)), (npk, c)

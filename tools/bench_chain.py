@@ -131,12 +131,18 @@ ms = e0.elapsed_time(e1) / 30
 out["chain_ms"] = round(ms, 3)
 out["chain_input_MSps"] = round(C * T / ms / 1e3, 1)
 out["chain_alg_GBps"] = round(C * T * (8 + 4 / 32) / ms / 1e6, 1)
-# the same chain fed with 24-bit datagrams: unpack kernel, optional blanker, chain
+# the same chain fed with 24-bit datagrams (6 B per sample instead of 8): the down-converter, or the blanker in front
+# of it, decodes them in its loads -- no unpack pass
 npk = (T // 240) // 8 * 8          # 240 * 8 = 1920 = 64 * 30: a multiple of the largest decimation
 Tp = npk * 240
-pk = torch.randint(0, 256, (C, npk, 1444), device=dev, dtype=torch.uint8)
+# the receivers' own signals (x above) in the 24-bit wire format: value * 256, three little-endian bytes
+pk = torch.zeros((C, npk, 1444), device=dev, dtype=torch.uint8)
+for c0 in range(0, C, 32):
+    v = torch.round(x[c0:c0 + 32, :Tp].reshape(-1, npk, 480) * 256.0).clamp(-(1 << 23), (1 << 23) - 1).to(torch.int32)
+    body = torch.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], dim=-1).to(torch.uint8).reshape(-1, npk, 1440)
+    pk[c0:c0 + 32, :, 4:] = body
+    del v, body
 nbk = ca.NoiseProcBatch(C); nbk.setup(True, 50.0, 2.0, 2e6)
-import ctypes as _C
 def chain_pk(nb):
     rc = ca.lib().csdr_demod_batch_process_packets(b.h, pk.data_ptr(), npk, 1444, nb.h if nb is not None else None,
                                                    aud.data_ptr(), T // 16 + 4096, stream)
