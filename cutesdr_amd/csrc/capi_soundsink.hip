@@ -1,0 +1,144 @@
+// capi_soundsink.hip -- C ABI of the sound-sink adaptation: the queue and the rate-error
+// loop of CSoundOut (reference interface/soundout.cpp:155-468, non-blocking mode) around the device resampler.
+// The step after the path in a live receiver: PutOutQueue resamples the demodulator's audio to the sound-card
+// rate with Rate = m_OutRatio (1 + m_RateCorrection) (CFractResampler on the GPU, csdr_resampler_*), the audio
+// thread pops with GetOutQueue, and once per second of consumed samples the P-controller CalcError (:456-468)
+// turns the average queue fill into the next correction.  The queue, the fill average and the controller are
+// scalar host logic; only the resampling is device work.
+#include "capi_common.hpp"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+constexpr int kQ = 16384;                 // OUTQSIZE (soundout.h:18)
+constexpr int kRate = 48000;              // SOUNDCARD_RATE (soundout.cpp:48)
+constexpr double kAlpha = 0.001;          // FILTERQLEVEL_ALPHA (:51)
+constexpr double kPGain = 2.38e-7;        // P_GAIN (:52)
+}
+
+struct csdr_soundsink {
+    csdr_resampler *rs = nullptr;
+    int stereo = 0;
+    bool startup = true;                  // m_Startup
+    double user_rate = kRate, out_ratio = 1.0, rate_corr = 0.0, gain = 1.0, ave_level = 0.0;
+    int head = 0, tail = 0, level = 0, rate_count = 0, ppm = 0;
+    std::vector<short> q, r;              // the ring (2 shorts per entry when stereo), resampler output
+};
+
+extern "C" {
+
+/* CSoundOut::CSoundOut (soundout.cpp:60-76) */
+csdr_soundsink *csdr_soundsink_create(int device, int stereo)
+{
+    csdr_resampler *rs = csdr_resampler_create(device);
+    if (!rs) return nullptr;
+    if (csdr_resampler_init(rs, 8192) < 0) { csdr_resampler_destroy(rs); return nullptr; }
+    csdr_soundsink *s = new csdr_soundsink();
+    s->rs = rs; s->stereo = stereo != 0;
+    s->q.assign((size_t)(s->stereo ? 2 : 1) * kQ, 0);
+    s->r.assign((size_t)2 * kQ, 0);
+    return s;
+}
+void csdr_soundsink_destroy(csdr_soundsink *s)
+{
+    if (!s) return;
+    csdr_resampler_destroy(s->rs);
+    delete s;
+}
+/* CSoundOut::ChangeUserDataRate (:155-175) */
+int csdr_soundsink_change_user_data_rate(csdr_soundsink *s, double rate)
+{
+    if (!s || !(rate > 0.0)) return csdr::fail(CSDR_EINVAL, "bad argument");
+    if (s->user_rate != rate) {
+        s->user_rate = rate;
+        std::fill(s->q.begin(), s->q.end(), (short)0);
+        s->out_ratio = rate / (double)kRate;
+        s->head = s->tail = s->level = 0;
+        s->ave_level = kQ / 2;
+        s->startup = true;
+    }
+    return CSDR_OK;
+}
+/* CSoundOut::SetVolume (:180-189): 0 mutes, 1..99 = -50 dB .. 0 dB */
+int csdr_soundsink_set_volume(csdr_soundsink *s, int vol)
+{
+    if (!s) return csdr::fail(CSDR_EINVAL, "bad handle");
+    if (vol == 0) s->gain = 0.0;
+    else if (vol <= 99) s->gain = std::pow(10.0, ((double)vol - 99.0) / 39.2);
+    return CSDR_OK;
+}
+/* CSoundOut::PutOutQueue, non-blocking branch (:196-247 complex -> stereo, :254-305 real -> mono).  in: n doubles
+ * (mono sink) or n interleaved double pairs (stereo sink); at most 8192 samples per call, as the resampler was
+ * initialised (:71).  Returns the resampled samples produced. */
+int csdr_soundsink_put(csdr_soundsink *s, int n, const double *in)
+{
+    if (!s || n < 0 || (n > 0 && !in)) return csdr::fail(CSDR_EINVAL, "bad argument");
+    if (n == 0) return 0;
+    const double rate = 1.0 * s->out_ratio * (1.0 + s->rate_corr);            // TEST_ERROR * m_OutRatio * (1 + m_RateCorrection)
+    if ((double)n / rate + 8.0 > (double)kQ) return csdr::fail(CSDR_EINVAL, "call too long for the %d-entry queue", kQ);
+    const int k = s->stereo ? csdr_resampler_resample_cpx_i16(s->rs, n, rate, in, s->r.data(), s->gain)
+                            : csdr_resampler_resample_real_i16(s->rs, n, rate, in, s->r.data(), s->gain);
+    if (k < 0) return k;
+    bool overflow = false;
+    for (int i = 0; i < k; i++) {
+        if (s->stereo) { s->q[2 * s->head] = s->r[2 * i]; s->q[2 * s->head + 1] = s->r[2 * i + 1]; }
+        else s->q[s->head] = s->r[i];
+        s->head = (s->head + 1) & (kQ - 1);
+        s->level++;
+        if (s->head == s->tail) {                       // full: drop a quarter of the queue (:228-236)
+            s->tail = (s->tail + kQ / 4) & (kQ - 1);
+            s->level -= kQ / 4;
+            overflow = true;
+            break;
+        }
+    }
+    if (overflow) s->ave_level = s->level;
+    s->ave_level = (1.0 - kAlpha) * s->ave_level + kAlpha * (double)s->level;
+    return k;
+}
+/* CSoundOut::GetOutQueue (:311-375 mono, :381-445 stereo): n samples, or n L/R pairs of a stereo sink */
+int csdr_soundsink_get(csdr_soundsink *s, int n, short *out)
+{
+    if (!s || n < 0 || (n > 0 && !out)) return csdr::fail(CSDR_EINVAL, "bad argument");
+    const int w = s->stereo ? 2 : 1;
+    if (s->startup) {                                   // silence until the queue is half full (:316-333)
+        std::memset(out, 0, sizeof(short) * (size_t)w * n);
+        if (s->level > kQ / 2) {
+            s->startup = false;
+            s->rate_count = -5 * kRate;                 // first update delayed to let the level settle
+            s->ppm = 0;
+            s->ave_level = s->level;
+        } else return n;
+    }
+    bool underflow = false;
+    for (int i = 0; i < n; i++) {
+        if (s->head != s->tail) {
+            if (s->stereo) { out[2 * i] = s->q[2 * s->tail]; out[2 * i + 1] = s->q[2 * s->tail + 1]; }
+            else out[i] = s->q[s->tail];
+            s->tail = (s->tail + 1) & (kQ - 1);
+            s->level--;
+        } else {                                        // empty: back up a quarter and repeat older data (:344-351)
+            s->tail = (s->tail - kQ / 4) & (kQ - 1);
+            if (s->stereo) { out[2 * i] = s->q[2 * s->tail]; out[2 * i + 1] = s->q[2 * s->tail + 1]; }
+            else out[i] = s->q[s->tail];
+            s->level += kQ / 4;
+            underflow = true;
+        }
+    }
+    s->ave_level = (1.0 - kAlpha) * s->ave_level + kAlpha * s->level;
+    if (underflow) s->ave_level = s->level;
+    s->rate_count += n;
+    if (s->rate_count >= kRate) {                       // CalcError (:456-468), every second of consumed samples
+        s->rate_corr = (double)(s->ave_level - kQ / 2) * kPGain;
+        s->ppm = (int)(s->rate_corr * 1e6);
+        s->rate_count = 0;
+    }
+    return n;
+}
+double csdr_soundsink_get_rate_correction(csdr_soundsink *s) { return s ? s->rate_corr : 0.0; }
+double csdr_soundsink_get_ave_level(csdr_soundsink *s) { return s ? s->ave_level : 0.0; }
+int csdr_soundsink_get_level(csdr_soundsink *s) { return s ? s->level : csdr::fail(CSDR_EINVAL, "bad handle"); }
+int csdr_soundsink_get_ppm_error(csdr_soundsink *s) { return s ? s->ppm : 0; }
+
+}  // extern "C"

@@ -794,3 +794,40 @@ class ResamplerBatch(_Obj):
         sync(self.device)
         out = dout.download(np.float32 if gain is None else np.int16, self.channels * cap).reshape(self.channels, cap)
         return out[:, :k].copy()
+
+
+class CSoundOut(_Obj):
+    """interface/soundout.cpp -- queue and rate-error loop of the sound sink (non-blocking mode) around the
+    device resampler; PutOutQueue / GetOutQueue / ChangeUserDataRate / SetVolume as in the reference"""
+    _destroy = "csdr_soundsink_destroy"
+
+    def __init__(self, stereo=False, device=0):
+        self.stereo = bool(stereo)
+        self.h = check_ptr(lib().csdr_soundsink_create(device, int(stereo)), "csdr_soundsink_create")
+
+    def ChangeUserDataRate(self, UsrDataRate):
+        check(lib().csdr_soundsink_change_user_data_rate(self.h, UsrDataRate))
+
+    def SetVolume(self, vol):
+        check(lib().csdr_soundsink_set_volume(self.h, vol))
+
+    def PutOutQueue(self, x):
+        a = _c128(x) if self.stereo else _f64(x)
+        return check(lib().csdr_soundsink_put(self.h, len(a), _vp(a)), "csdr_soundsink_put")
+
+    def GetOutQueue(self, n):
+        out = np.zeros((n, 2) if self.stereo else n, dtype=np.int16)
+        check(lib().csdr_soundsink_get(self.h, n, _vp(out)), "csdr_soundsink_get")
+        return out
+
+    def rate_correction(self):
+        return lib().csdr_soundsink_get_rate_correction(self.h)
+
+    def ave_level(self):
+        return lib().csdr_soundsink_get_ave_level(self.h)
+
+    def level(self):
+        return check(lib().csdr_soundsink_get_level(self.h))
+
+    def ppm_error(self):
+        return lib().csdr_soundsink_get_ppm_error(self.h)

@@ -353,6 +353,30 @@ int csdr_resampler_batch_resample(csdr_resampler_batch *b, const float *d_in, lo
                                   float *d_out_f32, short *d_out_i16, long long out_stride, double gain, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * Sound-sink adaptation: the queue and rate-error loop of CSoundOut
+ * (interface/soundout.cpp, non-blocking mode) around the device resampler -- the step right after the path in
+ * a live receiver.  put = PutOutQueue (:196-305): resample to 48 kHz int16 with Rate = m_OutRatio *
+ * (1 + m_RateCorrection) and the volume gain, queue (16384 entries; overflow drops a quarter); get = GetOutQueue
+ * (:311-445) for the audio thread (silence until half full, underflow backs up a quarter); every second of
+ * consumed samples the P-controller CalcError (:456-468) sets the correction from the average fill level.
+ * One producer thread and one consumer thread as in the reference: the caller serialises put and get per handle.
+ * -------------------------------------------------------------------------------------- */
+typedef struct csdr_soundsink csdr_soundsink;
+csdr_soundsink *csdr_soundsink_create(int device, int stereo);               /* soundout.cpp:60-76 */
+void csdr_soundsink_destroy(csdr_soundsink *s);
+int csdr_soundsink_change_user_data_rate(csdr_soundsink *s, double rate);    /* :155-175 */
+int csdr_soundsink_set_volume(csdr_soundsink *s, int vol);                   /* :180-189 */
+/* in: n doubles (mono sink) or n interleaved double pairs (stereo sink), at most 8192 samples; returns the
+ * resampled samples produced */
+int csdr_soundsink_put(csdr_soundsink *s, int n, const double *in);
+/* out: n shorts, or n L/R pairs of a stereo sink; returns n */
+int csdr_soundsink_get(csdr_soundsink *s, int n, short *out);
+double csdr_soundsink_get_rate_correction(csdr_soundsink *s);                /* m_RateCorrection */
+double csdr_soundsink_get_ave_level(csdr_soundsink *s);                      /* m_AveOutQLevel */
+int csdr_soundsink_get_level(csdr_soundsink *s);                             /* m_OutQLevel */
+int csdr_soundsink_get_ppm_error(csdr_soundsink *s);                         /* m_PpmError */
+
+/* ----------------------------------------------------------------------------------------
  * Input-rate stages in front of the down-converter
  *
  * CNoiseProc (dsp/noiseproc.h:23-58): impulse blanker.  setup = SetupBlanker (noiseproc.cpp:78-119,

@@ -1399,3 +1399,119 @@ void orc_spurcal(double *dc, int n_doubles, const double *data)
         else       dc[0] = (1.0 - 1.0 / 100000.0) * dc[0] + (1.0 / 100000.0) * data[i];
     }
 }
+
+
+/* ==================================================================================== */
+/* CSoundOut queue + rate-error loop (interface/soundout.cpp)  -- SURVEY 8(f) row f3        */
+/* ==================================================================================== */
+/* The non-blocking mode of the sound sink: PutOutQueue resamples to the sound-card rate with
+ * Rate = m_OutRatio * (1 + m_RateCorrection) and the volume gain, pushes into a 16384-entry ring
+ * (overflow: drop a quarter of the queue), GetOutQueue pops for the audio thread (start-up silence
+ * until the queue is half full, underflow: back up a quarter), both track the average fill level,
+ * and once per second of consumed samples CalcError sets the correction from it.               */
+#define SS_OUTQSIZE 16384               /* soundout.h:18 */
+#define SS_RATE 48000                   /* soundout.cpp:48 */
+#define SS_ALPHA 0.001                  /* soundout.cpp:51 */
+#define SS_PGAIN 2.38e-7                /* soundout.cpp:52 */
+struct orc_soundsink {
+    orc_resampler *rs;
+    int stereo, startup;
+    double user_rate, out_ratio, rate_corr, gain, ave_level;
+    int head, tail, level, rate_count, ppm;
+    short q[2 * SS_OUTQSIZE];
+};
+orc_soundsink *orc_soundsink_new(int stereo)
+{
+    orc_soundsink *s = (orc_soundsink *)zalloc(sizeof(*s));     /* ctor soundout.cpp:60-76 */
+    s->rs = orc_resampler_new();
+    orc_resampler_init(s->rs, 8192);
+    s->stereo = stereo; s->user_rate = SS_RATE; s->out_ratio = 1.0; s->rate_corr = 0.0; s->gain = 1.0; s->startup = 1;
+    return s;
+}
+void orc_soundsink_free(orc_soundsink *s) { if (s) { orc_resampler_free(s->rs); free(s); } }
+void orc_soundsink_change_rate(orc_soundsink *s, double rate)   /* ChangeUserDataRate :155-175 */
+{
+    if (s->user_rate != rate) {
+        s->user_rate = rate;
+        memset(s->q, 0, sizeof(s->q));
+        s->out_ratio = rate / (double)SS_RATE;
+        s->head = s->tail = s->level = 0;
+        s->ave_level = SS_OUTQSIZE / 2;
+        s->startup = 1;
+    }
+}
+void orc_soundsink_set_volume(orc_soundsink *s, int vol)        /* SetVolume :180-189 */
+{
+    if (vol == 0) s->gain = 0.0;
+    else if (vol <= 99) s->gain = pow(10.0, ((double)vol - 99.0) / 39.2);
+}
+static void ss_calc_error(orc_soundsink *s)                     /* CalcError :456-468 */
+{
+    double error = (double)(s->ave_level - SS_OUTQSIZE / 2);
+    error = error * SS_PGAIN;
+    s->rate_corr = error;
+    s->ppm = (int)(s->rate_corr * 1e6);
+}
+/* PutOutQueue, non-blocking branch (:196-247 stereo, :254-305 mono); in: n reals or n complex pairs.
+ * Returns the resampled samples that were produced (queued unless the overflow rule dropped them). */
+int orc_soundsink_put(orc_soundsink *s, int n, const double *in)
+{
+    static short r[2 * SS_OUTQSIZE];
+    int i, overflow = 0, k;
+    const double rate = 1.0 * s->out_ratio * (1.0 + s->rate_corr);
+    if (n == 0) return 0;
+    k = s->stereo ? orc_resampler_cpx_i16(s->rs, n, rate, (const orc_cpx *)in, r, s->gain)
+                  : orc_resampler_real_i16(s->rs, n, rate, in, r, s->gain);
+    for (i = 0; i < k; i++) {
+        if (s->stereo) { s->q[2 * s->head] = r[2 * i]; s->q[2 * s->head + 1] = r[2 * i + 1]; }
+        else s->q[s->head] = r[i];
+        s->head = (s->head + 1) & (SS_OUTQSIZE - 1);
+        s->level++;
+        if (s->head == s->tail) {                                /* full: drop a quarter of the queue */
+            s->tail = (s->tail + SS_OUTQSIZE / 4) & (SS_OUTQSIZE - 1);
+            s->level -= SS_OUTQSIZE / 4;
+            overflow = 1;
+            break;
+        }
+    }
+    if (overflow) s->ave_level = s->level;
+    s->ave_level = (1.0 - SS_ALPHA) * s->ave_level + SS_ALPHA * (double)s->level;
+    return k;
+}
+/* GetOutQueue (:311-375 mono, :381-445 stereo): n samples (mono) or n L/R pairs (stereo) */
+void orc_soundsink_get(orc_soundsink *s, int n, short *out)
+{
+    int i, underflow = 0;
+    const int w = s->stereo ? 2 : 1;
+    if (s->startup) {
+        for (i = 0; i < w * n; i++) out[i] = 0;
+        if (s->level > SS_OUTQSIZE / 2) {
+            s->startup = 0;
+            s->rate_count = -5 * SS_RATE;
+            s->ppm = 0;
+            s->ave_level = s->level;
+        } else return;
+    }
+    for (i = 0; i < n; i++) {
+        if (s->head != s->tail) {
+            if (s->stereo) { out[2 * i] = s->q[2 * s->tail]; out[2 * i + 1] = s->q[2 * s->tail + 1]; }
+            else out[i] = s->q[s->tail];
+            s->tail = (s->tail + 1) & (SS_OUTQSIZE - 1);
+            s->level--;
+        } else {                                                 /* empty: back up and repeat older data */
+            s->tail = (s->tail - SS_OUTQSIZE / 4) & (SS_OUTQSIZE - 1);
+            if (s->stereo) { out[2 * i] = s->q[2 * s->tail]; out[2 * i + 1] = s->q[2 * s->tail + 1]; }
+            else out[i] = s->q[s->tail];
+            s->level += SS_OUTQSIZE / 4;
+            underflow = 1;
+        }
+    }
+    s->ave_level = (1.0 - SS_ALPHA) * s->ave_level + SS_ALPHA * s->level;
+    if (underflow) s->ave_level = s->level;
+    s->rate_count += n;
+    if (s->rate_count >= SS_RATE) { ss_calc_error(s); s->rate_count = 0; }
+}
+double orc_soundsink_rate_correction(const orc_soundsink *s) { return s->rate_corr; }
+double orc_soundsink_ave_level(const orc_soundsink *s) { return s->ave_level; }
+int orc_soundsink_level(const orc_soundsink *s) { return s->level; }
+int orc_soundsink_ppm(const orc_soundsink *s) { return s->ppm; }

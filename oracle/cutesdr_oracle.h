@@ -183,6 +183,19 @@ void orc_noiseproc_process(orc_noiseproc *p, int n, const double *in, double *ou
 int orc_unpack_packet(const unsigned char *pkt, int len, double *out);
 void orc_spurcal(double *dc, int n_doubles, const double *data);
 
+/* CSoundOut queue + rate-error loop, non-blocking mode (interface/soundout.cpp:155-468) */
+typedef struct orc_soundsink orc_soundsink;
+orc_soundsink *orc_soundsink_new(int stereo);
+void orc_soundsink_free(orc_soundsink *s);
+void orc_soundsink_change_rate(orc_soundsink *s, double rate);
+void orc_soundsink_set_volume(orc_soundsink *s, int vol);
+int orc_soundsink_put(orc_soundsink *s, int n, const double *in);
+void orc_soundsink_get(orc_soundsink *s, int n, short *out);
+double orc_soundsink_rate_correction(const orc_soundsink *s);
+double orc_soundsink_ave_level(const orc_soundsink *s);
+int orc_soundsink_level(const orc_soundsink *s);
+int orc_soundsink_ppm(const orc_soundsink *s);
+
 #ifdef __cplusplus
 }
 #endif

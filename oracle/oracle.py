@@ -89,6 +89,11 @@ def _declare(L):
     f("orc_noiseproc_new", P); f("orc_noiseproc_free", None, P)
     f("orc_noiseproc_setup", I, P, I, D, D, D); f("orc_noiseproc_process", None, P, I, P, P)
     f("orc_unpack_packet", I, P, I, P); f("orc_spurcal", None, P, I, P)
+    f("orc_soundsink_new", P, I); f("orc_soundsink_free", None, P)
+    f("orc_soundsink_change_rate", None, P, D); f("orc_soundsink_set_volume", None, P, I)
+    f("orc_soundsink_put", I, P, I, P); f("orc_soundsink_get", None, P, I, P)
+    f("orc_soundsink_rate_correction", D, P); f("orc_soundsink_ave_level", D, P)
+    f("orc_soundsink_level", I, P); f("orc_soundsink_ppm", I, P)
     f("orc_smeter_new", P); f("orc_smeter_free", None, P)
     f("orc_smeter_process", None, P, I, P, D)
     f("orc_smeter_peak", D, P); f("orc_smeter_ave", D, P)
@@ -535,3 +540,39 @@ def fm_defaults():
                      LowCutmax=-5000, FilterClickResolution=100, Offset=0, SquelchValue=0,
                      AgcSlope=0, AgcThresh=-100, AgcManualGain=30, AgcDecay=200,
                      AgcOn=1, AgcHangOn=0, Symetric=1)
+
+
+class CSoundOut(_Handle):
+    """interface/soundout.cpp:155-468, non-blocking mode: queue + rate-error loop around CFractResampler"""
+    _free = "orc_soundsink_free"
+
+    def __init__(self, stereo=False):
+        self.stereo = bool(stereo)
+        self.h = lib().orc_soundsink_new(int(stereo))
+
+    def ChangeUserDataRate(self, rate):
+        lib().orc_soundsink_change_rate(self.h, rate)
+
+    def SetVolume(self, vol):
+        lib().orc_soundsink_set_volume(self.h, vol)
+
+    def PutOutQueue(self, x):
+        a = _c128(x) if self.stereo else np.ascontiguousarray(x, dtype=np.float64)
+        return lib().orc_soundsink_put(self.h, len(a), _ptr(a))
+
+    def GetOutQueue(self, n):
+        out = np.zeros((n, 2) if self.stereo else n, dtype=np.int16)
+        lib().orc_soundsink_get(self.h, n, _ptr(out))
+        return out
+
+    def rate_correction(self):
+        return lib().orc_soundsink_rate_correction(self.h)
+
+    def ave_level(self):
+        return lib().orc_soundsink_ave_level(self.h)
+
+    def level(self):
+        return lib().orc_soundsink_level(self.h)
+
+    def ppm_error(self):
+        return lib().orc_soundsink_ppm(self.h)
