@@ -52,9 +52,10 @@ for key, cs in sorted(pmc.items()):
     kern["%s grid %d" % (name, grid)] = e
 # the stand-alone measurements (all 256 channels in one launch)
 for sub, (what, alg) in known.items():
-    cands = [(k[1], k) for k in pmc if sub in k[0]]          # the stand-alone launch is the largest shape of its kernel
+    # the stand-alone launch of a kernel: the shape whose counted traffic is nearest the known byte count
+    cands = [(abs(kern["%s grid %d" % k].get("hbm_bytes_fetch_doubled", 0.0) / alg - 1.0), k) for k in pmc if sub in k[0]]
     if not cands: continue
-    k = max(cands)[1]
+    k = min(cands)[1]
     e = kern["%s grid %d" % k]
     e["standalone"] = what
     e["algorithmic_bytes"] = alg
