@@ -35,7 +35,8 @@ for l in open(os.path.join(out, "chain.log")):
 npk = (T // 240) // 8 * 8
 known = {   # kernel substring -> (what, algorithmic bytes per launch of the stand-alone measurement, grid predicate)
     "downconv_kernel": ("K2 alone: 256 ch x 2^21 in, /32 out", C * T * (8 + 8 / 32.0)),
-    "spectrum_kernel<12>": ("K3: 256 ch x 512 frames x 4096, 8 B in + 4 B out per bin (only the last frame's bels are written)", C * 512 * 4096 * 8 + C * 4096 * 4),
+    "spectrum_kernel<12>": ("K3: 256 ch x 512 frames x 4096, 8 B in + 4 B out per bin (SURVEY 8d); the kernel keeps the running sums in "
+                            "registers and writes only the last frame's bels, so its traffic is the 8 B in", C * 512 * 4096 * 12),
     "noiseblank_kernel": ("K6 blanker: 256 ch x 2^21, 8 B in + 8 B out", C * T * 16),
     "unpack_kernel": ("K6 unpack 24 bit: 6 B in + 8 B out per sample", C * (T // 240) * 240 * 14),
 }
@@ -53,7 +54,8 @@ for key, cs in sorted(pmc.items()):
 # the stand-alone measurements (all 256 channels in one launch)
 for sub, (what, alg) in known.items():
     # the stand-alone launch of a kernel: the shape whose counted traffic is nearest the known byte count
-    cands = [(abs(kern["%s grid %d" % k].get("hbm_bytes_fetch_doubled", 0.0) / alg - 1.0), k) for k in pmc if sub in k[0]]
+    cands = [(abs(kern["%s grid %d" % k].get("hbm_bytes_fetch_doubled", 0.0) / alg - 1.0) if len([q for q in pmc if sub in q[0]]) > 1 else 0.0, k)
+             for k in pmc if sub in k[0]]
     if not cands: continue
     k = min(cands)[1]
     e = kern["%s grid %d" % k]
