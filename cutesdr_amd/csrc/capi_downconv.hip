@@ -15,10 +15,11 @@ struct csdr_downconvert_batch {
     int hist_stride;                       // samples per channel in each history half
     float *d_hist; int hist_cur;           // 2 x [channels][hist_stride] mixed samples
     DcChan *d_chan; int *d_list; float *d_amp;
-    // per-call NCO state and channel lists travel through pinned host memory (a ring of slots, one event each)
-    // so that a batch step only enqueues: copies from pageable memory would block the host on the stream
-    static constexpr int kSlots = 8;
-    unsigned char *h_pin; size_t slot_bytes; int slot; hipEvent_t slot_ev[kSlots]; bool slot_used[kSlots];
+    // The NCO state lives on the device (2 x [channels], ping-pong: the kernel advances it) and the channel
+    // lists change only with the plans: a process call copies nothing.  The host mirror runs the same
+    // arithmetic; after a retune or a rate change (state_dirty / lists_dirty) the next call uploads it.
+    int chan_cur; bool state_dirty, lists_dirty;
+    std::vector<int> list_off, list_len;   // per plan: offset and length of its channel list in d_list
 };
 
 static int ensure_hist(csdr_downconvert_batch *b)
@@ -70,17 +71,13 @@ csdr_downconvert_batch *csdr_downconvert_batch_create(int device, int channels)
     b->plan_of.assign(channels, 0);
     b->hist_stride = 0; b->d_hist = nullptr; b->hist_cur = 0;
     b->d_chan = nullptr; b->d_list = nullptr; b->d_amp = nullptr;
-    b->h_pin = nullptr; b->slot = 0; b->slot_bytes = (sizeof(DcChan) + sizeof(int)) * (size_t)channels;
-    for (int i = 0; i < csdr_downconvert_batch::kSlots; i++) { b->slot_ev[i] = nullptr; b->slot_used[i] = false; }
+    b->chan_cur = 0; b->state_dirty = true; b->lists_dirty = true;
     std::vector<float> amp(DC_AMP_N);
     dc_amp_table(amp.data(), DC_AMP_N);
-    bool ok = hipMalloc((void **)&b->d_chan, sizeof(DcChan) * channels) == hipSuccess &&
+    bool ok = hipMalloc((void **)&b->d_chan, sizeof(DcChan) * channels * 2) == hipSuccess &&
               hipMalloc((void **)&b->d_list, sizeof(int) * channels) == hipSuccess &&
               hipMalloc((void **)&b->d_amp, sizeof(float) * DC_AMP_N) == hipSuccess &&
-              hipHostMalloc((void **)&b->h_pin, b->slot_bytes * csdr_downconvert_batch::kSlots, hipHostMallocDefault) == hipSuccess &&
               hipMemcpy(b->d_amp, amp.data(), sizeof(float) * DC_AMP_N, hipMemcpyHostToDevice) == hipSuccess;
-    for (int i = 0; ok && i < csdr_downconvert_batch::kSlots; i++)
-        ok = hipEventCreateWithFlags(&b->slot_ev[i], hipEventDisableTiming) == hipSuccess;
     if (!ok || ensure_hist(b) != CSDR_OK) {
         fail(CSDR_ENOMEM, "device allocation failed");
         csdr_downconvert_batch_destroy(b);
@@ -97,8 +94,6 @@ void csdr_downconvert_batch_destroy(csdr_downconvert_batch *b)
     if (b->d_chan) (void)hipFree(b->d_chan);
     if (b->d_list) (void)hipFree(b->d_list);
     if (b->d_amp) (void)hipFree(b->d_amp);
-    if (b->h_pin) (void)hipHostFree(b->h_pin);
-    for (hipEvent_t e : b->slot_ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -117,6 +112,7 @@ int csdr_downconvert_batch_set_frequency(csdr_downconvert_batch *b, int channel,
 {
     DCB_CHECK(b, channel);
     DCB_FOR(b, channel, i) b->ch[i].set_frequency(freq);
+    b->state_dirty = true;               // the new increment reaches the device with the next process call
     return CSDR_OK;
 }
 
@@ -141,6 +137,7 @@ double csdr_downconvert_batch_set_data_rate(csdr_downconvert_batch *b, int chann
                 return -1.0;
             }
             c.set_frequency(c.nco_freq);                          // :169, re-adds the CW offset
+            b->state_dirty = true; b->lists_dirty = true;
         }
         out = c.out_rate;
     }
@@ -200,24 +197,34 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
                 return fail(CSDR_EINVAL, "n_per_channel (%d) must be a multiple of 2^%d for channel %d "
                             "(reference: InLength must be a multiple of 2^stages, downconvert.cpp:181-183)",
                             n_per_channel, b->plans[pi].nstages, i);
-    // NCO state of every channel at the start of this call, in the next pinned slot (wait only if the copy
-    // that last used this slot, kSlots calls ago, has not been consumed yet)
-    const int slot = b->slot;
-    b->slot = (b->slot + 1) % csdr_downconvert_batch::kSlots;
-    if (b->slot_used[slot]) CSDR_HIP(hipEventSynchronize(b->slot_ev[slot]));
-    DcChan *hc = reinterpret_cast<DcChan *>(b->h_pin + (size_t)slot * b->slot_bytes);
-    int *all_lists = reinterpret_cast<int *>(hc + b->channels);
-    for (int i = 0; i < b->channels; i++) { hc[i].phase = b->ch[i].phase; hc[i].inc = b->ch[i].inc; hc[i].age = b->ch[i].age; }
-    CSDR_HIP(hipMemcpyAsync(b->d_chan, hc, sizeof(DcChan) * b->channels, hipMemcpyHostToDevice, s));
+    // after a retune / rate change: the host mirror's state and the channel lists go to the device once
+    // (setters synchronise: nothing of this handle may still be running on the old values)
+    if (b->state_dirty || b->lists_dirty) {
+        CSDR_HIP(hipDeviceSynchronize());
+        if (b->state_dirty) {
+            std::vector<DcChan> hc(b->channels);
+            for (int i = 0; i < b->channels; i++) { hc[i].phase = b->ch[i].phase; hc[i].inc = b->ch[i].inc; hc[i].age = b->ch[i].age; }
+            CSDR_HIP(hipMemcpy(b->d_chan + (size_t)b->chan_cur * b->channels, hc.data(), sizeof(DcChan) * b->channels,
+                               hipMemcpyHostToDevice));
+            b->state_dirty = false;
+        }
+        if (b->lists_dirty) {
+            std::vector<int> all(b->channels);
+            b->list_off.assign(b->plans.size(), 0); b->list_len.assign(b->plans.size(), 0);
+            size_t off = 0;
+            for (size_t pi = 0; pi < b->plans.size(); pi++) {
+                b->list_off[pi] = (int)off;
+                for (int i = 0; i < b->channels; i++) if (b->plan_of[i] == (int)pi) all[off++] = i;
+                b->list_len[pi] = (int)off - b->list_off[pi];
+            }
+            CSDR_HIP(hipMemcpy(b->d_list, all.data(), sizeof(int) * b->channels, hipMemcpyHostToDevice));
+            b->lists_dirty = false;
+        }
+    }
     const size_t half = (size_t)b->channels * b->hist_stride * 2;
-    std::vector<int> list;
-    size_t list_off = 0;
     std::vector<DcArgs> launches;
     for (size_t pi = 0; pi < b->plans.size(); pi++) {
-        list.clear();
-        for (int i = 0; i < b->channels; i++) if (b->plan_of[i] == (int)pi) list.push_back(i);
-        if (list.empty()) continue;
-        memcpy(all_lists + list_off, list.data(), list.size() * sizeof(int));
+        if (b->list_len[pi] == 0) continue;
         const DcPlan &p = b->plans[pi];
         DcArgs a;
         memset(&a, 0, sizeof(a));
@@ -226,8 +233,10 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         a.hist = (const dc_v2f *)(b->d_hist + b->hist_cur * half);
         a.hist_next = (dc_v2f *)(b->d_hist + (b->hist_cur ^ 1) * half);
         a.hist_stride = b->hist_stride;
-        a.chan = b->d_chan; a.chan_list = b->d_list + list_off; a.amp = b->d_amp; a.in_rows = d_in_rows;
-        a.nchan = (int)list.size(); a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
+        a.chan = b->d_chan + (size_t)b->chan_cur * b->channels;
+        a.chan_next = b->d_chan + (size_t)(b->chan_cur ^ 1) * b->channels;
+        a.chan_list = b->d_list + b->list_off[pi]; a.amp = b->d_amp; a.in_rows = d_in_rows;
+        a.nchan = b->list_len[pi]; a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
         for (int q = 0; q < p.nstages; q++) { a.st[q] = p.st[q]; a.kind[q] = p.kind[q]; }
         // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long
         long min_seg = (long)DC_TILE_SAMPLES * 8;
@@ -239,18 +248,15 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         seg_len = (seg_len + DC_TILE_SAMPLES - 1) / DC_TILE_SAMPLES * DC_TILE_SAMPLES;
         a.seg_len = (int)seg_len;
         a.nseg = (int)((n_per_channel + seg_len - 1) / seg_len);
-        list_off += list.size();
         launches.push_back(a);
     }
-    CSDR_HIP(hipMemcpyAsync(b->d_list, all_lists, sizeof(int) * b->channels, hipMemcpyHostToDevice, s));
-    CSDR_HIP(hipEventRecord(b->slot_ev[slot], s));
-    b->slot_used[slot] = true;
     // a call shorter than a channel's warm-up keeps part of the old history: every row of the
     // next history half is fully rewritten by the kernel (tail copy + new samples)
     for (auto &la : launches) CSDR_HIP(downconv_launch(la, s));
     b->hist_cur ^= 1;
+    b->chan_cur ^= 1;                                   // the kernels left the advanced NCO state in the other half
     for (int i = 0; i < b->channels; i++) {
-        b->ch[i].phase += hc[i].inc * (unsigned long long)n_per_channel;   // the increment the kernel was given
+        b->ch[i].phase += b->ch[i].inc * (unsigned long long)n_per_channel;   // the mirror runs the same arithmetic
         b->ch[i].age += (unsigned long long)n_per_channel;
     }
     return CSDR_OK;

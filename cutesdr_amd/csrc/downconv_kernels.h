@@ -33,7 +33,9 @@ struct DcArgs {
     dc_v2f *out;       long out_stride;      // [channels][out_stride], n_in >> nstages valid
     const dc_v2f *hist; dc_v2f *hist_next;   // [channels][hist_stride], first W valid: mixed samples, ping-pong
     long hist_stride;
-    const DcChan *chan;                      // [channels]
+    const DcChan *chan;                      // [channels] NCO state at the start of the call
+    DcChan *chan_next;                       // [channels] state after it, written by segment 0 of every channel
+                                             // (ping-pong like the history: no workgroup reads what another writes)
     const int *chan_list;                    // optional [nchan] channel ids of this launch
     const int *in_rows;                      // optional [channels]: input row of each channel id
     const float *amp;                        // [DC_AMP_N] amplitude envelope a_n

@@ -327,6 +327,15 @@ void downconv_kernel(DcArgs a)
         printf("dcprof t%d: mix %llu bar %llu stages %llu bar %llu hist %llu out %llu bar %llu\n", t, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
     if (wg == 0 && (t == 0 || t == 256)) printf("dcstages t%d: %llu %llu %llu %llu %llu %llu\n", t, tk[8], tk[9], tk[10], tk[11], tk[12], tk[13]);
 #endif
+    // the NCO runs on: phase and age after this call's n_in samples (the host keeps the same arithmetic in its
+    // mirror, so a retune uploads a consistent state)
+    if (seg == 0 && t == 0) {
+        DcChan nx;
+        nx.phase = cs.phase + cs.inc * (unsigned long long)a.n_in;
+        nx.inc = cs.inc;
+        nx.age = cs.age + (unsigned long long)a.n_in;
+        a.chan_next[ch] = nx;
+    }
     // calls shorter than the warm-up length keep the tail of the old history in front
     if (seg == a.nseg - 1 && a.n_in < a.W)
         for (int j = t; j < a.W - a.n_in; j += DC_T) hist_next[j] = hist[j + a.n_in];

@@ -657,6 +657,11 @@ void postchain_kernel(PcArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
     PcLds &S = *reinterpret_cast<PcLds *>(pc_smem);
     const int ch = blockIdx.x, t = threadIdx.x;
+    // A channel's bursts are a sequential walk: this kernel is bound by its own latency, not by throughput, and
+    // in the batch chain it shares CUs with the down-converter of other groups / the next call, whose 12-16 waves
+    // per CU would otherwise take most issue slots.  Highest issue priority for these few waves costs the
+    // streaming kernel next to nothing and keeps the walk at the speed it has alone.
+    __builtin_amdgcn_s_setprio(3);
     const G g{t, t & 63, t >> 6, &S};
     PcChannel &C = a.chan[ch];
     float *g_dly = a.agc_dly + (long)ch * PC_AGC_RING * 2;      // linear: last dly_n inputs, oldest first
