@@ -21,7 +21,9 @@ struct csdr_fastfir_batch {
     int cus;                          // compute units of the device (run-length heuristic)
     hipStream_t last_stream;          // stream of the most recent process call (setup waits for it)
     bool per_channel;                 // false: one shared filter
-    float *d_h;                       // [filters][n] complex fp32 in pass-F3 register order
+    float *d_h;                       // [filters][n] complex fp32 in pass-F3 register order of the generic kernel
+    float *d_h2;                      // N = 16384: the same responses in the pipelined kernel's order (it consumes H as
+                                      // its tail groups finish bins); both are kept, a launch may go to either kernel
     float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
     int hist_cur;                     // which half holds the previous call's tail
     int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
@@ -29,7 +31,7 @@ struct csdr_fastfir_batch {
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
-    std::vector<int> perm;            // device slot -> natural bin
+    std::vector<int> perm, perm2;     // device slot -> natural bin, generic / pipelined kernel
 };
 
 static void build_perm(csdr_fastfir_batch *b)
@@ -41,18 +43,29 @@ static void build_perm(csdr_fastfir_batch *b)
         for (int t = 0; t < T; t++)
             for (int e = 0; e < 2; e++)
                 b->perm[(j * T + t) * 2 + e] = fastfir_bin_of(b->log2n, t, 2 * j + e);
+    b->perm2.clear();
+    if (b->n == 16384) {
+        b->perm2.resize(b->n);
+        for (int j = 0; j < 16; j++)
+            for (int t = 0; t < T; t++)
+                for (int e = 0; e < 2; e++) b->perm2[(j * T + t) * 2 + e] = fastfir2_bin_of(t, j, e);
+    }
 }
 
 static int upload_response(csdr_fastfir_batch *b, int slot, const std::vector<cd> &H)
 {
     std::vector<float> dev(2 * (size_t)b->n);
-    for (int i = 0; i < b->n; i++) {
-        const cd v = H[b->perm[i]];
-        dev[2 * i] = (float)v.real();
-        dev[2 * i + 1] = (float)v.imag();
+    for (int pass = 0; pass < 2; pass++) {
+        const std::vector<int> &perm = pass ? b->perm2 : b->perm;
+        float *dst = pass ? b->d_h2 : b->d_h;
+        if (perm.empty() || !dst) continue;
+        for (int i = 0; i < b->n; i++) {
+            const cd v = H[perm[i]];
+            dev[2 * i] = (float)v.real();
+            dev[2 * i + 1] = (float)v.imag();
+        }
+        CSDR_HIP(hipMemcpy(dst + (size_t)slot * 2 * b->n, dev.data(), dev.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    CSDR_HIP(hipMemcpy(b->d_h + (size_t)slot * 2 * b->n, dev.data(), dev.size() * sizeof(float),
-                       hipMemcpyHostToDevice));
     return CSDR_OK;
 }
 
@@ -81,7 +94,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
         const char *v = getenv("CSDR_FASTFIR_VARIANT");
         b->variant = (fft_size == 16384 && !(v && atoi(v) == 0)) ? 2 : 0;
     }
-    b->d_h = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
+    b->d_h = b->d_h2 = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
     build_perm(b);
     const size_t hbytes = (size_t)fft_size * 8, histbytes = 2 * (size_t)channels * (fft_size / 2) * 8;
@@ -96,6 +109,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
             tw2[2 * (k * 32 + i)] = (float)std::cos(a); tw2[2 * (k * 32 + i) + 1] = (float)std::sin(a);
         }
     bool ok = hipMalloc((void **)&b->d_h, hbytes) == hipSuccess &&
+              (fft_size != 16384 || (hipMalloc((void **)&b->d_h2, hbytes) == hipSuccess && hipMemset(b->d_h2, 0, hbytes) == hipSuccess)) &&
               hipMalloc((void **)&b->d_hist, histbytes) == hipSuccess &&
               hipMalloc((void **)&b->d_tw1, 8192) == hipSuccess &&
               hipMalloc((void **)&b->d_tw2, 8192) == hipSuccess &&
@@ -117,6 +131,7 @@ void csdr_fastfir_batch_destroy(csdr_fastfir_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->d_h) (void)hipFree(b->d_h);
+    if (b->d_h2) (void)hipFree(b->d_h2);
     if (b->d_hist) (void)hipFree(b->d_hist);
     if (b->d_tw1) (void)hipFree(b->d_tw1);
     if (b->d_tw2) (void)hipFree(b->d_tw2);
@@ -148,6 +163,14 @@ int csdr_fastfir_batch_setup(csdr_fastfir_batch *b, int channel, double flo, dou
             CSDR_HIP(hipMemcpy((char *)nh + one * c, b->d_h, one, hipMemcpyDeviceToDevice));
         CSDR_HIP(hipFree(b->d_h));
         b->d_h = nh;
+        if (b->d_h2) {
+            float *nh2 = nullptr;
+            CSDR_HIP(hipMalloc((void **)&nh2, one * b->channels));
+            for (int c = 0; c < b->channels; c++)
+                CSDR_HIP(hipMemcpy((char *)nh2 + one * c, b->d_h2, one, hipMemcpyDeviceToDevice));
+            CSDR_HIP(hipFree(b->d_h2));
+            b->d_h2 = nh2;
+        }
         b->resp.resize(b->channels, b->resp[0]);
         b->per_channel = true;
     }
@@ -230,8 +253,10 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.blocks_per_run = blocks_per_wg;
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
     a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
-    if (b->variant >= 2 && (a.blocks_per_run & 1) == 0 && (a.nblocks % a.blocks_per_run & 1) == 0)
+    if (b->variant >= 2 && (a.blocks_per_run & 1) == 0 && (a.nblocks % a.blocks_per_run & 1) == 0) {
+        a.h = (const v4f_h *)b->d_h2;         // its own H order
         CSDR_HIP(fastfir2_launch(a, s));     // walks its blocks in pairs
+    }
     else CSDR_HIP(fastfir_launch(b->log2n, a, s));
     b->hist_cur ^= 1;        // the kernel left this call's tail in the other half
     return CSDR_OK;
@@ -242,11 +267,6 @@ int csdr__fastfir_set_variant(csdr_fastfir_batch *b, int variant)
 {
     if (!b || (variant != 0 && variant != 2) || (variant && b->n != 16384)) return CSDR_EINVAL;
     b->variant = variant;
-    build_perm(b);
-    for (size_t i = 0; i < b->resp.size(); i++) {
-        int rc = upload_response(b, (int)i, b->resp[i]);
-        if (rc) return rc;
-    }
     return CSDR_OK;
 }
 

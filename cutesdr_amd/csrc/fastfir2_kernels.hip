@@ -137,17 +137,19 @@ void fastfir_os2_kernel(FastFirArgs a)
 #endif
     // one block: [oldh | newh] in, the valid half out; block b+1's new half is left in oldh
     auto one_block = [&](const int b, v2f (&oldh)[16], v2f (&newh)[16]) {
-        // ================= F1: radix-16 DIF on [oldh | newh], twiddle, scatter to LDS =================
+        // ================= F1: radix-16 forward transform of [oldh | newh], twiddle, scatter to LDS =================
+        // (a decimation-in-time network like every transform of this kernel -- FMA butterflies; its
+        // bit-reversed input order costs nothing, the samples sit in registers: position bitrev(n1) <- row n1)
         CSDR_SB();
         CSDR_PRIO(1);
         {
             v2f y0[R0], y1[R0];
-#pragma unroll
-            for (int n1 = 0; n1 < HALF; n1++) {
-                y0[n1] = oldh[n1];        y0[HALF + n1] = newh[n1];
-                y1[n1] = oldh[HALF + n1]; y1[HALF + n1] = newh[HALF + n1];
-            }
-            static_for<0, R0 / 4>([&](auto I) { dif_head<I.value, R0, +1>(y0); dif_head<I.value, R0, +1>(y1); });
+            static_for<0, HALF>([&](auto N1) {
+                constexpr int n1 = N1.value, po = bitrev<R0>(n1), pn = bitrev<R0>(HALF + n1);
+                y0[po] = oldh[n1];        y0[pn] = newh[n1];
+                y1[po] = oldh[HALF + n1]; y1[pn] = newh[HALF + n1];
+            });
+            static_for<0, R0 / 4>([&](auto Gg) { dit_head4<Gg.value, R0, +1>(y0); dit_head4<Gg.value, R0, +1>(y1); });
             CSDR_SB();
             // block b+1's new half: into the registers of the old half, which the butterflies above have read
             // (unconditional, so that the block stays one straight line of code: after the last block of the
@@ -156,25 +158,25 @@ void fastfir_os2_kernel(FastFirArgs a)
             CSDR_SB();
             CSDR_PRIO(0);
             v4f wv[R0];
-            static_for<0, R0 / 4 + 1>([&](auto Gg) {
-                constexpr int g = Gg.value;
-                if constexpr (g < R0 / 4) {
-                    dif_tail4<g, R0, +1>(y0);
-                    dif_tail4<g, R0, +1>(y1);
-                    static_for<4 * g, 4 * g + 4>([&](auto Rr) {
-                        constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+            static_for<0, R0 / 4 + 1>([&](auto Ii) {
+                constexpr int i = Ii.value;                // tail group i finishes rows k0 = i, i+4, i+8, i+12
+                if constexpr (i < R0 / 4) {
+                    dit_tail<i, R0, +1>(y0);
+                    dit_tail<i, R0, +1>(y1);
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int k0 = i + 4 * P.value;
                         if constexpr (k0 != 0) {
-                            y0[r] = cmul(y0[r], pw[0][k0]);
-                            y1[r] = cmul(y1[r], pw[1][k0]);
+                            y0[k0] = cmul(y0[k0], pw[0][k0]);
+                            y1[k0] = cmul(y1[k0], pw[1][k0]);
                         }
-                        wv[r] = store_operand(y0[r], y1[r]);
+                        wv[k0] = store_operand(y0[k0], y1[k0]);
                     });
                 }
-                if constexpr (g > 0) {                 // rows of the previous group: written while this one computes
+                if constexpr (i > 0) {                 // rows of the previous group: written while this one computes
                     CSDR_STORE_GROUP_BEGIN();
-                    static_for<4 * (g - 1), 4 * g>([&](auto Rr) {
-                        constexpr int r = Rr.value, k0 = bitrev<R0>(r);
-                        *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0) = wv[r];
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int k0 = (i - 1) + 4 * P.value;
+                        *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0) = wv[k0];
                     });
                     CSDR_STORE_GROUP_END();
                 } else {
@@ -186,55 +188,52 @@ void fastfir_os2_kernel(FastFirArgs a)
         __syncthreads();
         CSDR_STAMP(1);                                 // barrier after F1
 
-        // ================= F2: radix-32 DIF inside sub-transform sb, column sn =================
+        // ================= F2: radix-32 forward inside sub-transform sb, column sn =================
         CSDR_PRIO(3);
         v4f hv[16];
         {
-            // the four points of head group i; three groups ahead of the butterflies (lgkmcnt counts to 15)
-            auto fetch = [&](auto I) {
-                constexpr int i = I.value;
-                x[i] = lds_ld8(col + 34 * i);
-                x[i + 8] = lds_ld8(col + 34 * (i + 8));
-                x[i + 16] = lds_ld8(col + 34 * (i + 16));
-                x[i + 24] = lds_ld8(col + 34 * (i + 24));
+            // the four points of head group g (network positions 4g..4g+3 <- rows bitrev(4g+q)); three groups
+            // ahead of the butterflies (lgkmcnt counts to 15)
+            auto fetch = [&](auto Gg) {
+                static_for<0, 4>([&](auto Q) {
+                    constexpr int p = 4 * Gg.value + Q.value;
+                    x[p] = lds_ld8(col + 34 * bitrev<32>(p));
+                });
             };
             static_for<0, 3>(fetch);
             CSDR_SB();
-            static_for<0, 8>([&](auto I) {
-                if constexpr (I.value + 3 < 8) fetch(std::integral_constant<int, I.value + 3>{});
-                dif_head<I.value, 32, +1>(x);
+            static_for<0, 8>([&](auto Gg) {
+                if constexpr (Gg.value + 3 < 8) fetch(std::integral_constant<int, Gg.value + 3>{});
+                dit_head4<Gg.value, 32, +1>(x);
                 CSDR_SB();
             });
             CSDR_STAMP(7);                             // F2 heads
-            dif_single<8, 32, +1>(x);
+            dit_single<8, 32, +1>(x);
             CSDR_SB();
-            // H[k] comes from L2, two loads per tail group below (a burst of sixteen held the wave for ~500
-            // cycles of issue alone); in flight from there to the multiply in F3
+            // tail group i finishes k1 = i, i+8, i+16, i+24: twiddle, store (one group behind).  H[k] comes from
+            // L2, two loads per tail group (a burst of sixteen held the wave for ~500 cycles of issue alone), in
+            // flight from here to the multiply in F3
             v2f tw[2][4];
-            static_for<1, 4>([&](auto Rr) { tw[0][Rr.value] = lds_ld8(twc + 32 * bitrev<32>(Rr.value)); });
+            static_for<1, 4>([&](auto P) { tw[0][P.value] = lds_ld8(twc + 32 * (8 * P.value)); });
             CSDR_SB();
-            CSDR_STAMP(8);                             // F2 middle stage, H loads issued
-            static_for<0, 9>([&](auto Gg) {
-                constexpr int g = Gg.value;
-                if constexpr (g < 7)                   // twiddles of the next group
-                    static_for<0, 4>([&](auto Q) {
-                        tw[(g + 1) & 1][Q.value] = lds_ld8(twc + 32 * bitrev<32>(4 * (g + 1) + Q.value));
-                    });
-                if constexpr (g < 8) {
-                    hv[2 * g] = buf_load16(r_h, t * 16, (2 * g) * (T * 16));
-                    hv[2 * g + 1] = buf_load16(r_h, t * 16, (2 * g + 1) * (T * 16));
-                }
-                if constexpr (g < 8) {
-                    dif_tail4<g, 32, +1>(x);
-                    static_for<0, 4>([&](auto Q) {
-                        constexpr int r = 4 * g + Q.value;
-                        if constexpr (r != 0) x[r] = cmul(x[r], tw[g & 1][Q.value]);
+            CSDR_STAMP(8);                             // F2 middle stage
+            static_for<0, 9>([&](auto Ii) {
+                constexpr int i = Ii.value;
+                if constexpr (i < 7)                   // twiddles of the next group
+                    static_for<0, 4>([&](auto P) { tw[(i + 1) & 1][P.value] = lds_ld8(twc + 32 * (i + 1 + 8 * P.value)); });
+                if constexpr (i < 8) {
+                    hv[2 * i] = buf_load16(r_h, t * 16, (2 * i) * (T * 16));
+                    hv[2 * i + 1] = buf_load16(r_h, t * 16, (2 * i + 1) * (T * 16));
+                    dit_tail<i, 32, +1>(x);
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int k1 = i + 8 * P.value;
+                        if constexpr (k1 != 0) x[k1] = cmul(x[k1], tw[i & 1][P.value]);
                     });
                 }
-                if constexpr (g > 0)
-                    static_for<4 * (g - 1), 4 * g>([&](auto Rr) {
-                        constexpr int r = Rr.value;
-                        lds_st8(col + 34 * bitrev<32>(r), x[r]);
+                if constexpr (i > 0)
+                    static_for<0, 4>([&](auto P) {
+                        constexpr int k1 = (i - 1) + 8 * P.value;
+                        lds_st8(col + 34 * k1, x[k1]);
                     });
                 CSDR_SB();
             });
@@ -248,32 +247,40 @@ void fastfir_os2_kernel(FastFirArgs a)
         // ================= F3 + H + I1: points 32t..32t+31, registers only =================
         CSDR_PRIO(2);
         {
-            // rows q, q+4, q+8, q+12 of 16-byte pairs feed head groups 2q and 2q+1
+            // forward: network position p <- point m2 = bitrev(p).  Rows q, q+4, q+8, q+12 of 16-byte pairs hold
+            // the points {2q, 2q+1} + 8 {0,1,2,3}: exactly the inputs of head groups bitrev3(2q) and bitrev3(2q+1)
+            v2f y[32];
             static_for<0, 4>([&](auto Q) {
                 static_for<0, 4>([&](auto P) {
                     constexpr int j = Q.value + 4 * P.value;
                     const v4f v = *reinterpret_cast<const v4f *>(rowp + 2 * j);
-                    x[2 * j] = v2f{v.x, v.y};
-                    x[2 * j + 1] = v2f{v.z, v.w};
+                    x[bitrev<32>(2 * j)] = v2f{v.x, v.y};
+                    x[bitrev<32>(2 * j + 1)] = v2f{v.z, v.w};
                 });
             });
             CSDR_SB();
-            static_for<0, 8>([&](auto I) {
-                dif_head<I.value, 32, +1>(x);
-                if constexpr ((I.value & 1) == 1) CSDR_SB();
+            static_for<0, 4>([&](auto Q) {
+                dit_head4<bitrev<8>(2 * Q.value), 32, +1>(x);
+                dit_head4<bitrev<8>(2 * Q.value + 1), 32, +1>(x);
+                CSDR_SB();
             });
-            dif_single<8, 32, +1>(x);
+            dit_single<8, 32, +1>(x);
             CSDR_SB();
-            static_for<0, 8>([&](auto Gg) {
-                constexpr int g = Gg.value;
-                dif_tail4<g, 32, +1>(x);
-                x[4 * g] = cmul(x[4 * g], v2f{hv[2 * g].x, hv[2 * g].y});
-                x[4 * g + 1] = cmul(x[4 * g + 1], v2f{hv[2 * g].z, hv[2 * g].w});
-                x[4 * g + 2] = cmul(x[4 * g + 2], v2f{hv[2 * g + 1].x, hv[2 * g + 1].y});
-                x[4 * g + 3] = cmul(x[4 * g + 3], v2f{hv[2 * g + 1].z, hv[2 * g + 1].w});
-                dit_head4<g, 32, -1>(x);
-                if constexpr ((g & 1) == 1) CSDR_SB();
+            // tail group i finishes the bins k2 = i, i+8, i+16, i+24 -- the four inputs (network positions
+            // 4g..4g+3, g = bitrev3(i), position 4g + 2 q1 + q0 <- k2 = i + 8 q1 + 16 q0) of the inverse's head
+            // group g: multiply by H and go straight on
+            static_for<0, 8>([&](auto Ii) {
+                constexpr int i = Ii.value, g = bitrev<8>(i);
+                dit_tail<i, 32, +1>(x);
+                y[4 * g] = cmul(x[i], v2f{hv[2 * i].x, hv[2 * i].y});
+                y[4 * g + 1] = cmul(x[i + 16], v2f{hv[2 * i].z, hv[2 * i].w});
+                y[4 * g + 2] = cmul(x[i + 8], v2f{hv[2 * i + 1].x, hv[2 * i + 1].y});
+                y[4 * g + 3] = cmul(x[i + 24], v2f{hv[2 * i + 1].z, hv[2 * i + 1].w});
+                dit_head4<g, 32, -1>(y);
+                if constexpr ((i & 1) == 1) CSDR_SB();
             });
+#pragma unroll
+            for (int i = 0; i < 32; i++) x[i] = y[i];
             CSDR_PRIO(1);
             dit_single<8, 32, -1>(x);
             CSDR_SB();
@@ -424,6 +431,16 @@ hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((fastfir_os2_kernel<14>), dim3(a.channels * a.runs), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
+}
+
+// Host mirror of the kernel's index algebra: thread t of pass F3 owns k0 = t >> 5 (sub-transform) and k1 = t & 31
+// (its row), and consumes H in the order its tail groups finish bins: float4 j = 2 i + h of thread t, half e,
+// multiplies k2 = i + 8 h + 16 e; natural bin k = k0 + 16 (k1 + 32 k2).
+int fastfir2_bin_of(int t, int j, int e)
+{
+    const int i = j >> 1, h = j & 1;
+    const int k2 = i + 8 * h + 16 * e;
+    return (t >> 5) + 16 * ((t & 31) + 32 * k2);
 }
 
 }  // namespace csdr

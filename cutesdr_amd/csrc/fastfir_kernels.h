@@ -31,5 +31,7 @@ int fastfir_bin_of(int log2n, int t, int r);
 
 // software-pipelined build for N = 16384 (fastfir2_kernels.hip): same LDS image and H order as fastfir_launch
 hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream);
+// natural-order spectrum bin of H slot (float4 index j*512 + t, half e) of that kernel
+int fastfir2_bin_of(int t, int j, int e);
 
 }  // namespace csdr
