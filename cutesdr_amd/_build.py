@@ -18,7 +18,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-
     os.environ.get("CSDR_EXTRA_HIPCC_FLAGS", "").split()
 # per-source additions: the overlap-save kernel is a long straight-line butterfly chain with two waves
 # per SIMD; LLVM's "max-ILP" machine scheduler orders it ~4 % faster than the default (measured A/B)
-FILE_FLAGS = {"fastfir2_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "fastfir_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+FILE_FLAGS = {"fastfir2_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("CSDR_K1_FLAGS", "").split(), "fastfir_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "spectrum_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}   # K3: +4 %; K2/K4 measured slower with it
 
 

@@ -205,7 +205,7 @@ void fastfir_os2_kernel(FastFirArgs a)
             static_for<0, 8>([&](auto Gg) {
                 if constexpr (Gg.value + 3 < 8) fetch(std::integral_constant<int, Gg.value + 3>{});
                 dit_head4<Gg.value, 32, +1>(x);
-                CSDR_SB();
+                if constexpr ((Gg.value & 1) == 1) CSDR_SB();
             });
             CSDR_STAMP(7);                             // F2 heads
             dit_single<8, 32, +1>(x);
@@ -333,7 +333,7 @@ void fastfir_os2_kernel(FastFirArgs a)
                 constexpr int g = Gg.value;
                 if constexpr (g + 2 < 8) fetch(std::integral_constant<int, g + 2>{});
                 dit_head4_conjtw<g, 32, -1, g == 0>(x, tw[4 * g], tw[4 * g + 1], tw[4 * g + 2], tw[4 * g + 3]);
-                CSDR_SB();
+                if constexpr ((g & 1) == 1) CSDR_SB();
             });
             dit_single<8, 32, -1>(x);
             CSDR_SB();
