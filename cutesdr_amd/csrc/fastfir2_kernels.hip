@@ -18,6 +18,7 @@
 // The outer-pass twiddle powers are computed once per block (pass I3) and reused by pass F1 of the
 // next block.
 #define CSDR_FMA_BFLY 1          // FMA-form decimation-in-time butterflies (fft_core.hpp)
+#define CSDR_PLAIN_CONST_FMA 1   // ... written without asm where the twiddle is a compile-time constant
 #include "fastfir_dev.hpp"
 #include "fastfir_kernels.h"
 

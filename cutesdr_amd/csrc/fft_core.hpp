@@ -177,6 +177,15 @@ __host__ __device__ __forceinline__ void bfly_dit(v2f &xa, v2f &xb)
         // (K = 4, 12 included: c = +-s = sqrt(1/2) needs no special case in this form)
         constexpr float c = kCos32[K];
         constexpr float s = (SIGN > 0 ? 1.0f : -1.0f) * kCos32[(K + 24) & 31];
+#ifdef CSDR_PLAIN_CONST_FMA
+        // experiment: no asm, both constant vectors as literals
+        const v2f w1 = {c, s}, w2 = {-s, c};
+        const v2f t = __builtin_elementwise_fma(xb.xx, w1, u);
+        const v2f a = __builtin_elementwise_fma(xb.yy, w2, t);
+        xb = u * 2.0f - a;
+        xa = a;
+        return;
+#else
         v2f t, a;
         const v2f w = {c, s};
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(xb), "s"(w), "v"(u));
@@ -184,6 +193,7 @@ __host__ __device__ __forceinline__ void bfly_dit(v2f &xa, v2f &xb)
         xb = u * 2.0f - a;
         xa = a;
         return;
+#endif
     }
 #endif
     if constexpr (K == 0) {
