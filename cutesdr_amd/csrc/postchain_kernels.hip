@@ -648,8 +648,11 @@ __device__ __forceinline__ void sliding_max(const Wg<NW> &g, PcLds &S, int W1, i
     g.sync();
 }
 
+#ifndef CSDR_PC_WAVES_PER_EU
+#define CSDR_PC_WAVES_PER_EU 1
+#endif
 template <int NW>
-__global__ __launch_bounds__(64 * NW)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? CSDR_PC_WAVES_PER_EU : 1)))
 void postchain_kernel(PcArgs a)
 {
     using G = Wg<NW>;
