@@ -361,12 +361,11 @@ int downconv_layout(DcArgs &a)
 hipError_t downconv_launch(DcArgs &a, hipStream_t stream)
 {
     const int lds = downconv_layout(a);
-    static int attr_bytes = 0;
-    if (lds > attr_bytes) {
+    // per launch: the attribute belongs to the current device, and a process may drive several
+    if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_bytes = lds;
     }
     hipLaunchKernelGGL(downconv_kernel, dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
     return hipGetLastError();

@@ -1080,12 +1080,11 @@ hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows,
 template <int NW>
 static hipError_t pc_launch_nw(const PcArgs &a, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // per launch: the attribute belongs to the current device, and a process may drive several
+    if (sizeof(PcLds) > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&postchain_kernel<NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PcLds));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(postchain_kernel<NW>, dim3(a.channels), dim3(64 * NW), sizeof(PcLds), stream, a);
     return hipGetLastError();
