@@ -54,6 +54,9 @@ static int find_plan(csdr_downconvert_batch *b, double in_rate, double max_bw)
     return (int)b->plans.size() - 1;
 }
 
+/* internal (tests): 1 = every down-converter launch takes the run-time-plan kernel, 0 = precompiled plans where
+ * they exist, -1 = query only; returns the number of precompiled plans in the library */
+extern "C" int csdr__downconv_force_dynamic(int on) { return downconv_force_dynamic(on); }
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
                                                     long long out_stride, void *stream, const void *d_packets, int pkt_len);

@@ -47,5 +47,6 @@ struct DcArgs {
 };
 
 hipError_t downconv_launch(DcArgs &a, hipStream_t stream);
+int downconv_force_dynamic(int on);     // tests: 1 = always the run-time-plan kernel, -1 = query; returns #precompiled plans
 
 }  // namespace csdr

@@ -1,373 +1,63 @@
-// downconv_kernels.hip -- NCO mixer + decimate-by-2^n cascade for gfx950 (K2 in DESIGN.md).
-//
-// Replaces CDownConvert::ProcessData (reference dsp/downconvert.cpp:186-263): the gain-stabilised
-// rotating-phasor NCO (:210-216) and the chain of CIC-3 (:444-460), fixed 11-tap (:348-423) and
-// generic 15..51-tap (:286-320) half-band decimators picked by SetDataRate (:114-173), batched
-// over many channels and fused into ONE pass over HBM: 8 B read per input sample, 8 B written
-// per output sample, every intermediate rate lives in LDS.
-//
-// Every stage is the FIR  y[j] = sum_k h[k] xe[2j+k],  xe = [stage history | stage input]
-// (SURVEY App. A.3), so the cascade is a pure feed-forward function of the mixed input stream
-// and can be cut anywhere: a workgroup owns one segment of one channel, rebuilds the stage
-// histories by running the W >= sum_s (L_s-1) 2^s samples in front of its segment through the
-// cascade (outputs discarded), then walks its segment tile by tile with the histories carried
-// in LDS.  Segment 0 warms up from the W mixed samples the previous call left behind.
-//
-// NCO: the reference phasor is e^{j(phi0+(n+1)delta)} times the amplitude a_n of the recurrence
-// a_{n+1} = a_n (1.95 - a_n^2), a_0 = 1 (-> sqrt(0.95)).  Here the phase is a 64-bit fixed-point
-// accumulator (exact per-sample phase, no drift), re-anchored with an accurate sincospi every
-// 16 rows and advanced by one complex multiply per row in between; a_n comes from a 512-entry
-// table for a channel's first samples and is constant afterwards.
-#include "fft_core.hpp"
-#include "downconv_kernels.h"
+// downconv_kernels.hip -- launch side of the NCO + decimator cascade (K2): the LDS layout, the run-time-plan
+// instantiation of the kernel and the table of the precompiled plans (downconv_kernel.hpp holds the device code).
+#include "downconv_kernel.hpp"
 
 namespace csdr {
 
-constexpr int DC_T = 64;                  // threads per workgroup
-constexpr int DC_ROW = 2 * DC_T;           // samples per row (16 B per lane)
-constexpr int DC_TILE = 512;              // input samples per tile
-constexpr int DC_ANCHOR_ROWS = 16;
-
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would make
-// every barrier of the cascade wait for the global loads prefetched for the next tile.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// e^{j * 2*pi * phase/2^64}
-__device__ __forceinline__ v2f phasor_of(unsigned long long phase)
-{
-    const float halfturns = (float)((int)(phase >> 32)) * 4.6566128730773926e-10f;   // 2^-31
-    float s, c;
-    sincospif(halfturns, &s, &c);
-    return v2f{c, s};
-}
-
-// One decimate-by-2 stage with the tap geometry fixed at compile time: L = 3 is the CIC-3
-// (downconvert.cpp:444-460), otherwise an L-tap half band whose non-zero taps are the even ones
-// (symmetric pairs 2q / L-1-2q) and the centre (downconvert.cpp:286-320, 348-423).  The pair
-// coefficients are wave-uniform and stay in scalar registers.
-//
-// The stage input xe = [history | input] is kept split by sample parity, E[m] = xe[2m] and
-// O[m] = xe[2m+1], so that output j reads E[j+q] / O[j+q]: consecutive lanes touch consecutive
-// LDS words (the interleaved layout made every tap read a 16-byte-stride access).  Outputs go to
-// the next stage's halves (its history is even, so output j has parity j&1) or, after the last
-// stage, to the linear tile-output region.
-// per-stage parameters, staged in LDS once per workgroup: the tap values are read from there (wide
-// uniform reads), the layout words sit packed in two registers with stage s in lane s (v_readlane)
-enum { DP_KIND = 0, DP_HIST2, DP_ROFF, DP_OOFF, DP_CC, DP_C0 = 8, DP_WORDS = 24 };   // rows of 96 B, taps 16-B aligned
-
-template <int L>
-__device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2f *yO, v2f *ylin, int nout,
-                                         const int *prm, int t)
-{
-    constexpr int NP = (L == 3) ? 2 : (L + 1) / 4;
-    constexpr int H = (L - 1) / 2;              // centre tap (odd index for every L = 4k+3)
-    constexpr int UN = 1;                       // outputs per thread and pass: all reads before any write
-    float c[NP];
-#pragma unroll
-    for (int q = 0; q < NP; q += 4) {
-        const v4f v = *reinterpret_cast<const v4f *>(prm + DP_C0 + q);
-        c[q] = v.x;
-        if (q + 1 < NP) c[q + 1] = v.y;
-        if (q + 2 < NP) c[q + 2] = v.z;
-        if (q + 3 < NP) c[q + 3] = v.w;
-    }
-    const float cc = __int_as_float(prm[DP_CC]);
-    for (int j0 = t; j0 < nout; j0 += UN * DC_T) {
-        v2f acc[UN];
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const int j = j0 + u * DC_T;
-            if (j < nout) {
-                if (L == 3) {
-                    acc[u] = (E[j] + O[j + 1]) * c[0] + (O[j] + E[j + 1]) * c[1];
-                } else {
-                    acc[u] = O[j + (H - 1) / 2] * cc;
-#pragma unroll
-                    for (int q = 0; q < NP; q++) acc[u] += (E[j + q] + E[j + H - q]) * c[q];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const int j = j0 + u * DC_T;
-            if (j < nout) {
-                if (ylin) ylin[j] = acc[u];
-                else if (j & 1) yO[j >> 1] = acc[u];
-                else yE[j >> 1] = acc[u];
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void downconv_kernel(DcArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-    const int t = threadIdx.x;
-    const int ns = a.nstages;
-    const int wg = blockIdx.x;
-    const int ci = wg / a.nseg, seg = wg % a.nseg;
-    if (ci >= a.nchan) return;
-    const int ch = a.chan_list ? a.chan_list[ci] : ci;
-    const DcChan cs = a.chan[ch];
-
-    // LDS regions R_s = [hist_s | stage-s input] at a.roff[s] (host computed); R_ns = tile outputs
-    const int *roff = a.roff;
-    __shared__ __attribute__((aligned(16))) int ptab[DC_MAX_STAGES + 1][DP_WORDS];
-    for (int i = t; i < (ns + 1) * DP_WORDS; i += DC_T) {
-        const int s = i / DP_WORDS, k = i % DP_WORDS;
-        int v = 0;
-        if (k == DP_ROFF) v = roff[s];
-        else if (k == DP_OOFF) v = a.ooff[s];
-        else if (s < ns) {
-            if (k == DP_KIND) v = a.kind[s];
-            else if (k == DP_HIST2) v = a.st[s].hist / 2;
-            else if (k == DP_CC) v = __float_as_int(a.st[s].ccoef);
-            else if (k >= DP_C0 && k - DP_C0 < DC_MAX_PAIRS) v = __float_as_int(a.st[s].c[k - DP_C0]);
-        }
-        ptab[s][k] = v;
-    }
-    for (int s = 0; s < ns; s++)
-        for (int i = t; i < a.st[s].hist; i += DC_T)
-            lds[roff[s] + ((i & 1) ? a.ooff[s] : 0) + (i >> 1)] = v2f{0.f, 0.f};
-    lds_barrier();
-    // lane s: kind | hist/2 << 8 | odd-half offset << 16, and the region offset, of stage s
-    int pv0, pv1;
-    {
-        const int *row = ptab[(t & 63) <= ns ? (t & 63) : ns];
-        pv0 = row[DP_KIND] | (row[DP_HIST2] << 8) | (row[DP_OOFF] << 16);
-        pv1 = row[DP_ROFF];
-    }
-    const v2f step1 = phasor_of(cs.inc);                 // one sample of NCO rotation
-    v2f p0 = {1.f, 0.f}, p1 = {1.f, 0.f};
-    int anchor_rows = 0;                                 // rows until the phasors are re-anchored
-
-    const long in_row = a.in_rows ? a.in_rows[ch] : ch;
-    const v2f *in = a.in + in_row * a.in_stride;
-    const unsigned char *pk = a.wire.pk ? a.wire.pk + in_row * a.wire.chan_stride : nullptr;   // datagram input
-    v2f *out = a.out + (long)ch * a.out_stride;
-    const v2f *hist = a.hist + (long)ch * a.hist_stride;
-    v2f *hist_next = a.hist_next + (long)ch * a.hist_stride;
-    const long seg_start = (long)seg * a.seg_len;
-    long seg_end = seg_start + a.seg_len;
-    if (seg_end > a.n_in) seg_end = a.n_in;
-    const v2f rowstep = phasor_of(cs.inc * (unsigned long long)DC_ROW);
-    const float a_inf = a.amp[DC_AMP_N - 1], inv_a_inf = 1.0f / a_inf;
-
-    // The raw input of a tile is fetched into registers one tile ahead, while the previous tile goes
-    // through the cascade: nothing waits on HBM latency except the very first tile.
-    constexpr int NR = DC_TILE / DC_ROW;
-    v4f raw[NR];
-    auto tile_len = [&](long p) {
-        const long lim = ((p < seg_start) ? seg_start : seg_end) - p;
-        return (int)(lim < DC_TILE ? lim : DC_TILE);
-    };
-    auto fetch = [&](long p) {
-        if (p >= seg_end || (p < seg_start && seg == 0)) return;      // past the end / history-fed warm-up
-        const int m = tile_len(p);
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int i = r * DC_ROW + 2 * t;
-            if (i < m) {
-                if (pk) {
-                    const wf4 w = wire_pair_fetch(pk, a.wire.pkt_len, p + i);          // raw words; p + i is even
-                    raw[r] = v4f{w.x, w.y, w.z, w.w};
-                } else {
-                    raw[r] = *reinterpret_cast<const v4f *>(in + p + i);
-                }
-            }
-        }
-    };
-
-    // datagram input: the prefetched words are decoded where they are consumed
-    auto unwire = [&](v4f r) -> v4f {
-        if (!pk) return r;
-        const wf4 w = wire_pair_decode(wf4{r.x, r.y, r.z, r.w}, a.wire.pkt_len);
-        return v4f{w.x, w.y, w.z, w.w};
-    };
-    // pos: index of the tile's first sample in this call's input (negative inside the warm-up)
-    long pos = seg_start - a.W;
-#ifdef DC_PROFILE
-    unsigned long long tk[20] = {0}, tlast = __builtin_readcyclecounter();
-#define DC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tk[k] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define DC_TICK(k)
-#endif
-    fetch(pos);
-    while (pos < seg_end) {
-        const bool warm = pos < seg_start;
-        const int n = tile_len(pos);
-        // stage-0 input: parity halves behind their histories (no decimation: the linear output region)
-        const int h0 = ns > 0 ? a.st[0].hist / 2 : 0;
-        v2f *r0 = lds + roff[0] + h0, *r0o = lds + roff[0] + (ns > 0 ? a.ooff[0] : 0) + h0;
-        // ---------------- stage-0 input: mix with the NCO (or take the mixed history) -----------
-        if (warm && seg == 0) {
-            for (int i = t; i < n; i += DC_T) {
-                const v2f v = hist[pos + a.W + i];
-                if (ns == 0) r0[i] = v;
-                else if (i & 1) r0o[i >> 1] = v;
-                else r0[i >> 1] = v;
-            }
-        } else {
-            // the phasors run on from tile to tile and are re-anchored every DC_ANCHOR_ROWS rows
-            // (and after a short tile, which breaks the row cadence)
-            // p0/p1 carry the steady-state amplitude a_inf
-            if (anchor_rows <= 0 || n != DC_TILE) {
-                p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(pos + 2 * t + 1)) * a_inf;
-                p1 = cmul(p0, step1);
-                anchor_rows = (n == DC_TILE) ? DC_ANCHOR_ROWS : 0;
-            }
-            anchor_rows -= NR;
-            // full tile, amplitude settled, no history to save: the lean path
-            const bool lean = ns > 0 && n == DC_TILE && cs.age + (unsigned long long)pos >= DC_AMP_N &&
-                              (warm || a.W == 0 || pos + n <= a.n_in - a.W);
-            if (lean) {
-                v2f *e = r0 + t, *o = r0o + t;
-#pragma unroll
-                for (int row = 0; row < NR; row++) {
-                    const v4f v = unwire(raw[row]);
-                    e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
-                    o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
-                    p0 = cmul(p0, rowstep);
-                    p1 = cmul(p1, rowstep);
-                }
-            } else
-#pragma unroll
-            for (int row = 0; row < NR; row++) {
-                const int i = row * DC_ROW + 2 * t;
-                const long gi = pos + i;                       // sample index within the call
-                if (i < n) {
-                    const v4f v = unwire(raw[row]);
-                    v2f x0 = cmul(v2f{v.x, v.y}, p0), x1 = cmul(v2f{v.z, v.w}, p1);
-                    const unsigned long long age = cs.age + (unsigned long long)gi;
-                    if (age + 1 < DC_AMP_N) {                   // start-up envelope (the phasors carry a_inf)
-                        x0 *= a.amp[age] * inv_a_inf; x1 *= a.amp[age + 1] * inv_a_inf;
-                    }
-                    if (ns == 0) {
-                        *reinterpret_cast<v4f *>(&r0[i]) = v4f{x0.x, x0.y, x1.x, x1.y};
-                    } else {
-                        r0[i >> 1] = x0; r0o[i >> 1] = x1;
-                    }
-                    // the last W mixed samples of the call are the next call's warm-up
-                    const long hj = gi - (a.n_in - a.W);
-                    if (!warm && hj >= 0 && a.W > 0)
-                        *reinterpret_cast<v4f *>(&hist_next[hj]) = v4f{x0.x, x0.y, x1.x, x1.y};
-                }
-                p0 = cmul(p0, rowstep);
-                p1 = cmul(p1, rowstep);
-            }
-        }
-        DC_TICK(0);
-        lds_barrier();
-        DC_TICK(1);
-        fetch(pos + n);                                       // next tile's input, in flight during the cascade
-        // ---------------- the cascade, LDS -> LDS ---------------------------------------------
-        int len = n;
-        for (int s = 0; s < ns; s++) {
-            const int d0 = __builtin_amdgcn_readlane(pv0, s), dn = __builtin_amdgcn_readlane(pv0, s + 1);
-            const v2f *E = lds + __builtin_amdgcn_readlane(pv1, s), *O = E + (d0 >> 16);
-            const bool last = s + 1 == ns;
-            const int hn2 = (dn >> 8) & 0xff;                   // 0 behind the last stage
-            v2f *yE = lds + __builtin_amdgcn_readlane(pv1, s + 1) + hn2;
-            v2f *yO = yE + (dn >> 16);
-            v2f *ylin = last ? yE : nullptr;
-            const int nout = len >> 1;
-#define DC_CASE(LL) case LL: dc_stage<LL>(E, O, yE, yO, ylin, nout, ptab[s], t); break;
-            switch (d0 & 0xff) {
-            DC_CASE(3) DC_CASE(11) DC_CASE(15) DC_CASE(19) DC_CASE(23) DC_CASE(27) DC_CASE(31)
-            DC_CASE(35) DC_CASE(39) DC_CASE(43) DC_CASE(47)
-            default: dc_stage<51>(E, O, yE, yO, ylin, nout, ptab[s], t); break;
-            }
-#undef DC_CASE
-            DC_TICK(8 + s);
-            lds_barrier();
-            DC_TICK(3);
-            len = nout;
-        }
-        // slide every stage's history at once: the last hist_s inputs of stage s (hist_s/2 per parity
-        // half) move to the front; one wave per stage (lanes 0-31 even half, 32-63 odd half); read,
-        // barrier, write because a short tile overlaps source and target
-        {
-            constexpr int R = (DC_MAX_STAGES * 64 + DC_T - 1) / DC_T;
-            v2f keep[R];
-            int dst[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int u = t + r * DC_T, odd = (u >> 5) & 1, i = u & 31;
-                const int sg = __builtin_amdgcn_readfirstlane(u >> 6);
-                dst[r] = -1;
-                if (sg < ns) {
-                    const int d = __builtin_amdgcn_readlane(pv0, sg);
-                    if (i < ((d >> 8) & 0xff)) {
-                        dst[r] = __builtin_amdgcn_readlane(pv1, sg) + (odd ? (d >> 16) : 0) + i;
-                        keep[r] = lds[dst[r] + (n >> (sg + 1))];
-                    }
-                }
-            }
-            lds_barrier();
-#pragma unroll
-            for (int r = 0; r < R; r++) if (dst[r] >= 0) lds[dst[r]] = keep[r];
-        }
-        DC_TICK(4);
-        // ---------------- tile outputs -> HBM ------------------------------------------------------
-        if (!warm) {
-            const v2f *y = lds + roff[ns];
-            const long obase = pos >> ns;
-            for (int j = t; j < len; j += DC_T) out[obase + j] = y[j];
-        }
-        DC_TICK(5);
-        lds_barrier();
-        DC_TICK(6);
-        pos += n;
-    }
-
-#ifdef DC_PROFILE
-    if (wg == 0 && (t == 0 || t == 256))
-        printf("dcprof t%d: mix %llu bar %llu stages %llu bar %llu hist %llu out %llu bar %llu\n", t, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6]);
-    if (wg == 0 && (t == 0 || t == 256)) printf("dcstages t%d: %llu %llu %llu %llu %llu %llu\n", t, tk[8], tk[9], tk[10], tk[11], tk[12], tk[13]);
-#endif
-    // the NCO runs on: phase and age after this call's n_in samples (the host keeps the same arithmetic in its
-    // mirror, so a retune uploads a consistent state)
-    if (seg == 0 && t == 0) {
-        DcChan nx;
-        nx.phase = cs.phase + cs.inc * (unsigned long long)a.n_in;
-        nx.inc = cs.inc;
-        nx.age = cs.age + (unsigned long long)a.n_in;
-        a.chan_next[ch] = nx;
-    }
-    // calls shorter than the warm-up length keep the tail of the old history in front
-    if (seg == a.nseg - 1 && a.n_in < a.W)
-        for (int j = t; j < a.W - a.n_in; j += DC_T) hist_next[j] = hist[j + a.n_in];
-}
-
 int downconv_layout(DcArgs &a)
 {
-    int o = 0;
-    for (int s = 0; s <= a.nstages; s++) {
-        a.roff[s] = o;
-        if (s < a.nstages) {
-            const int half = (a.st[s].hist / 2 + (DC_TILE >> (s + 1)) + 2) & ~1;    // + slack for the CIC's O[j+1]
-            a.ooff[s] = half;
-            o += 2 * half;
-        } else {
-            a.ooff[s] = 0;
-            o += ((DC_TILE >> s) + 1) & ~1;
-        }
-    }
-    return o * 8 + 64;
+    const DcLayout l = dc_layout_of(a.kind, a.nstages);
+    for (int s = 0; s <= a.nstages; s++) { a.roff[s] = l.roff[s]; a.ooff[s] = l.ooff[s]; }
+    return l.slots * 8 + 64;
+}
+
+// the precompiled plans: one launch function per DC_PLAN(id, kinds...) line of the generated table
+struct DcCompiledPlan {
+    int ns;
+    int kind[DC_MAX_STAGES];
+    hipError_t (*launch)(DcArgs &, hipStream_t);
+};
+#if __has_include("downconv_plans.inc")
+#define DC_PLAN(id, ...) hipError_t downconv_launch_plan_##id(DcArgs &, hipStream_t);
+#include "downconv_plans.inc"
+#undef DC_PLAN
+template <int... K> static constexpr int dc_count_kinds() { return sizeof...(K); }
+static const DcCompiledPlan dc_compiled[] = {
+#define DC_PLAN(id, ...) {dc_count_kinds<__VA_ARGS__>(), {__VA_ARGS__}, &downconv_launch_plan_##id},
+#include "downconv_plans.inc"
+#undef DC_PLAN
+    {-1, {0}, nullptr}};
+#else
+static const DcCompiledPlan dc_compiled[] = {{-1, {0}, nullptr}};
+#endif
+
+static int dc_force_dynamic = 0;
+/* tests: 1 = every launch takes the run-time-plan kernel; returns the number of precompiled plans */
+int downconv_force_dynamic(int on)
+{
+    if (on >= 0) dc_force_dynamic = on;
+    int n = 0;
+    while (dc_compiled[n].launch) n++;
+    return n;
 }
 
 hipError_t downconv_launch(DcArgs &a, hipStream_t stream)
 {
     const int lds = downconv_layout(a);
+    if (!dc_force_dynamic)
+        for (const DcCompiledPlan *p = dc_compiled; p->launch; p++) {
+            if (p->ns != a.nstages) continue;
+            bool same = true;
+            for (int s = 0; s < p->ns; s++) same = same && p->kind[s] == a.kind[s];
+            if (same) return p->launch(a, stream);
+        }
     // per launch: the attribute belongs to the current device, and a process may drive several
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<DcPlanDyn>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(downconv_kernel, dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
+    hipLaunchKernelGGL(downconv_kernel<DcPlanDyn>, dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,30 @@
+// downconv_plan.hip -- the down-converter kernel (downconv_kernel.hpp) instantiated for ONE compile-time plan.
+// cutesdr_amd/_build.py compiles this file once per entry of its DC_PLANS list, with
+//   -DDC_PLAN_ID=<n> -DDC_PLAN_KINDS=<stage kinds, comma separated>
+// (tools/list_dc_plans.py derives the list from the reference's radio rates x demodulator bandwidths), and writes
+// the matching table downconv_plans.inc for downconv_kernels.hip.  Compiled without those macros (the build's glob
+// over *.hip does that once) it is empty.
+#ifdef DC_PLAN_ID
+#include "downconv_kernel.hpp"
+
+namespace csdr {
+
+#define DC_CAT2(a, b) a##b
+#define DC_CAT(a, b) DC_CAT2(a, b)
+
+hipError_t DC_CAT(downconv_launch_plan_, DC_PLAN_ID)(DcArgs &a, hipStream_t stream)
+{
+    using P = DcPlanT<DC_PLAN_KINDS>;
+    const int lds = dc_layout_of(P::KIND, P::NS).slots * 8 + 64;
+    // per launch: the attribute belongs to the current device, and a process may drive several
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<P>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(downconv_kernel<P>, dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace csdr
+#endif

@@ -100,3 +100,43 @@ def test_batch_mixed_chains_segments_and_state(oracle):
             want = np.concatenate([refs[c].ProcessData(part[c][i:i + 65536]) for i in range(0, T, 65536)])
             assert len(got[c]) == len(want)
             assert np.abs(got[c] - want).max() <= TOL, c
+
+
+def test_precompiled_plans_reproduce_the_runtime_plan_kernel(oracle):
+    """The kernel compiled for a stage sequence (DC_PLANS in cutesdr_amd/_build.py, the reference's radio rates x
+    demodulator bandwidths: tools/list_dc_plans.py) against the same kernel with the plan taken at run time: the
+    same words out, ragged call lengths included (short tiles take the generic stage code in both), and both within
+    the tolerance of the oracle."""
+    import ctypes as C
+    import cutesdr_amd as ca
+    from cutesdr_amd import _build
+    L = ca.lib()
+    L.csdr__downconv_force_dynamic.restype = C.c_int
+    L.csdr__downconv_force_dynamic.argtypes = [C.c_int]
+    assert L.csdr__downconv_force_dynamic(-1) == len(_build.DC_PLANS)
+    cases = [(2e6, 15000, [11, 11, 15, 19, 31]), (2e6, 1000, [3, 3, 11, 11, 11, 11, 15]), (62500, 10000, [51]),
+             (250000, 20000, [23, 51]), (625000, 15000, [11, 15, 27]), (80e6 / 130, 10000, [11, 15, 19, 35])]
+    try:
+        for in_rate, bw, chain in cases:
+            assert tuple(chain) in _build.DC_PLANS
+            # (every call long enough that no stage sees fewer samples than its taps: the reference's early return for
+            # such calls is a documented deviation, DESIGN section 4)
+            # and none longer than the reference's half-band scratch buffer
+            calls = [16384, 8192 + 640, 4096 + (3 << len(chain)), 20000 - 20000 % (1 << len(chain))]
+            x = tones_plus_noise(11, sum(calls), in_rate, [in_rate * 0.05 + 300.0, in_rate * 0.05 - 900.0, in_rate * 0.19])
+            outs = []
+            for dyn in (0, 1):
+                L.csdr__downconv_force_dynamic(dyn)
+                dc = ca.CDownConvert()
+                dc.SetDataRate(in_rate, bw)
+                assert dc.stages() == chain
+                dc.SetFrequency(-in_rate * 0.05)
+                pos, got = 0, []
+                for n in calls:
+                    got.append(dc.ProcessData(x[pos:pos + n])); pos += n
+                outs.append(np.concatenate(got))
+            assert np.array_equal(outs[0], outs[1])
+            _, refs = run_oracle(oracle, in_rate, bw, -in_rate * 0.05, np.split(x, np.cumsum(calls)[:-1]))
+            assert np.abs(outs[0] - np.concatenate(refs)).max() <= TOL
+    finally:
+        L.csdr__downconv_force_dynamic(0)

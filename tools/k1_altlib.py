@@ -17,8 +17,9 @@ alt = []
 for unit in units:
     src = os.path.join(_build.CSRC, unit + ".hip")
     obj = os.path.join(_build.OBJ, "%s.%s.o" % (unit, name))
-    subprocess.check_call([_build._hipcc()] + _build.FLAGS + _build.FILE_FLAGS.get(unit + ".hip", []) + extra + ["-c", src, "-o", obj])
+    subprocess.check_call([_build._hipcc()] + _build.FLAGS + _build.FILE_FLAGS.get(unit + ".hip", []) + ["-I", _build.OBJ] + extra + ["-c", src, "-o", obj])
     alt.append(obj)
-objs = [o for o in sorted(glob.glob(os.path.join(_build.OBJ, "*.hip.o"))) if os.path.basename(o)[:-6] not in units]
+objs = [o for o in sorted(glob.glob(os.path.join(_build.OBJ, "*.hip.o")) + glob.glob(os.path.join(_build.OBJ, "downconv_plan_*.o")))
+        if os.path.basename(o)[:-6] not in units]
 subprocess.check_call([_build._hipcc(), "-shared", "-fPIC", "--offload-arch=" + _build.ARCH, "-o", out] + objs + alt)
 print(out)

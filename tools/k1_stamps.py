@@ -16,7 +16,8 @@ def build():
     obj = os.path.join(_build.OBJ, "fastfir2_kernels.stamps.o")
     subprocess.check_call([_build._hipcc()] + _build.FLAGS + _build.FILE_FLAGS["fastfir2_kernels.hip"] +
                           ["-DCSDR_K1_STAMPS", "-c", src, "-o", obj])
-    objs = [o for o in sorted(glob.glob(os.path.join(_build.OBJ, "*.hip.o"))) if not o.endswith("fastfir2_kernels.hip.o")]
+    objs = [o for o in sorted(glob.glob(os.path.join(_build.OBJ, "*.hip.o")) + glob.glob(os.path.join(_build.OBJ, "downconv_plan_*.o")))
+            if not o.endswith("fastfir2_kernels.hip.o")]
     subprocess.check_call([_build._hipcc(), "-shared", "-fPIC", "--offload-arch=" + _build.ARCH, "-o", OUT] + objs + [obj])
     print(OUT)
 

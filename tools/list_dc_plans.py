@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""The decimator plans (stage sequences of CDownConvert::SetDataRate, dsp/downconvert.cpp:127-166) that the
+reference's radios can ask for: its sample-rate tables (interface/sdrinterface.cpp:75-114: SDR-IQ, NetSDR, SDR-IP)
+x the demodulators' maximum bandwidths (gui/mainwindow.cpp:1006-1050: AM/SAM 10 kHz, FM 15 kHz, SSB 20 kHz,
+CW 1 kHz).  cutesdr_amd/_build.py compiles the down-converter once per plan listed in DC_PLANS (a kernel that knows
+its stage sequence at compile time); every other sequence runs the same kernel with a run-time plan.
+Prints the list in the form _build.py holds it."""
+import os, re
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = open(os.path.join(root, "include", "csdr_hb_taps.h")).read()
+maxbw = [eval(x.strip()) for x in re.search(r"csdr_hb_maxbw\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
+lens = [int(x) for x in re.search(r"csdr_hb_len\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
+CIC3 = .5 - .4985
+
+def plan(rate, bw):
+    f, k = rate, []
+    while bw > 0 and f > bw / maxbw[-1] and f > 7900.0 * 2.0 and len(k) < 9:
+        if f >= bw / CIC3: k.append(3)
+        else: k.append(next(lens[i] for i, m in enumerate(maxbw) if f >= bw / m))
+        f /= 2.0
+    return tuple(k)
+
+RATES = [66666666.6667 / d for d in (1200.0, 600.0, 420.0, 340.0)] + [80.0e6 / d for d in (1280.0, 320.0, 128.0, 130.0, 40.0)]
+BWS = [1000.0, 10000.0, 15000.0, 20000.0]
+plans = {}
+for r in RATES:
+    for b in BWS:
+        plans.setdefault(plan(r, b), []).append("%.0f/%.0f" % (r, b))
+if __name__ == "__main__":
+    for p in sorted(plans, key=lambda p: (len(p), p)):
+        if p: print("    %-40s # %s" % (str(p) + ",", ", ".join(plans[p])))
