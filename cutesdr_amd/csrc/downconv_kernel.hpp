@@ -289,6 +289,82 @@ void downconv_kernel(DcArgs a)
 #endif
     fetch(pos);
     while (pos < seg_end) {
+        if constexpr (FIX && P::NS > 0) {
+            // ---- steady state of a compile-time plan: complete tiles mixed from this call's input, the NCO
+            // amplitude settled, nothing to save for the next call.  No tile length, no path selection, no lane
+            // predicate; the other tiles (history-fed warm-up, the last W samples, a segment's odd end) take the
+            // general body below, which keeps the same one-tile-ahead prefetch protocol.
+            const long hi = a.W ? (seg_end < (long)a.n_in - a.W ? seg_end : (long)a.n_in - a.W) : seg_end;
+            while (true) {
+                const bool w = pos < seg_start;
+                const long lim = w ? seg_start : hi;
+                if (!(pos + DC_TILE <= lim && (seg > 0 || pos >= 0) && cs.age + (unsigned long long)pos >= DC_AMP_N)) break;
+                if (anchor_rows <= 0) {
+                    p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(pos + 2 * t + 1)) * a_inf;
+                    p1 = cmul(p0, step1);
+                    anchor_rows = DC_ANCHOR_ROWS;
+                }
+                anchor_rows -= NR;
+                {
+                    v2f *e = lds + LY.roff[0] + dc_hist_of(P::KIND[0]) / 2 + t, *o = e + LY.ooff[0];
+#pragma unroll
+                    for (int row = 0; row < NR; row++) {
+                        const v4f v = unwire(raw[row]);
+                        e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
+                        o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
+                        p0 = cmul(p0, rowstep);
+                        p1 = cmul(p1, rowstep);
+                    }
+                }
+                lds_barrier();
+                if (pos + 2 * DC_TILE <= lim) {                 // the next tile is complete too: all rows, no bounds
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const long i = pos + DC_TILE + r * DC_ROW + 2 * t;
+                        if (pk) {
+                            const wf4 wv = wire_pair_fetch(pk, a.wire.pkt_len, i);
+                            raw[r] = v4f{wv.x, wv.y, wv.z, wv.w};
+                        } else {
+                            raw[r] = *reinterpret_cast<const v4f *>(in + i);
+                        }
+                    }
+                } else {
+                    fetch(pos + DC_TILE);
+                }
+                static_for<0, P::NS>([&](auto S) {
+                    constexpr int s = S.value, L = P::KIND[s];
+                    constexpr bool last = s + 1 == P::NS;
+                    const v2f *E = lds + LY.roff[s], *O = E + LY.ooff[s];
+                    v2f *yE = lds + LY.roff[s + 1] + (last ? 0 : dc_hist_of(P::KIND[s + 1]) / 2), *yO = yE + LY.ooff[s + 1];
+                    dc_stage_full<L, ((DC_TILE / 2) >> s)>(E, O, yE, yO, last, t);
+                    lds_barrier();
+                });
+                {
+                    v2f keep[P::NS];
+                    const int i = t & 31, odd = t >> 5;
+                    static_for<0, P::NS>([&](auto S) {
+                        constexpr int sg = S.value;
+                        if (i < dc_hist_of(P::KIND[sg]) / 2) keep[sg] = lds[LY.roff[sg] + (odd ? LY.ooff[sg] : 0) + i + (DC_TILE >> (sg + 1))];
+                    });
+                    lds_barrier();
+                    static_for<0, P::NS>([&](auto S) {
+                        constexpr int sg = S.value;
+                        if (i < dc_hist_of(P::KIND[sg]) / 2) lds[LY.roff[sg] + (odd ? LY.ooff[sg] : 0) + i] = keep[sg];
+                    });
+                }
+                if (!w) {
+                    constexpr int LEN = DC_TILE >> P::NS;
+                    const v2f *y = lds + LY.roff[P::NS];
+                    const long obase = pos >> P::NS;
+#pragma unroll
+                    for (int j = 0; j < (LEN + DC_T - 1) / DC_T; j++)
+                        if (LEN >= DC_T || t < LEN) out[obase + j * DC_T + t] = y[j * DC_T + t];
+                }
+                lds_barrier();
+                pos += DC_TILE;
+            }
+            if (pos >= seg_end) break;
+        }
         const bool warm = pos < seg_start;
         const int n = tile_len(pos);
         // stage-0 input: parity halves behind their histories (no decimation: the linear output region)
