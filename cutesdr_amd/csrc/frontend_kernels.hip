@@ -82,6 +82,15 @@ void noiseblank_kernel(NbArgs a)
         // one tile ahead, so that they are in flight while the current tile goes through its scans
         f2 nx[NB_PER], nxo[NB_PER], nxd[NB_PER];
         auto fetch = [&](long b0) {
+            // a tile whose three streams lie inside this call's float rows (all but the first tiles of a call and a
+            // segment's last one): plain loads, no per-sample source selection or bounds.  (The same for datagram
+            // input -- aligned pairs kept as raw words, decoded where consumed -- was measured: 201 VGPRs, slower.)
+            if (!pk && b0 - M1 >= 0 && b0 - D1 >= 0 && b0 + NB_TILE <= seg_b) {
+                const f2 *p = in + b0 + (long)t * NB_PER;
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) { nx[k] = p[k]; nxo[k] = p[k - M1]; nxd[k] = p[k - D1]; }
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 const long i = b0 + (long)t * NB_PER + k;
