@@ -295,6 +295,10 @@ void downconv_kernel(DcArgs a)
             // predicate; the other tiles (history-fed warm-up, the last W samples, a segment's odd end) take the
             // general body below, which keeps the same one-tile-ahead prefetch protocol.
             const long hi = a.W ? (seg_end < (long)a.n_in - a.W ? seg_end : (long)a.n_in - a.W) : seg_end;
+            // one copy of the loop per input format (float rows, 16-bit and 24-bit datagrams): the datagram length is a
+            // constant inside each, so the decode carries no format test and the sample-index division is a multiply
+            auto steady = [&](auto FMT) {
+            constexpr int fmt = FMT.value;               // 0: float rows, otherwise the datagram length
             while (true) {
                 const bool w = pos < seg_start;
                 const long lim = w ? seg_start : hi;
@@ -309,7 +313,11 @@ void downconv_kernel(DcArgs a)
                     v2f *e = lds + LY.roff[0] + dc_hist_of(P::KIND[0]) / 2 + t, *o = e + LY.ooff[0];
 #pragma unroll
                     for (int row = 0; row < NR; row++) {
-                        const v4f v = unwire(raw[row]);
+                        v4f v = raw[row];
+                        if constexpr (fmt != 0) {
+                            const wf4 d = wire_pair_decode(wf4{v.x, v.y, v.z, v.w}, fmt);
+                            v = v4f{d.x, d.y, d.z, d.w};
+                        }
                         e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
                         o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
                         p0 = cmul(p0, rowstep);
@@ -321,8 +329,8 @@ void downconv_kernel(DcArgs a)
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
                         const long i = pos + DC_TILE + r * DC_ROW + 2 * t;
-                        if (pk) {
-                            const wf4 wv = wire_pair_fetch(pk, a.wire.pkt_len, i);
+                        if constexpr (fmt != 0) {
+                            const wf4 wv = wire_pair_fetch(pk, fmt, i);
                             raw[r] = v4f{wv.x, wv.y, wv.z, wv.w};
                         } else {
                             raw[r] = *reinterpret_cast<const v4f *>(in + i);
@@ -363,6 +371,10 @@ void downconv_kernel(DcArgs a)
                 lds_barrier();
                 pos += DC_TILE;
             }
+            };
+            if (!pk) steady(std::integral_constant<int, 0>{});
+            else if (a.wire.pkt_len == 1444) steady(std::integral_constant<int, 1444>{});
+            else steady(std::integral_constant<int, 1028>{});
             if (pos >= seg_end) break;
         }
         const bool warm = pos < seg_start;
