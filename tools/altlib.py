@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Builds a copy of the library whose K1 (fastfir2_kernels.hip) is compiled with extra flags, for A/B runs of
-kernel experiments in one gpurun call:   python tools/k1_altlib.py NAME [unit.hip[,unit2.hip]] [-DFLAG ...]
+kernel experiments in one gpurun call:   python tools/altlib.py NAME [unit.hip[,unit2.hip]] [-DFLAG ...]
   -> cutesdr_amd/libcutesdr_mi_NAME.so;   then   CSDR_LIB_PATH=<that> python tools/ab_fastfir.py 0,2"""
 import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
