@@ -69,8 +69,11 @@ __device__ __forceinline__ void fft_fwd_passes(v2f (&x)[32], v2f *lds, const v2f
     dft_dif<32, +1>(x);
 }
 
+#ifndef CSDR_SPEC_WAVES
+#define CSDR_SPEC_WAVES 1
+#endif
 template <int LOG2N>
-__global__ __launch_bounds__(SpecCfg<LOG2N>::T)
+__global__ __launch_bounds__(SpecCfg<LOG2N>::T) __attribute__((amdgpu_waves_per_eu(CSDR_SPEC_WAVES)))
 void spectrum_kernel(SpectrumArgs a)
 {
     using Cfg = SpecCfg<LOG2N>;
@@ -104,19 +107,30 @@ void spectrum_kernel(SpectrumArgs a)
         const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);     // display order, fft.cpp:564-589
         sm[r] = a.nparts == 1 ? sum[j] : 0.f;
     });
-    for (int f = f0; f < f1; f++) {
+    // the samples of frame f+1 are fetched while frame f goes through its transform (one workgroup has only two
+    // waves and three share a CU: nothing else would hide the HBM latency of a frame's 32 loads per thread)
+    v2f nxt[32];
+    auto fetch = [&](int f) {
         const v2f *src = in + (long)f * N;
+#pragma unroll
+        for (int e = 0; e < G; e++)
+#pragma unroll
+            for (int n1 = 0; n1 < R0; n1++) nxt[e * R0 + n1] = src[1024 * n1 + G * t + e];
+    };
+    if (f0 < f1) fetch(f0);
+    for (int f = f0; f < f1; f++) {
         v2f x[32];
 #pragma unroll
         for (int e = 0; e < G; e++)
 #pragma unroll
             for (int n1 = 0; n1 < R0; n1++) {
                 const int i = 1024 * n1 + G * t + e;
-                const v2f s = src[i];
+                const v2f s = nxt[e * R0 + n1];
                 const float w = a.win[i];
                 if (s.x > 32000.0f) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
                 x[e * R0 + n1] = v2f{w * s.y, w * s.x};           // I/Q swapped, fft.cpp:280-281
             }
+        if (f + 1 < f1) fetch(f + 1);
         const float prev_count = (float)ave_count;
         total++;                                                  // CpxFFT counters, fft.cpp:515-517
         if (ave_count < a.ave_size) ave_count++;
