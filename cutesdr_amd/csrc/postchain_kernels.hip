@@ -86,7 +86,8 @@ struct PcLds {
     float pk[PT + 16];                   // sliding peak, then the log gain argument
     float w0[PT + PC_FIR_MAX + 17];      // [FIR history | tile] work array (audio / envelope / I)
     float w1[PT + PC_FIR_MAX + 17];      // second work array (theta / Q)
-    float h0[PC_FIR_MAX + 5], h1[PC_FIR_MAX + 5];   // FIR taps of the active demodulator
+    float h0[PC_FIR_MAX + 17], h1[PC_FIR_MAX + 17]; // FIR taps of the active demodulator, reversed and zero padded:
+                                                    // h[4 + r] = tap ntaps-1-r (16-byte aligned rows of four)
     float w2[PT + 16];                   // third work array (S-meter dB, attack average, PLL phase, |hp|)
     float rt[PC_RLEVELS][PC_NCHUNK];     // log table over the chunk maxima of the sliding peak
     double pw_sm[LCMAX + 1], pw_dc[LCMAX + 1], pw_sq[LCMAX + 1], pw_fd[LCMAX + 1];   // powers of the averager coefficients
@@ -271,20 +272,47 @@ struct Wg {
     }
 };
 
-// acc[j] = sum_k h[k] * x[i_j - k] for this thread's outputs i_j = t + NT j; x points at the tile
-// (ntaps-1 history samples sit in front of it), h and x in LDS.  Each tap is fetched once per thread.
+// The outputs a thread of the tile owns: LC consecutive ones with four waves (the FIRs below then share one register
+// window of the input), the strided t + NT j otherwise.
+template <int NW> __device__ __forceinline__ int pc_out_index(int t, int j)
+{ return NW == 4 ? Wg<NW>::LC * t + j : t + Wg<NW>::NT * j; }
+
+// acc[j] = sum_k tap[k] * x[i_j - k], k ascending, for this thread's outputs i_j = pc_out_index(t, j).  `arr` is the
+// work array [ntaps-1 history | tile | zeros], `hr` the taps as PcLds holds them (reversed, zero padded).
+// Four waves: the four outputs are consecutive, so the thread walks ONE window of the array in 16-byte reads
+// (ntaps/4 + 1 of them, and as many of the taps) instead of fetching every tap's sample for every output -- the
+// squelch filter alone was a fifth of an FM tile.  The products are added in the same order as the plain loop
+// (padded taps contribute exact zeros), so the words do not change.
 template <int NW>
-__device__ __forceinline__ void fir_blk(const float *h, int ntaps, const float *x, int t, float (&acc)[Wg<NW>::LC])
+__device__ __forceinline__ void fir_blk(const float *hr, int ntaps, const float *arr, int t, float (&acc)[Wg<NW>::LC])
 {
     constexpr int NT = Wg<NW>::NT, NO = Wg<NW>::LC;
 #pragma unroll
     for (int j = 0; j < NO; j++) acc[j] = 0.f;
-    const float *p = x + t;
-#pragma unroll 3
-    for (int k = 0; k < ntaps; k++) {
-        const float hk = h[k];
+    if constexpr (NW == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int Q = (ntaps + 2) / 4 + 1;                      // samples 4t .. 4t + ntaps + 2 of the array
+        const f4 *v = reinterpret_cast<const f4 *>(arr) + t;
+        const f4 *g = reinterpret_cast<const f4 *>(hr);
+        f4 B = g[Q];
+        for (int q = Q - 1; q >= 0; q--) {
+            const f4 A = g[q], V = v[q];
+            const float cw[7] = {A.y, A.z, A.w, B.x, B.y, B.z, B.w};     // taps r = 4q-3 .. 4q+3 (+4 in hr)
+            const float sv[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
-        for (int j = 0; j < NO; j++) acc[j] += hk * p[NT * j - k];
+            for (int e = 3; e >= 0; e--)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] += cw[e - j + 3] * sv[e];
+            B = A;
+        }
+    } else {
+        const float *p = arr + (ntaps - 1) + t;
+#pragma unroll 3
+        for (int k = 0; k < ntaps; k++) {
+            const float hk = hr[4 + ntaps - 1 - k];
+#pragma unroll
+            for (int j = 0; j < NO; j++) acc[j] += hk * p[NT * j - k];
+        }
     }
 }
 // keep the last `hist` (< 128) entries of [hist | n] in front for the next tile; barrier inside
@@ -696,10 +724,15 @@ void postchain_kernel(PcArgs a)
     const PcFir *fir = mode == PC_MODE_AM ? &C.am.fir : mode == PC_MODE_SAM ? &C.sam.fir : mode == PC_MODE_FM ? &C.fm.hp : nullptr;
     const int nt = fir ? fir->ntaps : 1;
     if (fir) {
-        for (int i = t; i < nt; i += NT) {
-            S.h0[i] = (mode == PC_MODE_FM || !stereo) ? fir->coef[i] : fir->icoef[i];
-            S.h1[i] = fir->qcoef[i];
+        for (int i = t; i < PC_FIR_MAX + 17; i += NT) {
+            const int k = nt - 1 - (i - 4);                      // reversed, four zeros in front, zeros behind
+            const bool in = k >= 0 && k < nt;
+            S.h0[i] = in ? ((mode == PC_MODE_FM || !stereo) ? fir->coef[k] : fir->icoef[k]) : 0.f;
+            S.h1[i] = in ? fir->qcoef[k] : 0.f;
         }
+        // behind the tile the FIR window reads up to three more samples: zeros, never written again
+        for (int i = t; i < PT + PC_FIR_MAX + 17; i += NT) { S.w0[i] = 0.f; S.w1[i] = 0.f; }
+        g.sync();
         for (int i = t; i < nt - 1; i += NT) { S.w0[i] = (mode == PC_MODE_FM || (mode == PC_MODE_AM && !stereo)) ? fir->zreal[i] : fir->zr[i]; S.w1[i] = fir->zi[i]; }
     }
     pow_table(S.pw_sm, 1.0 - sm.att_a, t);
@@ -721,6 +754,12 @@ void postchain_kernel(PcArgs a)
         for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < cnt) nxt[j] = in[g0 + i]; }
     };
     if (kPrefetch && total > 0) fetch(0, a.burst < PT ? a.burst : PT);
+#ifdef PC_PROFILE
+    unsigned long long tk[16] = {0}, tlast = __builtin_readcyclecounter();
+#define PC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tk[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define PC_TICK(k)
+#endif
     for (int b = 0; b < a.nbursts; b++) {
         for (int t0 = 0; t0 < a.burst; t0 += PT) {
             const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
@@ -738,6 +777,7 @@ void postchain_kernel(PcArgs a)
                 for (int i = t; i < n; i += NT) x[i] = in[gi + i];
             }
             g.sync();
+            PC_TICK(0);
             // ---------------- S-meter (smeter.cpp:62-93) ----------------
             if (do_sm) {
                 for (int i = t; i < n; i += NT) {
@@ -748,6 +788,7 @@ void postchain_kernel(PcArgs a)
                 smeter_tile(g, sm, S.w2, n, S.pw_sm);
                 g.sync();
             }
+            PC_TICK(1);
             // ---------------- AGC (agc.cpp:174-296 / 301-401) ----------------
             if (do_agc) {
                 if (!agc.on) {
@@ -763,7 +804,9 @@ void postchain_kernel(PcArgs a)
                     }
                     g.sync();
                     // sliding maximum: pk[i] = max E[i .. i+W1], E = [W1 history | tile] = S.mg
+                    PC_TICK(2);
                     sliding_max(g, S, W1, n);
+                    PC_TICK(3);
                     // the last W1 magnitudes are the next tile's history (forward move, NT at a time)
                     for (int i0 = 0; i0 < W1; i0 += NT) {
                         const int i = i0 + t;
@@ -772,6 +815,7 @@ void postchain_kernel(PcArgs a)
                         if (i < W1) S.mg[i] = v;
                         g.sync();
                     }
+                    PC_TICK(4);
                     // attack / decay averagers -> log gain argument max(att, dec) per sample in S.pk
                     {
                         double att = agc.attack_ave, dec = agc.decay_ave;
@@ -805,6 +849,7 @@ void postchain_kernel(PcArgs a)
                         }
                     }
                     g.sync();
+                    PC_TICK(5);
                     // gain law + delay line: out[i] = in[i - D] * gain[i]; S.dl = [D old | n new]
                     const float knee = (float)agc.knee, slm1 = (float)(agc.gain_slope - 1.0), fixed_gain = (float)agc.fixed_gain;
                     float2 outv[LC];
@@ -829,6 +874,7 @@ void postchain_kernel(PcArgs a)
                     g.sync();
                 }
             }
+            PC_TICK(6);
             // x[0..n) now holds the AGC output (or the input); x = S.dl + D
             // ---------------- demodulators ----------------
             if (mode == PC_MODE_NONE || mode >= PC_MODE_USB) {
@@ -848,14 +894,14 @@ void postchain_kernel(PcArgs a)
                                         [&](int i, float, double z0, double z1) { w[i] = (float)(z0 - z1); });
                 g.sync();
                 float acc[LC], acq[LC];
-                fir_blk<NW>(S.h0, nt, w, t, acc);
+                fir_blk<NW>(S.h0, nt, S.w0, t, acc);
                 if (stereo) {
-                    fir_blk<NW>(S.h1, nt, w, t, acq);
+                    fir_blk<NW>(S.h1, nt, S.w0, t, acq);
 #pragma unroll
-                    for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < n) outs[gi + i] = make_float2(acc[j], acq[j]); }
+                    for (int j = 0; j < LC; j++) { const int i = pc_out_index<NW>(t, j); if (i < n) outs[gi + i] = make_float2(acc[j], acq[j]); }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < n) outm[gi + i] = acc[j]; }
+                    for (int j = 0; j < LC; j++) { const int i = pc_out_index<NW>(t, j); if (i < n) outm[gi + i] = acc[j]; }
                 }
                 g.sync();
                 slide(g, S.w0, nt - 1, n);
@@ -865,6 +911,7 @@ void postchain_kernel(PcArgs a)
                 float *th = S.w1 + (nt - 1), *au = S.w0 + (nt - 1);
                 for (int i = t; i < n; i += NT) th[i] = atan2f(x[i].y, x[i].x) * (float)kInvTwoPiD;
                 g.sync();
+                PC_TICK(7);
                 if (mode == PC_MODE_FM) {
                     const PcFm &F = C.fm;
                     bool scanned;
@@ -891,26 +938,30 @@ void postchain_kernel(PcArgs a)
                         fm_ph = g.bcast0(fm_ph, 0); fm_fr = g.bcast0(fm_fr, 1);
                     }
                     g.sync();
+                    PC_TICK(8);
                     {   // audio = (freq - its running mean) * gain  (fmdemod.cpp:178-186): the mean is linear
                         const double og = F.out_gain * kTwoPiD;
                         fm_dc = kTwoPiD * lin1_scan<true>(g, au, n, 1.0 - F.dc_alpha, F.dc_alpha, fm_dc * kInvTwoPiD, S.pw_fd,
                                     [&](int i, float f, double dc, double) { au[i] = (float)(((double)f - dc) * og); });
                     }
                     g.sync();
+                    PC_TICK(9);
                     // raw audio to the output row; squelch is decided at the end of the burst
                     for (int i = t; i < n; i += NT) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
                     if (a.burst <= 16384) {                               // MAX_SQBUF_SIZE
                         float acc[LC];
-                        fir_blk<NW>(S.h0, nt, au, t, acc);
+                        fir_blk<NW>(S.h0, nt, S.w0, t, acc);
 #pragma unroll
-                        for (int j = 0; j < LC; j++) S.w2[(t + NT * j) & (PT - 1)] = fabsf(acc[j]);
+                        for (int j = 0; j < LC; j++) S.w2[pc_out_index<NW>(t, j) & (PT - 1)] = fabsf(acc[j]);
                         g.sync();
                         fm_sq = lin1_scan<false>(g, S.w2, n, 1.0 - F.sq_alpha, F.sq_alpha, fm_sq, S.pw_sq,
                                                  [](int, float, double, double) {});
                     }
                     g.sync();
+                    PC_TICK(10);
                     slide(g, S.w0, nt - 1, n);
                     g.sync();
+                    PC_TICK(11);
                 } else {                                                  // SAM, samdemod.cpp:78-158
                     const PcSam &M = C.sam;
                     const double sgn = stereo ? 1.0 : -1.0;
@@ -958,11 +1009,11 @@ void postchain_kernel(PcArgs a)
                         for (int i = t; i < n; i += NT) outm[gi + i] = au[i];
                     } else {
                         float ar[LC], ai[LC];
-                        fir_blk<NW>(S.h0, nt, au, t, ar);
-                        fir_blk<NW>(S.h1, nt, th, t, ai);
+                        fir_blk<NW>(S.h0, nt, S.w0, t, ar);
+                        fir_blk<NW>(S.h1, nt, S.w1, t, ai);
 #pragma unroll
                         for (int j = 0; j < LC; j++) {                    // lower sideband left, upper right
-                            const int i = t + NT * j;
+                            const int i = pc_out_index<NW>(t, j);
                             if (i < n) outs[gi + i] = make_float2(ar[j] + ai[j], ar[j] - ai[j]);
                         }
                         g.sync();
@@ -997,6 +1048,12 @@ void postchain_kernel(PcArgs a)
         }
     }
 
+    PC_TICK(12);
+#ifdef PC_PROFILE
+    if (blockIdx.x == 0 && t == 0)
+        printf("pcprof mode %d: load %llu smeter %llu agcmag %llu slmax %llu histmove %llu aver %llu gain %llu atan %llu pll %llu dc %llu sqfir %llu slide %llu burstend %llu\n",
+               mode, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[8], tk[9], tk[10], tk[11], tk[12]);
+#endif
     // ---------------- write the state back ----------------
     g.sync();
     if (do_agc && agc.on) {
