@@ -100,6 +100,22 @@ struct PcLds {
 
 __device__ __forceinline__ double wrap_turn(double a) { return a - rint(a); }    // [-0.5, 0.5]
 
+// A wave's scan steps on the DPP network instead of __shfl_up (two ds_bpermute per double and step: an LDS-pipe
+// round trip each, and a tile runs some ninety such steps one after the other on a single wave per SIMD).
+// pc_dpp<CTRL, ROW_MASK>(v, ident): v of the source lane, `ident` where the step has none.  The six steps
+// row_shr 1, 2, 4, 8, row_bcast 15 (rows 1, 3), row_bcast 31 (rows 2, 3) leave in every lane the combination of
+// lanes 0 .. lane, like the six __shfl_up steps (associativity is all they need; identities make the lane guards
+// unnecessary); wave_shr 1 then gives the exclusive value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double pc_dpp(double v, double ident)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v), o = (unsigned long long)__double_as_longlong(ident);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#define PC_SCAN_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+
 // workgroup context: thread id, lane, wave; barrier that orders LDS traffic of the whole workgroup
 template <int NW>
 struct Wg {
@@ -142,13 +158,10 @@ struct Wg {
     // (At, Bt) = composition of all threads.
     __device__ __forceinline__ void scan1(double &A, double &B, double &At, double &Bt) const
     {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double A1 = __shfl_up(A, d), B1 = __shfl_up(B, d);
-            if (lane >= d) { B = A * B1 + B; A = A * A1; }
-        }
-        double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
-        if (lane == 0) { Ae = 1.0; Be = 0.0; }
+#define PC_STEP(C_, R_) { const double A1 = pc_dpp<C_, R_>(A, 1.0), B1 = pc_dpp<C_, R_>(B, 0.0); B = A * B1 + B; A = A * A1; }
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
+        double Ae = pc_dpp<0x138, 0xf>(A, 1.0), Be = pc_dpp<0x138, 0xf>(B, 0.0);
         if constexpr (NW == 1) {
             At = __shfl(A, 63); Bt = __shfl(B, 63);
         } else {
@@ -170,11 +183,10 @@ struct Wg {
     // maps x -> max(A x + B, C): same contract
     __device__ __forceinline__ void scan_max(double &A, double &B, double &Cc, double &At, double &Bt, double &Ct) const
     {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double A1 = __shfl_up(A, d), B1 = __shfl_up(B, d), C1 = __shfl_up(Cc, d);
-            if (lane >= d) { Cc = fmax(A * C1 + B, Cc); B = A * B1 + B; A = A * A1; }
-        }
+#define PC_STEP(C_, R_) { const double A1 = pc_dpp<C_, R_>(A, 1.0), B1 = pc_dpp<C_, R_>(B, 0.0), C1 = pc_dpp<C_, R_>(Cc, -1.0e300); \
+                          Cc = fmax(A * C1 + B, Cc); B = A * B1 + B; A = A * A1; }
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
         if constexpr (NW == 1) {
             At = __shfl(A, 63); Bt = __shfl(B, 63); Ct = __shfl(Cc, 63);
         } else {
@@ -192,20 +204,17 @@ struct Wg {
     // 2x2 affine maps s -> M s + v: same contract as scan1 (m, v in: chunk map; out: exclusive), totals in mt, vt
     __device__ __forceinline__ void scan2(double (&m)[4], double (&v)[2], double (&mt)[4], double (&vt)[2]) const
     {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double p00 = __shfl_up(m[0], d), p01 = __shfl_up(m[1], d), p10 = __shfl_up(m[2], d), p11 = __shfl_up(m[3], d);
-            const double q0 = __shfl_up(v[0], d), q1 = __shfl_up(v[1], d);
-            if (lane >= d) {
-                const double nv0 = m[0] * q0 + m[1] * q1 + v[0], nv1 = m[2] * q0 + m[3] * q1 + v[1];
-                const double n00 = m[0] * p00 + m[1] * p10, n01 = m[0] * p01 + m[1] * p11;
-                const double n10 = m[2] * p00 + m[3] * p10, n11 = m[2] * p01 + m[3] * p11;
-                m[0] = n00; m[1] = n01; m[2] = n10; m[3] = n11; v[0] = nv0; v[1] = nv1;
-            }
-        }
-        double e[4] = {__shfl_up(m[0], 1), __shfl_up(m[1], 1), __shfl_up(m[2], 1), __shfl_up(m[3], 1)};
-        double ev[2] = {__shfl_up(v[0], 1), __shfl_up(v[1], 1)};
-        if (lane == 0) { e[0] = 1.0; e[1] = 0.0; e[2] = 0.0; e[3] = 1.0; ev[0] = 0.0; ev[1] = 0.0; }
+#define PC_STEP(C_, R_) { \
+            const double p00 = pc_dpp<C_, R_>(m[0], 1.0), p01 = pc_dpp<C_, R_>(m[1], 0.0), p10 = pc_dpp<C_, R_>(m[2], 0.0), p11 = pc_dpp<C_, R_>(m[3], 1.0); \
+            const double q0 = pc_dpp<C_, R_>(v[0], 0.0), q1 = pc_dpp<C_, R_>(v[1], 0.0); \
+            const double nv0 = m[0] * q0 + m[1] * q1 + v[0], nv1 = m[2] * q0 + m[3] * q1 + v[1]; \
+            const double n00 = m[0] * p00 + m[1] * p10, n01 = m[0] * p01 + m[1] * p11; \
+            const double n10 = m[2] * p00 + m[3] * p10, n11 = m[2] * p01 + m[3] * p11; \
+            m[0] = n00; m[1] = n01; m[2] = n10; m[3] = n11; v[0] = nv0; v[1] = nv1; }
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
+        double e[4] = {pc_dpp<0x138, 0xf>(m[0], 1.0), pc_dpp<0x138, 0xf>(m[1], 0.0), pc_dpp<0x138, 0xf>(m[2], 0.0), pc_dpp<0x138, 0xf>(m[3], 1.0)};
+        double ev[2] = {pc_dpp<0x138, 0xf>(v[0], 0.0), pc_dpp<0x138, 0xf>(v[1], 0.0)};
         if constexpr (NW == 1) {
 #pragma unroll
             for (int k = 0; k < 4; k++) mt[k] = __shfl(m[k], 63);
@@ -246,8 +255,9 @@ struct Wg {
     __device__ __forceinline__ double scan_sum_excl(double x) const
     {
         double incl = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+#define PC_STEP(C_, R_) incl += pc_dpp<C_, R_>(incl, 0.0);
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
         double ex = incl - x;
         if constexpr (NW > 1) {
             if (lane == 63) S->xch[w][0] = incl;
