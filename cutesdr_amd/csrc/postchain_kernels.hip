@@ -956,8 +956,10 @@ void postchain_kernel(PcArgs a)
                     }
                     g.sync();
                     PC_TICK(9);
-                    // raw audio to the output row; squelch is decided at the end of the burst
-                    for (int i = t; i < n; i += NT) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
+                    // raw audio to the output row; squelch is decided at the end of the burst (a burst of one tile
+                    // keeps it in LDS instead: the low-pass at the end of the burst reads it from there)
+                    if (a.burst > PT)
+                        for (int i = t; i < n; i += NT) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
                     if (a.burst <= 16384) {                               // MAX_SQBUF_SIZE
                         float acc[LC];
                         fir_blk<NW>(S.h0, nt, S.w0, t, acc);
@@ -1047,7 +1049,8 @@ void postchain_kernel(PcArgs a)
                 if (fm_squelched) {
                     for (int i = t; i < n; i += NT) { if (stereo) outs[g0 + t0 + i] = make_float2(0.f, 0.f); else outm[g0 + t0 + i] = 0.f; }
                 } else {                                                  // low-pass biquad over the burst
-                    for (int i = t; i < n; i += NT) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i];
+                    if (a.burst > PT) { for (int i = t; i < n; i += NT) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i]; }
+                    else { const float *au = S.w0 + (nt - 1); for (int i = t; i < n; i += NT) S.w2[i] = au[i]; }
                     g.sync();
                     biquad_scan(g, S.w2, n, lp, S.bq);
                     g.sync();
