@@ -93,7 +93,8 @@ struct PcLds {
     double pw_sm[LCMAX + 1], pw_dc[LCMAX + 1], pw_sq[LCMAX + 1], pw_fd[LCMAX + 1];   // powers of the averager coefficients
     double bq[BQ_TAB];                   // biquad chunk tables
     double pm[(LCMAX + 1) * 4];          // PLL transition-matrix powers
-    double xch[8][8];                    // per-wave totals of a workgroup scan
+    double xch[2][8][8];                 // per-wave totals of a workgroup scan; two banks used in turn, so that a scan
+                                         // needs ONE workgroup barrier (the next scan's writes go to the other bank)
     double bc[4];                        // broadcast slot (thread 0 -> workgroup)
     int flag;                            // workgroup-wide "any"
 };
@@ -122,6 +123,8 @@ struct Wg {
     static constexpr int NT = 64 * NW, LC = PT / NT;
     int t, lane, w;
     PcLds *S;
+    mutable int bank = 0;                // exchange bank of the next workgroup scan (uniform)
+    __device__ __forceinline__ double (*xbank() const)[8] { double (*b)[8] = S->xch[bank]; bank ^= 1; return b; }
     __device__ __forceinline__ void sync() const
     {
         if constexpr (NW == 1) {
@@ -165,18 +168,18 @@ struct Wg {
         if constexpr (NW == 1) {
             At = __shfl(A, 63); Bt = __shfl(B, 63);
         } else {
-            if (lane == 63) { S->xch[w][0] = A; S->xch[w][1] = B; }
+            double (*xc)[8] = xbank();
+            if (lane == 63) { xc[w][0] = A; xc[w][1] = B; }
             __syncthreads();
             double PA = 1.0, PB = 0.0;
             At = 1.0; Bt = 0.0;
 #pragma unroll
             for (int q = 0; q < NW; q++) {
-                const double qa = S->xch[q][0], qb = S->xch[q][1];
+                const double qa = xc[q][0], qb = xc[q][1];
                 if (q < w) { PB = qa * PB + qb; PA = qa * PA; }
                 Bt = qa * Bt + qb; At = qa * At;
             }
             Be = Ae * PB + Be; Ae = Ae * PA;
-            __syncthreads();
         }
         A = Ae; B = Be;
     }
@@ -190,15 +193,15 @@ struct Wg {
         if constexpr (NW == 1) {
             At = __shfl(A, 63); Bt = __shfl(B, 63); Ct = __shfl(Cc, 63);
         } else {
-            if (lane == 63) { S->xch[w][0] = A; S->xch[w][1] = B; S->xch[w][2] = Cc; }
+            double (*xc)[8] = xbank();
+            if (lane == 63) { xc[w][0] = A; xc[w][1] = B; xc[w][2] = Cc; }
             __syncthreads();
             At = 1.0; Bt = 0.0; Ct = -1.0e300;
 #pragma unroll
             for (int q = 0; q < NW; q++) {
-                const double qa = S->xch[q][0], qb = S->xch[q][1], qc = S->xch[q][2];
+                const double qa = xc[q][0], qb = xc[q][1], qc = xc[q][2];
                 Ct = fmax(qa * Ct + qb, qc); Bt = qa * Bt + qb; At = qa * At;
             }
-            __syncthreads();
         }
     }
     // 2x2 affine maps s -> M s + v: same contract as scan1 (m, v in: chunk map; out: exclusive), totals in mt, vt
@@ -220,17 +223,18 @@ struct Wg {
             for (int k = 0; k < 4; k++) mt[k] = __shfl(m[k], 63);
             vt[0] = __shfl(v[0], 63); vt[1] = __shfl(v[1], 63);
         } else {
+            double (*xc)[8] = xbank();
             if (lane == 63) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) S->xch[w][k] = m[k];
-                S->xch[w][4] = v[0]; S->xch[w][5] = v[1];
+                for (int k = 0; k < 4; k++) xc[w][k] = m[k];
+                xc[w][4] = v[0]; xc[w][5] = v[1];
             }
             __syncthreads();
             double P[4] = {1.0, 0.0, 0.0, 1.0}, Pv[2] = {0.0, 0.0};
             mt[0] = 1.0; mt[1] = 0.0; mt[2] = 0.0; mt[3] = 1.0; vt[0] = 0.0; vt[1] = 0.0;
 #pragma unroll
             for (int q = 0; q < NW; q++) {
-                const double *x = S->xch[q];
+                const double *x = xc[q];
                 auto apply = [&](double (&M)[4], double (&V)[2]) {
                     const double nv0 = x[0] * V[0] + x[1] * V[1] + x[4], nv1 = x[2] * V[0] + x[3] * V[1] + x[5];
                     const double n00 = x[0] * M[0] + x[1] * M[2], n01 = x[0] * M[1] + x[1] * M[3];
@@ -245,7 +249,6 @@ struct Wg {
             const double n00 = e[0] * P[0] + e[1] * P[2], n01 = e[0] * P[1] + e[1] * P[3];
             const double n10 = e[2] * P[0] + e[3] * P[2], n11 = e[2] * P[1] + e[3] * P[3];
             e[0] = n00; e[1] = n01; e[2] = n10; e[3] = n11; ev[0] = nv0; ev[1] = nv1;
-            __syncthreads();
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) m[k] = e[k];
@@ -260,11 +263,11 @@ struct Wg {
 #undef PC_STEP
         double ex = incl - x;
         if constexpr (NW > 1) {
-            if (lane == 63) S->xch[w][0] = incl;
+            double (*xc)[8] = xbank();
+            if (lane == 63) xc[w][0] = incl;
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < NW; q++) if (q < w) ex += S->xch[q][0];
-            __syncthreads();
+            for (int q = 0; q < NW; q++) if (q < w) ex += xc[q][0];
         }
         return ex;
     }
@@ -273,10 +276,10 @@ struct Wg {
     {
         float p = __shfl_up(v, 1);
         if constexpr (NW > 1) {
-            if (lane == 63) S->xch[w][6] = (double)v;
+            double (*xc)[8] = xbank();
+            if (lane == 63) xc[w][6] = (double)v;
             __syncthreads();
-            if (lane == 0 && w > 0) p = (float)S->xch[w - 1][6];
-            __syncthreads();
+            if (lane == 0 && w > 0) p = (float)xc[w - 1][6];
         }
         return t == 0 ? first : p;
     }
@@ -817,12 +820,14 @@ void postchain_kernel(PcArgs a)
                     PC_TICK(2);
                     sliding_max(g, S, W1, n);
                     PC_TICK(3);
-                    // the last W1 magnitudes are the next tile's history (forward move, NT at a time)
-                    for (int i0 = 0; i0 < W1; i0 += NT) {
-                        const int i = i0 + t;
-                        const float v = S.mg[(i < W1 ? i : 0) + n];
+                    // the last W1 magnitudes are the next tile's history: read all, one barrier, write all
+                    {
+                        float keepm[PH / NT];
+#pragma unroll
+                        for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) keepm[j] = S.mg[n + i]; }
                         g.sync();
-                        if (i < W1) S.mg[i] = v;
+#pragma unroll
+                        for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) S.mg[i] = keepm[j]; }
                         g.sync();
                     }
                     PC_TICK(4);
