@@ -22,18 +22,35 @@ namespace csdr {
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int NB_T = 256, NB_PER = 4, NB_TILE = NB_T * NB_PER;
 
-__device__ __forceinline__ double wave_incl_scan_add(double v, int lane)
+// Wave scans on the DPP network (row_shr 1, 2, 4, 8, then row_bcast 15 into rows 1, 3 and row_bcast 31 into rows
+// 2, 3; a step without a source lane reads the identity) instead of __shfl_up: a 64-bit shuffle is two
+// ds_bpermute -- an LDS-pipe round trip per step, twelve steps per tile on every wave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long nb_dpp64(unsigned long long v, unsigned long long ident)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(v, d); if (lane >= d) v += o; }
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)ident, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(ident >> 32), (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define NB_SCAN_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+__device__ __forceinline__ double wave_incl_scan_add(double v, int)
+{
+#define NB_STEP(C_, R_) v += __longlong_as_double((long long)nb_dpp64<C_, R_>((unsigned long long)__double_as_longlong(v), 0ull));
+    NB_SCAN_STEPS(NB_STEP)
+#undef NB_STEP
     return v;
 }
-__device__ __forceinline__ long long wave_incl_scan_max(long long v, int lane)
+constexpr long long NB_NEVER = -(1LL << 60);
+__device__ __forceinline__ long long wave_incl_scan_max(long long v, int)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(v, d); if (lane >= d && o > v) v = o; }
+#define NB_STEP(C_, R_) { const long long o = (long long)nb_dpp64<C_, R_>((unsigned long long)v, (unsigned long long)NB_NEVER); v = o > v ? o : v; }
+    NB_SCAN_STEPS(NB_STEP)
+#undef NB_STEP
     return v;
 }
+// the value of the lane in front (lane 0: NB_NEVER)
+__device__ __forceinline__ long long wave_prev_lane(long long v)
+{ return (long long)nb_dpp64<0x138, 0xf>((unsigned long long)v, (unsigned long long)NB_NEVER); }
 
 __global__ __launch_bounds__(NB_T)
 void noiseblank_kernel(NbArgs a)
@@ -137,8 +154,8 @@ void noiseblank_kernel(NbArgs a)
             __syncthreads();
             long long before = last;                       // latest trigger before this thread's samples
             for (int q = 0; q < w; q++) before = wmax[q] > before ? wmax[q] : before;
-            const long long upto = __shfl_up(inclm, 1);
-            if (lane > 0 && upto > before) before = upto;
+            const long long upto = wave_prev_lane(inclm);
+            if (upto > before) before = upto;
             long long tile_last = last;
             for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
 #pragma unroll
