@@ -183,6 +183,33 @@ struct Wg {
         }
         A = Ae; B = Be;
     }
+    // two independent scans of that kind in lockstep: one wave per SIMD pays every instruction's latency, and
+    // the two dependency chains fill each other's gaps; one exchange, one barrier
+    __device__ __forceinline__ void scan1x2(double &A, double &B, double &At, double &Bt, double &C, double &D, double &Ct, double &Dt) const
+    {
+#define PC_STEP(C_, R_) { const double A1 = pc_dpp<C_, R_>(A, 1.0), B1 = pc_dpp<C_, R_>(B, 0.0), C1 = pc_dpp<C_, R_>(C, 1.0), D1 = pc_dpp<C_, R_>(D, 0.0); \
+                          B = A * B1 + B; A = A * A1; D = C * D1 + D; C = C * C1; }
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
+        double Ae = pc_dpp<0x138, 0xf>(A, 1.0), Be = pc_dpp<0x138, 0xf>(B, 0.0), Ce = pc_dpp<0x138, 0xf>(C, 1.0), De = pc_dpp<0x138, 0xf>(D, 0.0);
+        if constexpr (NW == 1) {
+            At = __shfl(A, 63); Bt = __shfl(B, 63); Ct = __shfl(C, 63); Dt = __shfl(D, 63);
+        } else {
+            double (*xc)[8] = xbank();
+            if (lane == 63) { xc[w][0] = A; xc[w][1] = B; xc[w][2] = C; xc[w][3] = D; }
+            __syncthreads();
+            double PA = 1.0, PB = 0.0, PC = 1.0, PD = 0.0;
+            At = 1.0; Bt = 0.0; Ct = 1.0; Dt = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const double qa = xc[q][0], qb = xc[q][1], qc = xc[q][2], qd = xc[q][3];
+                if (q < w) { PB = qa * PB + qb; PA = qa * PA; PD = qc * PD + qd; PC = qc * PC; }
+                Bt = qa * Bt + qb; At = qa * At; Dt = qc * Dt + qd; Ct = qc * Ct;
+            }
+            Be = Ae * PB + Be; Ae = Ae * PA; De = Ce * PD + De; Ce = Ce * PC;
+        }
+        A = Ae; B = Be; C = Ce; D = De;
+    }
     // maps x -> max(A x + B, C): same contract
     __device__ __forceinline__ void scan_max(double &A, double &B, double &Cc, double &At, double &Bt, double &Ct) const
     {
@@ -274,7 +301,7 @@ struct Wg {
     // value of thread t-1 (thread 0 gets `first`)
     __device__ __forceinline__ float prev_thread(float v, float first) const
     {
-        float p = __shfl_up(v, 1);
+        float p = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));   // wave_shr:1
         if constexpr (NW > 1) {
             double (*xc)[8] = xbank();
             if (lane == 63) xc[w][6] = (double)v;
@@ -536,6 +563,60 @@ __device__ __forceinline__ bool agc_ave_scan(const Wg<NW> &g, const float *pk, i
             return true;
         }
         sel = nsel;
+    }
+    return false;
+}
+
+// Both averagers (attack, decay) of a tile in the same rounds: their scans are independent, and run in lockstep
+// (Wg::scan1x2).  emit(i, attack_i, decay_i).
+template <int NW, class F>
+__device__ __forceinline__ bool agc_ave_scan2(const Wg<NW> &g, const float *pk, int n, double a_rise, double a_fall, double d_rise,
+                                              double d_fall, double &att, double &dec, F emit)
+{
+    constexpr int LC = Wg<NW>::LC;
+    const int base = LC * g.t;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    const double att0 = att, dec0 = dec;
+    float pv[LC];
+    unsigned sa = 0, sd = 0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        pv[j] = j < cnt ? pk[base + j] : 0.f;
+        if (j < cnt && (double)pv[j] > att0) sa |= 1u << j;
+        if (j < cnt && (double)pv[j] > dec0) sd |= 1u << j;
+    }
+    for (int round = 0; round < PC_AGC_ROUNDS; round++) {
+        double A = 1.0, B = 0.0, At, Bt, C = 1.0, D = 0.0, Ct, Dt;
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            if (j < cnt) {
+                const double al = (sa >> j & 1) ? a_rise : a_fall, dl = (sd >> j & 1) ? d_rise : d_fall;
+                A = A - al * A; B = B + al * ((double)pv[j] - B);
+                C = C - dl * C; D = D + dl * ((double)pv[j] - D);
+            }
+        }
+        g.scan1x2(A, B, At, Bt, C, D, Ct, Dt);
+        double x = A * att0 + B, y = C * dec0 + D;
+        double va[LC], vd[LC];
+        unsigned na = 0, nd = 0;
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            if (j < cnt) {
+                if ((double)pv[j] > x) na |= 1u << j;
+                if ((double)pv[j] > y) nd |= 1u << j;
+                const double al = (sa >> j & 1) ? a_rise : a_fall, dl = (sd >> j & 1) ? d_rise : d_fall;
+                x = x + al * ((double)pv[j] - x);
+                y = y + dl * ((double)pv[j] - y);
+            }
+            va[j] = x; vd[j] = y;
+        }
+        if (!g.any(na != sa || nd != sd)) {
+#pragma unroll
+            for (int j = 0; j < LC; j++) if (j < cnt) emit(base + j, va[j], vd[j]);
+            att = At * att0 + Bt; dec = Ct * dec0 + Dt;
+            return true;
+        }
+        sa = na; sd = nd;
     }
     return false;
 }
@@ -835,10 +916,15 @@ void postchain_kernel(PcArgs a)
                     {
                         double att = agc.attack_ave, dec = agc.decay_ave;
                         bool ok = !agc.hang;                              // the hang timer is a counter: walked
-                        if (ok) ok = agc_ave_scan(g, S.pk, n, agc.att_rise, agc.att_fall, att,
-                                                  [&](int i, double v) { S.w2[i] = (float)v; });
-                        if (ok) ok = agc_ave_scan(g, S.pk, n, agc.dec_rise, agc.dec_fall, dec,
-                                                  [&](int i, double v) { S.pk[i] = fmaxf(S.w2[i], (float)v); });
+                        if constexpr (NW == 4) {           // (16 samples per thread would not fit the registers twice)
+                            if (ok) ok = agc_ave_scan2(g, S.pk, n, agc.att_rise, agc.att_fall, agc.dec_rise, agc.dec_fall, att, dec,
+                                                       [&](int i, double va, double vd) { S.pk[i] = fmaxf((float)va, (float)vd); });
+                        } else {
+                            if (ok) ok = agc_ave_scan(g, S.pk, n, agc.att_rise, agc.att_fall, att,
+                                                      [&](int i, double v) { S.w2[i] = (float)v; });
+                            if (ok) ok = agc_ave_scan(g, S.pk, n, agc.dec_rise, agc.dec_fall, dec,
+                                                      [&](int i, double v) { S.pk[i] = fmaxf(S.w2[i], (float)v); });
+                        }
                         if (ok) { agc.attack_ave = att; agc.decay_ave = dec; }
                         else {
                             g.sync();
