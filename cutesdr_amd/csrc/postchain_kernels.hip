@@ -183,6 +183,32 @@ struct Wg {
         }
         A = Ae; B = Be;
     }
+    // scan1 and, in lockstep with it, the workgroup maximum of pk (returned in pk on every thread)
+    __device__ __forceinline__ void scan1_max(double &A, double &B, double &At, double &Bt, double &pk) const
+    {
+#define PC_STEP(C_, R_) { const double A1 = pc_dpp<C_, R_>(A, 1.0), B1 = pc_dpp<C_, R_>(B, 0.0), P1 = pc_dpp<C_, R_>(pk, -1.0e300); \
+                          B = A * B1 + B; A = A * A1; pk = fmax(pk, P1); }
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
+        double Ae = pc_dpp<0x138, 0xf>(A, 1.0), Be = pc_dpp<0x138, 0xf>(B, 0.0);
+        if constexpr (NW == 1) {
+            At = __shfl(A, 63); Bt = __shfl(B, 63); pk = __shfl(pk, 63);
+        } else {
+            double (*xc)[8] = xbank();
+            if (lane == 63) { xc[w][0] = A; xc[w][1] = B; xc[w][2] = pk; }
+            __syncthreads();
+            double PA = 1.0, PB = 0.0;
+            At = 1.0; Bt = 0.0; pk = -1.0e300;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const double qa = xc[q][0], qb = xc[q][1];
+                if (q < w) { PB = qa * PB + qb; PA = qa * PA; }
+                Bt = qa * Bt + qb; At = qa * At; pk = fmax(pk, xc[q][2]);
+            }
+            Be = Ae * PB + Be; Ae = Ae * PA;
+        }
+        A = Ae; B = Be;
+    }
     // two independent scans of that kind in lockstep: one wave per SIMD pays every instruction's latency, and
     // the two dependency chains fill each other's gaps; one exchange, one barrier
     __device__ __forceinline__ void scan1x2(double &A, double &B, double &At, double &Bt, double &C, double &D, double &Ct, double &Dt) const
@@ -452,7 +478,7 @@ __device__ __forceinline__ void smeter_tile(const Wg<NW> &g, PcSMeter &sm, const
         if (j < cnt) pk = fmax(pk, (double)xv[j]);
     }
     double A = apw_att[cnt], B = p, At, Bt;
-    g.scan1(A, B, At, Bt);
+    g.scan1_max(A, B, At, Bt, pk);                                   // pk: now the maximum of the whole tile
     const double S = A * sm.att_ave + B;
     const double att_end = At * sm.att_ave + Bt;
     double MA = 1.0, MB = 0.0, MC = -1.0e300, TA, TB, TC;            // chunk map of the decay average
@@ -465,10 +491,7 @@ __device__ __forceinline__ void smeter_tile(const Wg<NW> &g, PcSMeter &sm, const
     }
     g.scan_max(MA, MB, MC, TA, TB, TC);
     const double dec_end = fmax(TA * sm.dec_ave + TB, TC);
-    // workgroup maximum of the dB values through the same machinery: x -> max(x, pk)
-    double QA = 1.0, QB = 0.0, QC = pk, UA, UB, UC;
-    g.scan_max(QA, QB, QC, UA, UB, UC);
-    sm.att_ave = att_end; sm.dec_ave = dec_end; sm.ave_mag = dec_end; sm.peak_mag = fmax(UA * sm.peak_mag + UB, UC);
+    sm.att_ave = att_end; sm.dec_ave = dec_end; sm.ave_mag = dec_end; sm.peak_mag = fmax(sm.peak_mag, pk);
 }
 
 // CIir direct form II (iir.cpp:171-186) over x[0..n) in place.  State s = (w1, w2):
