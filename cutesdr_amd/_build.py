@@ -34,6 +34,16 @@ DC_PLANS = [
     (11, 11, 15, 19, 31), (11, 11, 15, 23, 51),
     (11, 11, 11, 11, 15, 19), (11, 11, 11, 15, 23, 51),
     (3, 3, 11, 11, 11, 11, 15),
+    # the same bandwidths at other common front-end rates (1.024 / 2.048 / 2.4 / 2.5 / 3.2 / 8 / 10 MS/s; SURVEY's
+    # config C5 is 10 MS/s FM): tools/list_dc_plans.py --more
+    (11, 15, 19, 31), (11, 15, 23, 47),
+    (11, 11, 11, 15, 27), (11, 11, 11, 19, 27), (11, 11, 15, 19, 35), (11, 11, 15, 23, 47),
+    (11, 11, 11, 11, 19, 27), (11, 11, 11, 15, 19, 35), (11, 11, 11, 15, 23, 43), (11, 11, 11, 15, 23, 47),
+    (3, 11, 11, 11, 11, 15, 19), (3, 11, 11, 11, 11, 15, 27), (11, 11, 11, 11, 15, 19, 31),
+    (11, 11, 11, 11, 15, 19, 35), (11, 11, 11, 11, 15, 23, 51),
+    (3, 3, 3, 11, 11, 11, 11, 15), (3, 3, 11, 11, 11, 11, 15, 19), (3, 11, 11, 11, 11, 15, 19, 35),
+    (3, 11, 11, 11, 11, 15, 23, 51),
+    (3, 3, 3, 3, 11, 11, 11, 11, 15),
 ]
 JOBS = max(1, min(8, os.cpu_count() or 1))
 

@@ -21,11 +21,20 @@ def plan(rate, bw):
     return tuple(k)
 
 RATES = [66666666.6667 / d for d in (1200.0, 600.0, 420.0, 340.0)] + [80.0e6 / d for d in (1280.0, 320.0, 128.0, 130.0, 40.0)]
+MORE_RATES = [1.024e6, 2.048e6, 2.4e6, 2.5e6, 3.2e6, 8e6, 10e6]          # other common front ends (--more)
 BWS = [1000.0, 10000.0, 15000.0, 20000.0]
-plans = {}
-for r in RATES:
-    for b in BWS:
-        plans.setdefault(plan(r, b), []).append("%.0f/%.0f" % (r, b))
+
+def table(rates, skip=()):
+    plans = {}
+    for r in rates:
+        for b in BWS:
+            p = plan(r, b)
+            if p and p not in skip: plans.setdefault(p, []).append("%.0f/%.0f" % (r, b))
+    return plans
+
+plans = table(RATES)
 if __name__ == "__main__":
-    for p in sorted(plans, key=lambda p: (len(p), p)):
-        if p: print("    %-40s # %s" % (str(p) + ",", ", ".join(plans[p])))
+    import sys
+    show = table(MORE_RATES, skip=plans) if "--more" in sys.argv else plans
+    for p in sorted(show, key=lambda p: (len(p), p)):
+        print("    %-44s # %s" % (str(p) + ",", ", ".join(show[p])))
