@@ -209,6 +209,59 @@ struct Wg {
         }
         A = Ae; B = Be;
     }
+    // scan1 and scan2 in lockstep (the FM squelch average and the speculative audio low-pass of a one-tile burst)
+    __device__ __forceinline__ void scan1_2(double &A, double &B, double &At, double &Bt, double (&m)[4], double (&v)[2], double (&mt)[4],
+                                            double (&vt)[2]) const
+    {
+#define PC_STEP(C_, R_) { \
+            const double A1 = pc_dpp<C_, R_>(A, 1.0), B1 = pc_dpp<C_, R_>(B, 0.0); \
+            const double p00 = pc_dpp<C_, R_>(m[0], 1.0), p01 = pc_dpp<C_, R_>(m[1], 0.0), p10 = pc_dpp<C_, R_>(m[2], 0.0), p11 = pc_dpp<C_, R_>(m[3], 1.0); \
+            const double q0 = pc_dpp<C_, R_>(v[0], 0.0), q1 = pc_dpp<C_, R_>(v[1], 0.0); \
+            B = A * B1 + B; A = A * A1; \
+            const double nv0 = m[0] * q0 + m[1] * q1 + v[0], nv1 = m[2] * q0 + m[3] * q1 + v[1]; \
+            const double n00 = m[0] * p00 + m[1] * p10, n01 = m[0] * p01 + m[1] * p11; \
+            const double n10 = m[2] * p00 + m[3] * p10, n11 = m[2] * p01 + m[3] * p11; \
+            m[0] = n00; m[1] = n01; m[2] = n10; m[3] = n11; v[0] = nv0; v[1] = nv1; }
+        PC_SCAN_STEPS(PC_STEP)
+#undef PC_STEP
+        double Ae = pc_dpp<0x138, 0xf>(A, 1.0), Be = pc_dpp<0x138, 0xf>(B, 0.0);
+        double e[4] = {pc_dpp<0x138, 0xf>(m[0], 1.0), pc_dpp<0x138, 0xf>(m[1], 0.0), pc_dpp<0x138, 0xf>(m[2], 0.0), pc_dpp<0x138, 0xf>(m[3], 1.0)};
+        double ev[2] = {pc_dpp<0x138, 0xf>(v[0], 0.0), pc_dpp<0x138, 0xf>(v[1], 0.0)};
+        static_assert(NW > 1, "scan1_2 is used by the four-wave kernel only");
+        double (*xc)[8] = xbank();
+        if (lane == 63) {
+            xc[w][0] = A; xc[w][1] = B;
+#pragma unroll
+            for (int k = 0; k < 4; k++) xc[w][2 + k] = m[k];
+            xc[w][6] = v[0]; xc[w][7] = v[1];
+        }
+        __syncthreads();
+        double PA = 1.0, PB = 0.0, P[4] = {1.0, 0.0, 0.0, 1.0}, Pv[2] = {0.0, 0.0};
+        At = 1.0; Bt = 0.0; mt[0] = 1.0; mt[1] = 0.0; mt[2] = 0.0; mt[3] = 1.0; vt[0] = 0.0; vt[1] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const double *x = xc[q];
+            auto apply = [&](double (&M)[4], double (&V)[2]) {
+                const double nv0 = x[2] * V[0] + x[3] * V[1] + x[6], nv1 = x[4] * V[0] + x[5] * V[1] + x[7];
+                const double n00 = x[2] * M[0] + x[3] * M[2], n01 = x[2] * M[1] + x[3] * M[3];
+                const double n10 = x[4] * M[0] + x[5] * M[2], n11 = x[4] * M[1] + x[5] * M[3];
+                M[0] = n00; M[1] = n01; M[2] = n10; M[3] = n11; V[0] = nv0; V[1] = nv1;
+            };
+            if (q < w) { PB = x[0] * PB + x[1]; PA = x[0] * PA; apply(P, Pv); }
+            Bt = x[0] * Bt + x[1]; At = x[0] * At; apply(mt, vt);
+        }
+        Be = Ae * PB + Be; Ae = Ae * PA;
+        {
+            const double nv0 = e[0] * Pv[0] + e[1] * Pv[1] + ev[0], nv1 = e[2] * Pv[0] + e[3] * Pv[1] + ev[1];
+            const double n00 = e[0] * P[0] + e[1] * P[2], n01 = e[0] * P[1] + e[1] * P[3];
+            const double n10 = e[2] * P[0] + e[3] * P[2], n11 = e[2] * P[1] + e[3] * P[3];
+            e[0] = n00; e[1] = n01; e[2] = n10; e[3] = n11; ev[0] = nv0; ev[1] = nv1;
+        }
+        A = Ae; B = Be;
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = e[k];
+        v[0] = ev[0]; v[1] = ev[1];
+    }
     // two independent scans of that kind in lockstep: one wave per SIMD pays every instruction's latency, and
     // the two dependency chains fill each other's gaps; one exchange, one barrier
     __device__ __forceinline__ void scan1x2(double &A, double &B, double &At, double &Bt, double &C, double &D, double &Ct, double &Dt) const
@@ -532,6 +585,39 @@ __device__ __forceinline__ void biquad_scan(const Wg<NW> &g, float *x, int n, Pc
         if (j < cnt) x[base + j] = (float)(y[j] + tab[68 + 2 * j] * S1 + tab[68 + 2 * j + 1] * S2);
     const double nw1 = mt[0] * f.w1a + mt[1] * f.w2a + vt[0], nw2 = mt[2] * f.w1a + mt[3] * f.w2a + vt[1];
     f.w1a = nw1; f.w2a = nw2;
+}
+
+// One-tile FM burst: the squelch average (lin1_scan without emit over sq[0..n)) and, in lockstep with it, the audio
+// low-pass of the burst over x[0..n) (biquad_scan) -- speculatively: whether the burst is squelched is only known
+// from the average, so the filtered samples stay in registers (y, this thread's LC consecutive ones) and the
+// filter state after the burst is returned in (w1n, w2n) for the caller to commit or drop.
+template <int NW>
+__device__ __forceinline__ double sq_and_lowpass(const Wg<NW> &g, const float *sq, const float *x, int n, double a, double gn, double s0,
+                                                 const double *apw, const PcIir &f, const double *tab, float (&y)[Wg<NW>::LC],
+                                                 double &w1n, double &w2n)
+{
+    constexpr int LC = Wg<NW>::LC;
+    const int base = LC * g.t;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    double p = 0.0, yy[LC], w1 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        const float sv = j < cnt ? sq[base + j] : 0.f;
+        p = j < cnt ? a * p + gn * (double)sv : p;
+        const double xv = j < cnt ? (double)x[base + j] : 0.0;
+        const double w0 = xv - f.a1 * w1 - f.a2 * w2;
+        yy[j] = f.b0 * w0 + f.b1 * w1 + f.b2 * w2;
+        if (j < cnt) { w2 = w1; w1 = w0; }
+    }
+    double A = apw[cnt], B = p, At, Bt;
+    double m[4] = {tab[4 * cnt], tab[4 * cnt + 1], tab[4 * cnt + 2], tab[4 * cnt + 3]}, v[2] = {w1, w2}, mt[4], vt[2];
+    g.scan1_2(A, B, At, Bt, m, v, mt, vt);
+    const double S1 = m[0] * f.w1a + m[1] * f.w2a + v[0], S2 = m[2] * f.w1a + m[3] * f.w2a + v[1];
+#pragma unroll
+    for (int j = 0; j < LC; j++) y[j] = (float)(yy[j] + tab[68 + 2 * j] * S1 + tab[68 + 2 * j + 1] * S2);
+    w1n = mt[0] * f.w1a + mt[1] * f.w2a + vt[0];
+    w2n = mt[2] * f.w1a + mt[3] * f.w2a + vt[1];
+    return At * s0 + Bt;
 }
 
 // CAgc's attack / decay averagers (agc.cpp:233-262):  ave += alpha (pk - ave),  alpha = rise when
@@ -877,6 +963,10 @@ void postchain_kernel(PcArgs a)
 #else
 #define PC_TICK(k)
 #endif
+    float lp_y[LC];                                       // one-tile FM burst: its low-passed audio, kept until the squelch decision
+    double lp_w1 = 0.0, lp_w2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) lp_y[j] = 0.f;
     for (int b = 0; b < a.nbursts; b++) {
         for (int t0 = 0; t0 < a.burst; t0 += PT) {
             const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
@@ -1080,6 +1170,12 @@ void postchain_kernel(PcArgs a)
 #pragma unroll
                         for (int j = 0; j < LC; j++) S.w2[pc_out_index<NW>(t, j) & (PT - 1)] = fabsf(acc[j]);
                         g.sync();
+                        if constexpr (NW == 4) {
+                            if (a.burst <= PT) fm_sq = sq_and_lowpass(g, S.w2, au, n, 1.0 - F.sq_alpha, F.sq_alpha, fm_sq, S.pw_sq, lp, S.bq,
+                                                                      lp_y, lp_w1, lp_w2);
+                            else fm_sq = lin1_scan<false>(g, S.w2, n, 1.0 - F.sq_alpha, F.sq_alpha, fm_sq, S.pw_sq,
+                                                          [](int, float, double, double) {});
+                        } else
                         fm_sq = lin1_scan<false>(g, S.w2, n, 1.0 - F.sq_alpha, F.sq_alpha, fm_sq, S.pw_sq,
                                                  [](int, float, double, double) {});
                     }
@@ -1162,6 +1258,13 @@ void postchain_kernel(PcArgs a)
                 const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
                 if (fm_squelched) {
                     for (int i = t; i < n; i += NT) { if (stereo) outs[g0 + t0 + i] = make_float2(0.f, 0.f); else outm[g0 + t0 + i] = 0.f; }
+                } else if (NW == 4 && a.burst <= PT) {                    // the low-pass ran with the squelch average: commit it
+#pragma unroll
+                    for (int j = 0; j < LC; j++) {
+                        const int i = LC * t + j;
+                        if (i < n) { if (stereo) outs[g0 + i] = make_float2(lp_y[j], lp_y[j]); else outm[g0 + i] = lp_y[j]; }
+                    }
+                    lp.w1a = lp_w1; lp.w2a = lp_w2;
                 } else {                                                  // low-pass biquad over the burst
                     if (a.burst > PT) { for (int i = t; i < n; i += NT) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i]; }
                     else { const float *au = S.w0 + (nt - 1); for (int i = t; i < n; i += NT) S.w2[i] = au[i]; }
