@@ -130,3 +130,22 @@ def test_biquad_and_agc_parameters_match_oracle(L, oracle):
     assert p[2] == pytest.approx(0.7 * 10 ** 5.0)
     assert (p[8], p[9], p[10]) == (937, 1125, 12500)
     assert p[4] == pytest.approx(1 - np.exp(-1 / (62500 * .002)))
+
+
+def test_precompiled_decimator_plans_are_the_documented_rate_bandwidth_table():
+    """DC_PLANS (cutesdr_amd/_build.py: the stage sequences the down-converter kernel is compiled for) is exactly what
+    tools/list_dc_plans.py derives from the reference's radio rates x demodulator bandwidths plus the listed other
+    front-end rates -- and every entry is a sequence SetDataRate's selection rule can produce (CIC-3s, then 11-tap
+    half bands, then non-decreasing longer ones)."""
+    import importlib.util, os
+    from cutesdr_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("list_dc_plans", os.path.join(root, "tools", "list_dc_plans.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    ref = m.table(m.RATES)
+    more = m.table(m.MORE_RATES, skip=ref)
+    assert set(_build.DC_PLANS) == set(ref) | set(more)
+    assert len(set(_build.DC_PLANS)) == len(_build.DC_PLANS)
+    for p in _build.DC_PLANS:
+        assert 1 <= len(p) <= 9 and all(k in (3, 11, 15, 19, 23, 27, 31, 35, 39, 43, 47, 51) for k in p)
+        assert list(p) == sorted(p)
