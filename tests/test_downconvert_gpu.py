@@ -140,3 +140,42 @@ def test_precompiled_plans_reproduce_the_runtime_plan_kernel(oracle):
             assert np.abs(outs[0] - np.concatenate(refs)).max() <= TOL
     finally:
         L.csdr__downconv_force_dynamic(0)
+
+
+def test_every_precompiled_plan_runs_and_matches_the_runtime_plan_kernel():
+    """All of DC_PLANS, each at a (rate, bandwidth) pair that selects it: the plan-compiled kernel and the run-time-plan
+    kernel give the same words on a three-call stream with a ragged middle call."""
+    import ctypes as C, importlib.util, os
+    import cutesdr_amd as ca
+    from cutesdr_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("list_dc_plans", os.path.join(root, "tools", "list_dc_plans.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    pairs = {}
+    for tab in (m.table(m.RATES), m.table(m.MORE_RATES)):
+        for p, where in tab.items():
+            pairs.setdefault(p, where[0])
+    L = ca.lib()
+    L.csdr__downconv_force_dynamic.restype = C.c_int
+    L.csdr__downconv_force_dynamic.argtypes = [C.c_int]
+    try:
+        for plan in _build.DC_PLANS:
+            in_rate, bw = pairs[plan]
+            unit = 1 << len(plan)
+            calls = [8192, 2048 + 3 * unit, 4096]
+            x = tones_plus_noise(5, sum(calls), in_rate, [in_rate * 0.07 + 200.0, in_rate * 0.07 - 700.0, in_rate * 0.21])
+            outs = []
+            for dyn in (0, 1):
+                L.csdr__downconv_force_dynamic(dyn)
+                dc = ca.CDownConvert()
+                dc.SetDataRate(in_rate, bw)
+                assert tuple(dc.stages()) == plan, (in_rate, bw)
+                dc.SetFrequency(-in_rate * 0.07)
+                pos, got = 0, []
+                for n in calls:
+                    got.append(dc.ProcessData(x[pos:pos + n])); pos += n
+                outs.append(np.concatenate(got))
+            assert len(outs[0]) == sum(calls) >> len(plan)
+            assert np.array_equal(outs[0], outs[1]), plan
+    finally:
+        L.csdr__downconv_force_dynamic(0)

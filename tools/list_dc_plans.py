@@ -29,7 +29,7 @@ def table(rates, skip=()):
     for r in rates:
         for b in BWS:
             p = plan(r, b)
-            if p and p not in skip: plans.setdefault(p, []).append("%.0f/%.0f" % (r, b))
+            if p and p not in skip: plans.setdefault(p, []).append((r, b))
     return plans
 
 plans = table(RATES)
@@ -37,4 +37,4 @@ if __name__ == "__main__":
     import sys
     show = table(MORE_RATES, skip=plans) if "--more" in sys.argv else plans
     for p in sorted(show, key=lambda p: (len(p), p)):
-        print("    %-44s # %s" % (str(p) + ",", ", ".join(show[p])))
+        print("    %-44s # %s" % (str(p) + ",", ", ".join("%.0f/%.0f" % rb for rb in show[p])))
