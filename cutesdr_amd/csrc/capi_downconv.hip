@@ -244,7 +244,9 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long
         long min_seg = (long)DC_TILE_SAMPLES * 8;
         if (min_seg < (long)p.W * 8) min_seg = (long)p.W * 8;
-        long nseg = (8192 + a.nchan - 1) / a.nchan;
+        // at most 8192 workgroups = two full rounds of the chip's 4096 one-wave slots (256 CUs x 16): a few more
+        // would start a third, nearly empty round (86 channels x 96 segments = 8256 took 1.8x the time of 85 x 96)
+        long nseg = 8192 / a.nchan;
         if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
         if (nseg < 1) nseg = 1;
         long seg_len = (n_per_channel + nseg - 1) / nseg;

@@ -59,9 +59,10 @@ inline DcPlan dc_make_plan(double in_rate, double max_bw)
     }
     p.nstages = n;
     p.out_rate = f;
-    const long unit = 1L << n;
+    // whole tiles: a segment's warm-up then runs through the kernel's complete-tile path only (a short tile takes
+    // the general stage code, several times a complete tile's cost), and 512 is a multiple of every 2^n here
+    const long unit = DC_TILE_SAMPLES > (1L << n) ? DC_TILE_SAMPLES : (1L << n);
     p.W = n ? (int)((need + unit - 1) / unit * unit) : 0;
-    if (p.W & 1) p.W++;
     return p;
 }
 
