@@ -22,29 +22,56 @@ FILE_FLAGS = {"fastfir2_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp
               "spectrum_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}   # K3: +4 %; K2/K4 measured slower with it
 
 
-# Decimator plans the down-converter is compiled for (downconv_plan.hip, one object each): the stage sequences
-# CDownConvert::SetDataRate picks for the reference's radio rates x demodulator bandwidths -- tools/list_dc_plans.py
-# prints this list with the (rate / bandwidth) pairs behind every line.  Any other sequence runs the same kernel
-# with a run-time plan.
-DC_PLANS = [
-    (23,), (27,), (35,), (39,), (51,),
-    (11, 15), (19, 27), (19, 31), (19, 35), (23, 43), (23, 51),
-    (11, 11, 15), (11, 15, 27), (15, 19, 35), (15, 23, 51),
-    (11, 11, 11, 15), (11, 11, 15, 19), (11, 15, 19, 35),
-    (11, 11, 15, 19, 31), (11, 11, 15, 23, 51),
-    (11, 11, 11, 11, 15, 19), (11, 11, 11, 15, 23, 51),
-    (3, 3, 11, 11, 11, 11, 15),
-    # the same bandwidths at other common front-end rates (1.024 / 2.048 / 2.4 / 2.5 / 3.2 / 8 / 10 MS/s; SURVEY's
-    # config C5 is 10 MS/s FM): tools/list_dc_plans.py --more
-    (11, 15, 19, 31), (11, 15, 23, 47),
-    (11, 11, 11, 15, 27), (11, 11, 11, 19, 27), (11, 11, 15, 19, 35), (11, 11, 15, 23, 47),
-    (11, 11, 11, 11, 19, 27), (11, 11, 11, 15, 19, 35), (11, 11, 11, 15, 23, 43), (11, 11, 11, 15, 23, 47),
-    (3, 11, 11, 11, 11, 15, 19), (3, 11, 11, 11, 11, 15, 27), (11, 11, 11, 11, 15, 19, 31),
-    (11, 11, 11, 11, 15, 19, 35), (11, 11, 11, 11, 15, 23, 51),
-    (3, 3, 3, 11, 11, 11, 11, 15), (3, 3, 11, 11, 11, 11, 15, 19), (3, 11, 11, 11, 11, 15, 19, 35),
-    (3, 11, 11, 11, 11, 15, 23, 51),
-    (3, 3, 3, 3, 11, 11, 11, 11, 15),
-]
+# Decimator plans the down-converter is compiled for (downconv_plan.hip, one object each): EVERY stage sequence
+# CDownConvert::SetDataRate (dsp/downconvert.cpp:127-166) can produce.  A stage's kind depends only on rho = rate at
+# that stage / bandwidth (CIC-3 above 1/CIC3_MAXBW, else the first half band whose threshold it reaches,
+# dsp/filtercoef.h:17-28), the rate halves from stage to stage, and the selection stops below the last threshold, at
+# the 15.8 kHz floor or after nine stages: so the sequences are the prefixes of one sequence per interval between
+# consecutive break points threshold * 2^s of the input ratio -- 164 of them.  all_dc_plans() also returns, for
+# every plan, a (rate, bandwidth) pair that selects it (the tests run each one); tools/list_dc_plans.py prints the
+# ones behind the reference's radios.  The kernel with a run-time plan stays as the form they are checked against.
+def _hb_tables():
+    import re
+    h = open(os.path.join(HERE, "..", "include", "csdr_hb_taps.h")).read()
+    maxbw = [eval(x.strip()) for x in re.search(r"csdr_hb_maxbw\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
+    lens = [int(x) for x in re.search(r"csdr_hb_len\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
+    cic3 = eval(re.search(r"#define CSDR_CIC3_MAXBW\s+(\S+)", h).group(1))
+    return maxbw, lens, cic3
+
+
+def dc_plan(rate, bw, tables=None):
+    """the stage kinds SetDataRate picks (dc_host.hpp: dc_make_plan)"""
+    maxbw, lens, cic3 = tables or _hb_tables()
+    f, k = rate, []
+    while bw > 0 and f > bw / maxbw[-1] and f > 7900.0 * 2.0 and len(k) < 9:
+        if f >= bw / cic3:
+            k.append(3)
+        else:
+            k.append(next(lens[i] for i, m in enumerate(maxbw) if f >= bw / m))
+        f /= 2.0
+    return tuple(k)
+
+
+def all_dc_plans():
+    """{plan: (rate, bandwidth) that selects it} for every plan there is"""
+    tables = _hb_tables()
+    maxbw, lens, cic3 = tables
+    thr = [1.0 / cic3] + [1.0 / x for x in maxbw]
+    bps = sorted({t * 2.0 ** s for t in thr for s in range(12)})
+    mids = [(a * b) ** 0.5 for a, b in zip(bps, bps[1:])] + [bps[-1] * 1.01]
+    out = {}
+    for r in mids:
+        full = dc_plan(15800.0 * 2.0 ** 12, 15800.0 * 2.0 ** 12 / r, tables)
+        for n in range(1, len(full) + 1):
+            if full[:n] in out:
+                continue
+            rate = 15800.0 * 2.0 ** n if n < len(full) else 15800.0 * 2.0 ** (n + 2)      # the floor cuts a prefix
+            assert dc_plan(rate, rate / r, tables) == full[:n]
+            out[full[:n]] = (rate, rate / r)
+    return out
+
+
+DC_PLANS = sorted(all_dc_plans(), key=lambda p: (len(p), p))
 JOBS = max(1, min(8, os.cpu_count() or 1))
 
 

@@ -143,21 +143,17 @@ def test_precompiled_plans_reproduce_the_runtime_plan_kernel(oracle):
 
 
 def test_every_precompiled_plan_runs_and_matches_the_runtime_plan_kernel():
-    """All of DC_PLANS, each at a (rate, bandwidth) pair that selects it: the plan-compiled kernel and the run-time-plan
-    kernel give the same words on a three-call stream with a ragged middle call."""
-    import ctypes as C, importlib.util, os
+    """All of DC_PLANS -- every stage sequence SetDataRate can produce -- each at a (rate, bandwidth) pair that selects
+    it: the plan-compiled kernel and the run-time-plan kernel give the same words on a three-call stream with a
+    ragged middle call."""
+    import ctypes as C
     import cutesdr_amd as ca
     from cutesdr_amd import _build
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("list_dc_plans", os.path.join(root, "tools", "list_dc_plans.py"))
-    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-    pairs = {}
-    for tab in (m.table(m.RATES), m.table(m.MORE_RATES)):
-        for p, where in tab.items():
-            pairs.setdefault(p, where[0])
+    pairs = _build.all_dc_plans()
     L = ca.lib()
     L.csdr__downconv_force_dynamic.restype = C.c_int
     L.csdr__downconv_force_dynamic.argtypes = [C.c_int]
+    assert L.csdr__downconv_force_dynamic(-1) == len(pairs) == len(_build.DC_PLANS)
     try:
         for plan in _build.DC_PLANS:
             in_rate, bw = pairs[plan]

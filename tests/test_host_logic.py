@@ -132,20 +132,29 @@ def test_biquad_and_agc_parameters_match_oracle(L, oracle):
     assert p[4] == pytest.approx(1 - np.exp(-1 / (62500 * .002)))
 
 
-def test_precompiled_decimator_plans_are_the_documented_rate_bandwidth_table():
-    """DC_PLANS (cutesdr_amd/_build.py: the stage sequences the down-converter kernel is compiled for) is exactly what
-    tools/list_dc_plans.py derives from the reference's radio rates x demodulator bandwidths plus the listed other
-    front-end rates -- and every entry is a sequence SetDataRate's selection rule can produce (CIC-3s, then 11-tap
-    half bands, then non-decreasing longer ones)."""
+def test_precompiled_decimator_plans_are_every_sequence_the_selection_rule_can_produce():
+    """DC_PLANS (cutesdr_amd/_build.py: the stage sequences the down-converter kernel is compiled for) against a brute
+    force over rates and bandwidths with the same selection rule: nothing the sweep finds is missing, every listed
+    plan comes with a (rate, bandwidth) pair that selects it, and the reference's radio table is inside."""
     import importlib.util, os
     from cutesdr_amd import _build
+    plans = _build.all_dc_plans()
+    assert sorted(plans, key=lambda p: (len(p), p)) == _build.DC_PLANS and len(plans) == 164
+    tables = _build._hb_tables()
+    for p, (rate, bw) in plans.items():
+        assert _build.dc_plan(rate, bw, tables) == p
+        assert 1 <= len(p) <= 9 and all(k in (3, 11, 15, 19, 23, 27, 31, 35, 39, 43, 47, 51) for k in p)
+        assert list(p) == sorted(p)
+    swept = set()
+    for ri in range(0, 700):
+        rate = 16000.0 * 1.0105 ** ri
+        for bi in range(0, 140):
+            bw = 200.0 * 1.09 ** bi
+            if bw > rate / 2: break
+            q = _build.dc_plan(rate, bw, tables)
+            if q: swept.add(q)
+    assert swept <= set(plans) and len(swept) > 100
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("list_dc_plans", os.path.join(root, "tools", "list_dc_plans.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-    ref = m.table(m.RATES)
-    more = m.table(m.MORE_RATES, skip=ref)
-    assert set(_build.DC_PLANS) == set(ref) | set(more)
-    assert len(set(_build.DC_PLANS)) == len(_build.DC_PLANS)
-    for p in _build.DC_PLANS:
-        assert 1 <= len(p) <= 9 and all(k in (3, 11, 15, 19, 23, 27, 31, 35, 39, 43, 47, 51) for k in p)
-        assert list(p) == sorted(p)
+    assert set(m.table(m.RATES)) | set(m.table(m.MORE_RATES)) <= set(plans)
