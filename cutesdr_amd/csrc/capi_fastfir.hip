@@ -253,9 +253,9 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.blocks_per_run = blocks_per_wg;
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
     a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
-    if (b->variant >= 2 && (a.blocks_per_run & 1) == 0 && (a.nblocks % a.blocks_per_run & 1) == 0) {
+    if (b->variant >= 2) {
         a.h = (const v4f_h *)b->d_h2;         // its own H order
-        CSDR_HIP(fastfir2_launch(a, s));     // walks its blocks in pairs
+        CSDR_HIP(fastfir2_launch(a, s));     // any block count (pairs, then a single trailing block)
     }
     else CSDR_HIP(fastfir_launch(b->log2n, a, s));
     b->hist_cur ^= 1;        // the kernel left this call's tail in the other half

@@ -26,6 +26,19 @@ namespace csdr {
 
 #define CSDR_SB() __builtin_amdgcn_sched_barrier(0)
 
+// Round-3 knobs (each A/B'd with tools/ab_many.sh).  The kernel runs at the chip's POWER limit
+// (1.87-1.91 GHz in-kernel against 2.4 nominal, tools/k1_cycles.py): what shortens a launch is less energy per
+// block -- fewer instructions, fewer bytes moved -- not fewer stall cycles.
+#ifndef K1_LDAUX
+#define K1_LDAUX 2          // cache policy of the input loads: nt (every sample is read once)
+#endif
+#ifndef K1_STAUX
+#define K1_STAUX 2          // ... and of the output stores (written once)
+#endif
+#ifndef K1_HREG
+#define K1_HREG 8           // float4 of this thread's share of H that stay in registers for the whole run (0..8 fit)
+#endif
+
 // Diagnostic build only (-DCSDR_K1_STAMPS, tools/k1_stamps.py): cycle shares of the passes of one block,
 // summed per wave in scalar registers and written to a.dbg after the loop.  No stamp executes otherwise.
 #ifdef CSDR_K1_STAMPS
@@ -61,6 +74,12 @@ __device__ __forceinline__ void lds_st8(v2f *p, v2f v)
 // through the interval (3, 2, 1, 0) makes whichever wave is behind the preferred one: the pair stays within
 // one segment of each other and the waits fall to 2k cycles.
 #define CSDR_PRIO(p) __builtin_amdgcn_s_setprio(p)
+
+// Timing ablations (tools/altlib.py NAME -DK1_ABLATE -DABL_...; the results are garbage, never shipped): H from a
+// constant instead of L2, pass twiddles from a constant instead of LDS, no workgroup barriers, no output stores.
+#ifdef K1_ABLATE
+__device__ __forceinline__ void keep_alive(v4f v) { asm volatile("" ::"v"(v)); }
+#endif
 
 template <int LOG2N>
 __global__ __launch_bounds__(FastFirCfg<LOG2N>::T)
@@ -99,7 +118,7 @@ void fastfir_os2_kernel(FastFirArgs a)
     auto load_half = [&](rsrc_t r, int soff, v2f (&dst)[16]) {
 #pragma unroll
         for (int n1 = 0; n1 < HALF; n1++) {
-            v4f v = buf_load16(r, voff, soff + n1 * 8192);
+            v4f v = buf_load16_aux<K1_LDAUX>(r, voff, soff + n1 * 8192);
             dst[n1] = v2f{v.x, v.y};
             dst[HALF + n1] = v2f{v.z, v.w};
         }
@@ -114,6 +133,18 @@ void fastfir_os2_kernel(FastFirArgs a)
 #pragma unroll
     for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);
 
+    // H: float4 j of this thread (fastfir2_bin_of) multiplies in F3's tail group j / 2.  The first K1_HREG of the
+    // sixteen stay in registers for the whole run -- all the registers the kernel has to spare: a 1 KB fetch from
+    // L2 costs about as much energy as four packed instructions -- the rest is fetched from L2 for every block
+    v4f hv[16];
+#pragma unroll
+    for (int j = 0; j < K1_HREG; j++) hv[j] = buf_load16(r_h, t * 16, j * (T * 16));
+#ifdef K1_ABLATE
+    v4f habl = {1.0f, 0.0f, 1.0f, 0.0f};
+    asm volatile("" : "+v"(habl));
+    v2f twabl = {0.8f, 0.6f};
+    asm volatile("" : "+v"(twabl));
+#endif
     v2f x[32];           // phase B: the 32 points of this thread
     // The two halves of a block's input, [n1] = column 2t row n1, [8 + n1] = column 2t+1 row n1.  The new
     // half of one block is the old half of the next: the block loop is unrolled by two and the buffers
@@ -132,6 +163,9 @@ void fastfir_os2_kernel(FastFirArgs a)
     v2f *const outer = lds + lds_pad(G * t);                // F1 / I3: row k0 at outer[lds_pad(1024) * k0]
     constexpr int OUTER_ROW = 1024 + 2 * (1024 / 32);       // padded elements between rows of the outer pass
 
+#ifdef K1_CYC          // diagnostic build (tools/k1_cycles.py): shader cycles and real time of the whole block loop
+    const unsigned long long cyc0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef CSDR_K1_STAMPS
     unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
@@ -186,12 +220,15 @@ void fastfir_os2_kernel(FastFirArgs a)
             });
         }
         CSDR_STAMP(0);                                 // F1 (and the loop-carried moves)
+#ifdef ABL_BAR
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
         __syncthreads();
+#endif
         CSDR_STAMP(1);                                 // barrier after F1
 
         // ================= F2: radix-32 forward inside sub-transform sb, column sn =================
         CSDR_PRIO(3);
-        v4f hv[16];
         {
             // the four points of head group g (network positions 4g..4g+3 <- rows bitrev(4g+q)); three groups
             // ahead of the butterflies (lgkmcnt counts to 15)
@@ -212,19 +249,31 @@ void fastfir_os2_kernel(FastFirArgs a)
             dit_single<8, 32, +1>(x);
             CSDR_SB();
             // tail group i finishes k1 = i, i+8, i+16, i+24: twiddle, store (one group behind).  H[k] comes from
-            // L2, two loads per tail group (a burst of sixteen held the wave for ~500 cycles of issue alone), in
-            // flight from here to the multiply in F3
+            // L2 (what is not resident: K1_HREG), at most two loads per tail group (a burst of sixteen held the wave for
+            // ~500 cycles of issue alone), in flight from here to the multiply in F3
             v2f tw[2][4];
+#ifdef ABL_TW
+            static_for<1, 4>([&](auto P) { tw[0][P.value] = twabl; });
+#else
             static_for<1, 4>([&](auto P) { tw[0][P.value] = lds_ld8(twc + 32 * (8 * P.value)); });
+#endif
             CSDR_SB();
             CSDR_STAMP(8);                             // F2 middle stage
             static_for<0, 9>([&](auto Ii) {
                 constexpr int i = Ii.value;
                 if constexpr (i < 7)                   // twiddles of the next group
+#ifdef ABL_TW
+                    static_for<0, 4>([&](auto P) { tw[(i + 1) & 1][P.value] = twabl; });
+#else
                     static_for<0, 4>([&](auto P) { tw[(i + 1) & 1][P.value] = lds_ld8(twc + 32 * (i + 1 + 8 * P.value)); });
+#endif
                 if constexpr (i < 8) {
-                    hv[2 * i] = buf_load16(r_h, t * 16, (2 * i) * (T * 16));
-                    hv[2 * i + 1] = buf_load16(r_h, t * 16, (2 * i + 1) * (T * 16));
+#ifdef ABL_H
+                    hv[2 * i] = habl; hv[2 * i + 1] = habl;
+#else
+                    if constexpr (2 * i >= K1_HREG) hv[2 * i] = buf_load16(r_h, t * 16, (2 * i) * (T * 16));
+                    if constexpr (2 * i + 1 >= K1_HREG) hv[2 * i + 1] = buf_load16(r_h, t * 16, (2 * i + 1) * (T * 16));
+#endif
                     dit_tail<i, 32, +1>(x);
                     static_for<0, 4>([&](auto P) {
                         constexpr int k1 = i + 8 * P.value;
@@ -269,15 +318,14 @@ void fastfir_os2_kernel(FastFirArgs a)
             CSDR_SB();
             // tail group i finishes the bins k2 = i, i+8, i+16, i+24 -- the four inputs (network positions
             // 4g..4g+3, g = bitrev3(i), position 4g + 2 q1 + q0 <- k2 = i + 8 q1 + 16 q0) of the inverse's head
-            // group g: multiply by H and go straight on
+            // group g: multiply by H (folded into that group's first butterflies) and go straight on
             static_for<0, 8>([&](auto Ii) {
                 constexpr int i = Ii.value, g = bitrev<8>(i);
                 dit_tail<i, 32, +1>(x);
-                y[4 * g] = cmul(x[i], v2f{hv[2 * i].x, hv[2 * i].y});
-                y[4 * g + 1] = cmul(x[i + 16], v2f{hv[2 * i].z, hv[2 * i].w});
-                y[4 * g + 2] = cmul(x[i + 8], v2f{hv[2 * i + 1].x, hv[2 * i + 1].y});
-                y[4 * g + 3] = cmul(x[i + 24], v2f{hv[2 * i + 1].z, hv[2 * i + 1].w});
-                dit_head4<g, 32, -1>(y);
+                // times H: the products of the odd inputs ride in the FMA butterflies of the inverse's first stage
+                y[4 * g] = x[i]; y[4 * g + 1] = x[i + 16]; y[4 * g + 2] = x[i + 8]; y[4 * g + 3] = x[i + 24];
+                dit_head4_tw<g, 32, -1>(y, v2f{hv[2 * i].x, hv[2 * i].y}, v2f{hv[2 * i].z, hv[2 * i].w},
+                                        v2f{hv[2 * i + 1].x, hv[2 * i + 1].y}, v2f{hv[2 * i + 1].z, hv[2 * i + 1].w});
                 if constexpr ((i & 1) == 1) CSDR_SB();
             });
 #pragma unroll
@@ -325,7 +373,11 @@ void fastfir_os2_kernel(FastFirArgs a)
                 });
                 static_for<0, 4>([&](auto Q) {
                     constexpr int r = 4 * Gg.value + Q.value;
+#ifdef ABL_TW
+                    if constexpr (r != 0) tw[r] = twabl;
+#else
                     if constexpr (r != 0) tw[r] = lds_ld8(twc + 32 * bitrev<32>(r));
+#endif
                 });
             };
             static_for<0, 2>(fetch);
@@ -350,7 +402,11 @@ void fastfir_os2_kernel(FastFirArgs a)
             });
         }
         CSDR_STAMP(4);                                 // I2
+#ifdef ABL_BAR
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
         __syncthreads();
+#endif
         CSDR_STAMP(5);                                 // barrier after I2
 
         // ================= I3: conj twiddle, radix-16 DIT inverse, store the valid half =================
@@ -380,15 +436,19 @@ void fastfir_os2_kernel(FastFirArgs a)
             static_for<0, R0 / 4 + 1>([&](auto I) {
                 constexpr int i = I.value;
                 if constexpr (i < R0 / 4) {
-                    dit_tail<i, R0, -1>(y0);
-                    dit_tail<i, R0, -1>(y1);
+                    dit_tail_upper<i, R0, -1>(y0);      // only rows 8..15 of the inverse transform are kept
+                    dit_tail_upper<i, R0, -1>(y1);
                     sv[2 * i] = store_operand(y0[i + 8], y1[i + 8]);
                     sv[2 * i + 1] = store_operand(y0[i + 12], y1[i + 12]);
                 }
                 if constexpr (i > 0) {
                     CSDR_STORE_GROUP_BEGIN();
-                    buf_store16(r_out, voff, b * (L * 8) + (i - 1) * 8192, sv[2 * (i - 1)]);
-                    buf_store16(r_out, voff, b * (L * 8) + (i - 1 + 4) * 8192, sv[2 * (i - 1) + 1]);
+#ifdef ABL_GST
+                    keep_alive(sv[2 * (i - 1)]); keep_alive(sv[2 * (i - 1) + 1]);
+#else
+                    buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1) * 8192, sv[2 * (i - 1)]);
+                    buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1 + 4) * 8192, sv[2 * (i - 1) + 1]);
+#endif
                     CSDR_STORE_GROUP_END();
                 } else {
                     CSDR_SB();
@@ -397,12 +457,25 @@ void fastfir_os2_kernel(FastFirArgs a)
         }
         CSDR_STAMP(6);                                 // I3
     };
-    // the host launches this kernel only with an even number of blocks in every run
-    for (int b = b0; b < b1; b += 2) {
+    // Everything fetched so far (both input halves, the resident part of H) is waited for HERE, once: left to the
+    // compiler the wait sits at the loop header ("vmcnt(7) ... vmcnt(0)" in front of F1's first butterflies), where
+    // on the back edge the eight youngest vector-memory operations are the output stores of the block just finished.
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0); lgkmcnt / expcnt left alone (gfx9 encoding)
+    int b = b0;
+    for (; b + 1 < b1; b += 2) {
         one_block(b, hp, hq);
         one_block(b + 1, hq, hp);
     }
+    const bool odd_tail = b < b1;                // uniform per workgroup: a run with an odd number of blocks
+    if (odd_tail) one_block(b, hp, hq);
 
+#ifdef K1_CYC
+    if (a.dbg && t == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg) + (long)blockIdx.x * 2;
+        o[0] = __builtin_amdgcn_s_memtime() - cyc0_;
+        o[1] = __builtin_amdgcn_s_memrealtime() - rt0_;
+    }
+#endif
 #ifdef CSDR_K1_STAMPS
     if (a.dbg && (t & 63) == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(a.dbg) + ((long)blockIdx.x * (T / 64) + (t >> 6)) * 16;
@@ -415,7 +488,8 @@ void fastfir_os2_kernel(FastFirArgs a)
         const rsrc_t r_hn = make_rsrc(a.hist_next + (long)ch * L, L * 8u);
         v4f sv[8];
 #pragma unroll
-        for (int n1 = 0; n1 < HALF; n1++) sv[n1] = store_operand(hp[n1], hp[HALF + n1]);
+        for (int n1 = 0; n1 < HALF; n1++)      // the last new half: in hp after a pair of blocks, in hq after a single one
+            sv[n1] = odd_tail ? store_operand(hq[n1], hq[HALF + n1]) : store_operand(hp[n1], hp[HALF + n1]);
         CSDR_STORE_GROUP_BEGIN();
 #pragma unroll
         for (int n1 = 0; n1 < HALF; n1++) buf_store16(r_hn, voff, n1 * 8192, sv[n1]);

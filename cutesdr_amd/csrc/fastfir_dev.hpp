@@ -22,6 +22,18 @@ __device__ __forceinline__ void buf_store16(rsrc_t r, int voff, int soff, v4f v)
 {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, 0);
 }
+// streaming forms: the samples are read once and written once (cache-policy bits of the buffer instruction:
+// 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__device__ __forceinline__ v4f buf_load16_aux(rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store16_aux(rsrc_t r, int voff, int soff, v4f v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, AUX);
+}
 
 // Wide stores (buffer_store_dwordx4 with an SGPR soffset, ds_write_b128) read their data VGPRs
 // over several cycles after issue.  hipcc (ROCm 7.2) pads the ">64-bit store data overwritten by

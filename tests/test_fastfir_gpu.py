@@ -158,9 +158,9 @@ def test_generic_kernel_at_16384_in_child_process():
 
 
 def test_pipelined_and_generic_kernels_agree(oracle):
-    """The pipelined build (FMA-form inverse butterflies) and the generic kernel against the oracle and against
-    each other, for even and odd block counts (odd: the generic kernel serves both objects, so those are
-    bit-identical) and across two calls (overlap carried)."""
+    """The pipelined build (FMA-form butterflies) and the generic kernel against the oracle and against each
+    other, for even and odd block counts (the pipelined kernel walks pairs of blocks, then a single trailing one)
+    and across two calls (overlap carried)."""
     import ctypes as C
     import cutesdr_amd as ca
     L = ca.lib()
@@ -177,11 +177,34 @@ def test_pipelined_and_generic_kernels_agree(oracle):
             assert L.csdr__fastfir_set_variant(b.h, v) == 0
             outs.append(np.concatenate([b.process(x), b.process(x[:, ::-1].copy())], axis=1))
         tol = TOL * np.abs(x).max()
-        if nb & 1:
-            assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), nb
         assert np.abs(outs[0] - outs[1]).max() <= tol, nb
         for c in range(Cn):
             ff = oracle.CFastFIR(n); ff.SetupParameters(-5000, 5000, 0, 62500.0)
             ref = np.concatenate([ff.ProcessData(x[c].astype(np.complex128)), ff.ProcessData(x[c, ::-1].astype(np.complex128))])
             for o in outs:
                 assert np.abs(o[c] - ref).max() <= tol, (nb, c)
+
+
+def test_pipelined_kernel_words_do_not_depend_on_chunking_or_run_length():
+    """One kernel serves every launch at N = 16384, so the output WORDS of a stream are the same however it is cut
+    into calls (odd and even hop counts) and into runs of blocks per workgroup (csdr_demod_batch_process relies on it:
+    the number of hops per call varies there)."""
+    import cutesdr_amd as ca
+    n, Cn, L = 16384, 3, 8192
+    rng = np.random.default_rng(11)
+    x = (3000.0 * (rng.standard_normal((Cn, 9 * L)) + 1j * rng.standard_normal((Cn, 9 * L)))).astype(np.complex64)
+
+    def run(cuts, bpw):
+        b = ca.FastFirBatch(Cn, n)
+        b.setup(-4000, 6000, 0, 62500.0)
+        parts, at = [], 0
+        for c in cuts:
+            parts.append(b.process(x[:, at * L:(at + c) * L].copy(), blocks_per_wg=bpw))
+            at += c
+        assert at == 9
+        return np.concatenate(parts, axis=1)
+
+    ref = run([9], 0)
+    for cuts, bpw in (([9], 1), ([9], 2), ([9], 4), ([9], 5), ([1] * 9, 0), ([2, 3, 4], 0), ([5, 4], 3), ([1, 8], 2)):
+        got = run(cuts, bpw)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (cuts, bpw)
