@@ -30,12 +30,21 @@ FILE_FLAGS = {"fastfir2_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp
 # consecutive break points threshold * 2^s of the input ratio -- 164 of them.  all_dc_plans() also returns, for
 # every plan, a (rate, bandwidth) pair that selects it (the tests run each one); tools/list_dc_plans.py prints the
 # ones behind the reference's radios.  The kernel with a run-time plan stays as the form they are checked against.
+def _difference(text):
+    """'(.5-.475)' -> 0.5 - 0.475: the thresholds are written as differences in dsp/filtercoef.h:17-28 and kept so"""
+    import re
+    m = re.fullmatch(r"\(?\s*([0-9.]+)\s*-\s*([0-9.]+)\s*\)?", text.strip())
+    if not m:
+        raise ValueError("unexpected threshold expression in csdr_hb_taps.h: %r" % text)
+    return float(m.group(1)) - float(m.group(2))
+
+
 def _hb_tables():
     import re
     h = open(os.path.join(HERE, "..", "include", "csdr_hb_taps.h")).read()
-    maxbw = [eval(x.strip()) for x in re.search(r"csdr_hb_maxbw\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
+    maxbw = [_difference(x) for x in re.search(r"csdr_hb_maxbw\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
     lens = [int(x) for x in re.search(r"csdr_hb_len\[[^\]]*\]\s*=\s*\{([^}]*)\}", h).group(1).split(",") if x.strip()]
-    cic3 = eval(re.search(r"#define CSDR_CIC3_MAXBW\s+(\S+)", h).group(1))
+    cic3 = _difference(re.search(r"#define CSDR_CIC3_MAXBW\s+(\S+)", h).group(1))
     return maxbw, lens, cic3
 
 
@@ -71,7 +80,32 @@ def all_dc_plans():
     return out
 
 
-DC_PLANS = sorted(all_dc_plans(), key=lambda p: (len(p), p))
+# The front-end rates of the reference's radios (interface/sdrinterface.cpp:75-114: SDR-IQ, NetSDR, SDR-IP), other
+# common front-end rates incl. the BASELINE configurations (2 and 10 MS/s) and the chain's own decimated rates, and
+# the demodulators' maximum bandwidths (gui/mainwindow.cpp:1006-1050: CW 1 kHz, AM/SAM 10 kHz, FM 15 kHz, SSB 20 kHz).
+RADIO_RATES = [66666666.6667 / d for d in (1200.0, 600.0, 420.0, 340.0)] + [80.0e6 / d for d in (1280.0, 320.0, 128.0, 130.0, 40.0)]
+MORE_RATES = [62500.0, 125000.0, 250000.0, 500000.0, 625000.0, 1.0e6, 1.024e6, 2.0e6, 2.048e6, 2.4e6, 2.5e6, 3.2e6, 8e6, 10e6]
+DEMOD_BWS = [1000.0, 10000.0, 15000.0, 20000.0]
+
+
+def default_dc_plans():
+    """the plans those rates x bandwidths select: what the library is compiled for by default"""
+    tables = _hb_tables()
+    out = {}
+    for r in RADIO_RATES + MORE_RATES:
+        for b in DEMOD_BWS:
+            p = dc_plan(r, b, tables)
+            if p:
+                out.setdefault(p, (r, b))
+    return out
+
+
+# Compiled by default: the plans behind the rates above (a few dozen).  CSDR_ALL_DC_PLANS=1 compiles all 164 the
+# selection rule can produce (~2 min on 8 cores, a 7 MB library); any other plan runs in the same kernel with the plan
+# taken at run time (downconv_kernel<DcPlanDyn>: same words, 1.5x the time).
+ALL_PLANS = os.environ.get("CSDR_ALL_DC_PLANS", "0") not in ("", "0")
+DC_PLAN_PAIRS = all_dc_plans() if ALL_PLANS else default_dc_plans()
+DC_PLANS = sorted(DC_PLAN_PAIRS, key=lambda p: (len(p), p))
 JOBS = max(1, min(8, os.cpu_count() or 1))
 
 
@@ -114,8 +148,8 @@ def build(force=False, verbose=False):
     objs = [j[1] for j in jobs]
     todo = []
     for src, obj, extra, deps in jobs:
-        stamp = obj + ".flags"                           # a plan object depends on its -D flags too
-        flags = " ".join(extra)
+        stamp = obj + ".flags"                           # an object depends on every flag of its compile command
+        flags = " ".join(FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + extra)
         if force or _newer(obj, [src] + headers + deps) or not os.path.exists(stamp) or open(stamp).read() != flags:
             todo.append((src, obj, extra, stamp, flags))
     procs = []

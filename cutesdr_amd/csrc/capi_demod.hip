@@ -718,6 +718,7 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     if (npackets == 0) return CSDR_OK;
     if (!device_ok(b->device)) return CSDR_EHIP;
     const long n = (long)npackets * (pkt_len == 1444 ? 240 : 256);
+    if (n > 0x7fffffffL) return fail(CSDR_EINVAL, "%d datagrams are more samples than one call can take", npackets);
     if (!nb)        // the down-converter decodes the datagrams in its own loads: no unpacked copy, no extra pass
         return demod_batch_run(b, nullptr, 0, (int)n, d_out, out_stride, stream, false, d_packets, pkt_len);
     // with the blanker: it decodes the datagrams in ITS loads and leaves blanked fp32 samples for the chain
@@ -728,6 +729,12 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
         CSDR_HIP(hipMalloc((void **)&b->d_blank, (size_t)b->channels * n * 8));
         b->raw_cap = n;
     }
+    // d_blank is the library's own staging buffer, single-buffered: in pipelined mode the down-converters of the
+    // PREVIOUS call (on the batch's own streams) may still be reading it, and the caller's stream -- on which the
+    // blanker of this call runs -- has not joined them yet (demod_batch_run does that, later)
+    if (b->pipelined)
+        for (size_t ki = 0; ki < b->cores.size(); ki++)
+            if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
     int rc = csdr__noiseproc_batch_process_packets(nb, d_packets, npackets, pkt_len, b->d_blank, b->raw_cap, stream);
     if (rc < 0) return rc;
     return demod_batch_run(b, b->d_blank, b->raw_cap, (int)n, d_out, out_stride, stream, false);

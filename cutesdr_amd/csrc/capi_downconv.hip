@@ -131,6 +131,9 @@ double csdr_downconvert_batch_set_data_rate(csdr_downconvert_batch *b, int chann
             const int pi = find_plan(b, in_rate, max_bw);
             b->plan_of[i] = pi;
             c.out_rate = b->plans[pi].out_rate;
+            // dirty from here on: plan_of / plans have changed, and the calls below can fail -- the next process call
+            // must rebuild its per-plan channel lists either way
+            b->state_dirty = true; b->lists_dirty = true;
             if (ensure_hist(b) != CSDR_OK) return -1.0;
             // a rebuilt chain starts from zeroed stage histories (ctor of every stage)
             const size_t half = (size_t)b->channels * b->hist_stride * 2;

@@ -103,6 +103,8 @@ int csdr__noiseproc_batch_process_packets(csdr_noiseproc_batch *b, const void *d
     if (pkt_len != 1028 && pkt_len != 1444) return fail(CSDR_EINVAL, "packet length %d", pkt_len);
     const int per = pkt_len == 1444 ? 240 : 256;
     if ((long)npackets * pkt_len >= (1l << 31)) return fail(CSDR_EINVAL, "a channel's datagrams of one call must stay below 2 GiB");
+    // the kernel fetches the 16-bit samples with 32-bit loads (wire_format.hpp): same rule as the down-converter
+    if ((uintptr_t)d_packets & 3) return fail(CSDR_EINVAL, "datagram buffer must be 4-byte aligned");
     return nb_run(b, nullptr, 0, WireIn{(const unsigned char *)d_packets, (long)npackets * pkt_len, pkt_len, per},
                   npackets * per, d_out, out_stride, stream);
 }

@@ -143,13 +143,13 @@ def test_precompiled_plans_reproduce_the_runtime_plan_kernel(oracle):
 
 
 def test_every_precompiled_plan_runs_and_matches_the_runtime_plan_kernel():
-    """All of DC_PLANS -- every stage sequence SetDataRate can produce -- each at a (rate, bandwidth) pair that selects
-    it: the plan-compiled kernel and the run-time-plan kernel give the same words on a three-call stream with a
-    ragged middle call."""
+    """All of DC_PLANS -- the plans behind the usual front-end rates by default, every stage sequence SetDataRate can
+    produce in a CSDR_ALL_DC_PLANS=1 build -- each at a (rate, bandwidth) pair that selects it: the plan-compiled
+    kernel and the run-time-plan kernel give the same words on a three-call stream with a ragged middle call."""
     import ctypes as C
     import cutesdr_amd as ca
     from cutesdr_amd import _build
-    pairs = _build.all_dc_plans()
+    pairs = _build.DC_PLAN_PAIRS
     L = ca.lib()
     L.csdr__downconv_force_dynamic.restype = C.c_int
     L.csdr__downconv_force_dynamic.argtypes = [C.c_int]

@@ -121,7 +121,9 @@ def test_dropin_host_matches_oracle(oracle, tmp_path):
     want = np.concatenate(want)
     assert int(total) == wtotal == len(audio) and int(rtotal) == wr
     assert float(rate) == d.GetOutputRate()
-    assert np.abs(audio[6144:] - want[6144:]).max() <= 1e-3 * FULL_SCALE
+    # the FM chain rule (test_postchain_gpu.py): 1e-3 of full scale from the fourth burst, 3e-5 from the seventh
+    assert np.abs(audio[3072:6144] - want[3072:6144]).max() <= 1e-3 * FULL_SCALE
+    assert np.abs(audio[6144:] - want[6144:]).max() <= 3e-5 * FULL_SCALE
     assert float(smeter) == pytest.approx(d.GetSMeterAve(), abs=0.02)
     _, wpix = f.GetScreenIntegerFFTData(255, 700, 0.0, -160.0, -900000, 900000)
     assert np.abs(pix - wpix).max() <= 1

@@ -132,14 +132,18 @@ def test_biquad_and_agc_parameters_match_oracle(L, oracle):
     assert p[4] == pytest.approx(1 - np.exp(-1 / (62500 * .002)))
 
 
-def test_precompiled_decimator_plans_are_every_sequence_the_selection_rule_can_produce():
-    """DC_PLANS (cutesdr_amd/_build.py: the stage sequences the down-converter kernel is compiled for) against a brute
-    force over rates and bandwidths with the same selection rule: nothing the sweep finds is missing, every listed
-    plan comes with a (rate, bandwidth) pair that selects it, and the reference's radio table is inside."""
+def test_decimator_plan_enumeration_is_every_sequence_the_selection_rule_can_produce():
+    """all_dc_plans() (cutesdr_amd/_build.py: the stage sequences a CSDR_ALL_DC_PLANS=1 build compiles the
+    down-converter for) against a brute force over rates and bandwidths with the same selection rule: nothing the
+    sweep finds is missing, every listed plan comes with a (rate, bandwidth) pair that selects it, and the default
+    build's table (the reference's radio rates x demodulator bandwidths) is inside."""
     import importlib.util, os
     from cutesdr_amd import _build
     plans = _build.all_dc_plans()
-    assert sorted(plans, key=lambda p: (len(p), p)) == _build.DC_PLANS and len(plans) == 164
+    assert len(plans) == 164 and set(_build.DC_PLANS) <= set(plans)
+    assert set(_build.default_dc_plans()) <= set(plans) and 20 <= len(_build.default_dc_plans()) <= 64
+    for p, (rate, bw) in _build.DC_PLAN_PAIRS.items():
+        assert _build.dc_plan(rate, bw) == p
     tables = _build._hb_tables()
     for p, (rate, bw) in plans.items():
         assert _build.dc_plan(rate, bw, tables) == p

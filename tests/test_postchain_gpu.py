@@ -1,12 +1,43 @@
 """GPU parity of the sample-rate stages (K4: S-meter, AGC, demodulators, CFir, CIir) and of the
 whole CDemodulator chain against the fp64 oracle, through the C ABI.
-Tolerances: audio <= 1e-3 * full scale, identical squelch decisions, sample counts
-exact; the leaf filters are compared much tighter (they are linear)."""
+Tolerances, the same rule in every test of this file, applied burst by burst (a burst = one
+FastFIR hop of audio):
+  * a stage on the oracle's own input (the leaf objects): 2e-5 of full scale from the first sample, PLLs from the
+    burst after they have locked (measured 1e-6 .. 6e-6);
+  * the whole chain, AM / SAM / SSB / CW: 5e-4 of full scale from sample 0, 2e-5 from the third burst;
+  * the whole chain, FM: 1e-3 from the fourth burst, 3e-5 from the seventh (its first bursts demodulate the phase of
+    the filter's start-up, where fp32 rounding is the signal: test_chain_parity_gpu.py);
+identical squelch decisions, exact sample counts; the leaf filters are compared much tighter (they are linear)."""
 import numpy as np
 import pytest
 from util_signals import tones_plus_noise, fm_carrier, am_carrier, FULL_SCALE
 
 pytestmark = pytest.mark.gpu
+
+STEADY = 2e-5 * FULL_SCALE
+FROM_ZERO = 5e-4 * FULL_SCALE
+FM_LOCKED = 1e-3 * FULL_SCALE          # FM chain, bursts 4..6
+FM_STEADY = 3e-5 * FULL_SCALE          # FM chain, from burst 7
+
+
+def burst_errors(got, want, hop=1024):
+    """max |got - want| of every burst of `hop` audio samples"""
+    assert len(got) == len(want)
+    return np.array([np.abs(got[j:j + hop] - want[j:j + hop]).max() for j in range(0, len(want), hop)])
+
+
+def check_chain_bursts(errs, mode, first_burst=0, what="", fm_late=0):
+    """the chain rule of the module docstring; errs[i] belongs to burst first_burst + i of the stream.  fm_late: bursts
+    by which the FM bounds start later (the start-up difference decays by ~5 per burst from whatever the first burst
+    left: a stream whose first burst differs by all of full scale instead of the usual 7 % needs one burst more)"""
+    errs = np.asarray(errs, dtype=float)
+    idx = first_burst + np.arange(len(errs))
+    if mode == "FM":
+        assert (errs[idx >= 3 + fm_late] <= FM_LOCKED).all(), (what, mode, errs[:10] / FULL_SCALE)
+        assert (errs[idx >= 6 + fm_late] <= FM_STEADY).all(), (what, mode, errs[:12] / FULL_SCALE)
+    else:
+        assert (errs <= FROM_ZERO).all(), (what, mode, errs[:6] / FULL_SCALE)
+        assert (errs[idx >= 2] <= STEADY).all(), (what, mode, errs[:8] / FULL_SCALE)
 
 
 def info(oracle_or_ca, **kw):
@@ -82,12 +113,12 @@ def test_agc_complex_and_real(oracle, hang, slope, thresh, decay):
     r.SetParameters(True, bool(hang), thresh, 30, slope, decay, fs)
     for part in (slice(0, 8192), slice(8192, 62500)):
         got, want = a.ProcessData(x[part]), r.ProcessData(x[part])
-        assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE
+        assert np.abs(got - want).max() <= STEADY, np.abs(got - want).max() / FULL_SCALE
     a2, r2 = ca.CAgc(), oracle.CAgc()
     a2.SetParameters(True, bool(hang), thresh, 30, slope, decay, fs)
     r2.SetParameters(True, bool(hang), thresh, 30, slope, decay, fs)
     got, want = a2.ProcessData(x.real.copy()), r2.ProcessData(x.real.copy())
-    assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE
+    assert np.abs(got - want).max() <= STEADY, np.abs(got - want).max() / FULL_SCALE
     a2.SetParameters(False, bool(hang), thresh, 45, slope, decay, fs)       # manual gain
     r2.SetParameters(False, bool(hang), thresh, 45, slope, decay, fs)
     np.testing.assert_allclose(a2.ProcessData(x[:1000]), r2.ProcessData(x[:1000]), rtol=1e-6, atol=1e-3)
@@ -117,12 +148,12 @@ def test_am_sam_fm_demod_leaves(oracle):
         d.SetBandwidth(4000.0); r.SetBandwidth(4000.0)
         for i in range(8):
             got, want = d.ProcessData(x[i * L:(i + 1) * L], stereo), r.ProcessData(x[i * L:(i + 1) * L], stereo)
-            assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE
+            assert np.abs(got - want).max() <= STEADY, ("am", i, np.abs(got - want).max() / FULL_SCALE)
         d, r = ca.CSamDemod(fs), oracle.CSamDemod(fs)
         for i in range(8):
             got, want = d.ProcessData(x[i * L:(i + 1) * L], stereo), r.ProcessData(x[i * L:(i + 1) * L], stereo)
-            if i >= 4:                                      # after PLL lock
-                assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE
+            # acquisition included: the walk of an unlocked tile follows the oracle sample by sample
+            assert np.abs(got - want).max() <= STEADY, ("sam", i, np.abs(got - want).max() / FULL_SCALE)
     fs = 62500.0
     x = fm_carrier(16 * L, fs, 300.0, fmod=1000.0, dev=3000.0, dbfs=-6.0, noise_dbfs=-60.0)
     for stereo in (False, True):
@@ -131,8 +162,7 @@ def test_am_sam_fm_demod_leaves(oracle):
         for i in range(16):
             got, want = d.ProcessData(x[i * L:(i + 1) * L], 5000.0, stereo), r.ProcessData(x[i * L:(i + 1) * L], 5000.0, stereo)
             assert d.squelched() == r.squelched(), i
-            if i >= 2:
-                assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, i
+            assert np.abs(got - want).max() <= STEADY, ("fm", i, np.abs(got - want).max() / FULL_SCALE)
         assert not d.squelched()                            # a clean carrier opens the squelch
     np.testing.assert_array_equal(ca.ssb_demod(x[:100]), oracle.ssb_demod(x[:100]))
     np.testing.assert_array_equal(ca.ssb_demod(x[:100], True), oracle.ssb_demod(x[:100], True))
@@ -161,33 +191,58 @@ def test_cdemodulator_chain_reference_call_pattern(oracle, mode):
         obj.SetDemodFreq(-100e3)
     assert d.GetOutputRate() == r.GetOutputRate()
     assert d.buf_limit() == r.buf_limit()
-    n = 19968 * 24
+    n = 19968 * (64 if mode == "CWU" else 24)              # CW decimates by 128: seven bursts take longer
     x = make_input(mode, n, fs)
     total_g = total_r = 0
-    tail_err = 0.0
+    errs = []
     for i in range(0, n, 256 * 13):                        # uneven relation to the 19968 window
         kg, og = d.ProcessData(x[i:i + 256 * 13])
         kr, orr = r.ProcessData(x[i:i + 256 * 13])
         assert kg == kr
         total_g += kg; total_r += kr
-        if kr and total_r > 6 * 1024:                       # settled: AGC attack + PLL lock
-            tail_err = max(tail_err, np.abs(og[:min(kr, 1024)] - orr[:min(kr, 1024)]).max())
-    assert total_g == total_r > 0
-    assert tail_err <= 1e-3 * FULL_SCALE
+        if kr:                                              # every burst the host gets to see, from the first one
+            assert kr % 1024 == 0
+            errs.append(np.abs(og[:1024] - orr[:1024]).max())
+            if mode == "FM":
+                assert (not og[:1024].any()) == (not orr[:1024].any())       # same squelch decision
+    assert total_g == total_r > 0 and len(errs) >= 7
+    check_chain_bursts(errs, mode, what="256-sample host calls")
     assert d.GetSMeterAve() == pytest.approx(r.GetSMeterAve(), abs=0.02)
 
 
-def test_chain_16384_filter_and_append_form(oracle):
+@pytest.mark.parametrize("stereo", [False, True], ids=["mono", "stereo"])
+def test_config_c2_16384_filter_every_burst(oracle, stereo):
+    """BASELINE config C2: one receiver, 2 MSPS -> CDownConvert -> 16384-pt CFastFIR -> AGC -> FM, both overloads of
+    ProcessData, fed window by window (m_InBufLimit samples per call); every 8192-sample burst from the first one
+    under the chain rule, identical squelch decisions; then the append form of the batch API on the same stream."""
     import cutesdr_amd as ca
     fs = 2e6
     d, r = ca.CDemodulator(16384), oracle.CDemodulator(16384)
     for obj, mod in ((d, ca), (r, oracle)):
         obj.SetInputSampleRate(fs); obj.SetDemod(2, info(mod)); obj.SetDemodFreq(-100e3)
-    n = 19968 * 60
+    lim = d.buf_limit()
+    assert lim == r.buf_limit()
+    n = lim * 132                                           # 82368 decimated samples: ten bursts of 8192
     x = make_input("FM", n, fs)
-    got, want = d.process_append(x), r.process_append(x)
-    assert len(got) == len(want) == (n // 32 // 8192) * 8192
-    assert np.abs(got[8192:] - want[8192:]).max() <= 1e-3 * FULL_SCALE
+    errs = []
+    for i in range(0, n, lim):
+        kg, og = d.ProcessData(x[i:i + lim], stereo)
+        kr, orr = r.ProcessData(x[i:i + lim], stereo)
+        assert kg == kr and kr in (0, 8192)
+        if kr:
+            errs.append(np.abs(og[:kr] - orr[:kr]).max())
+            assert (not og[:kr].any()) == (not orr[:kr].any())
+            assert np.abs(orr[:kr]).max() > 100.0 or len(errs) == 1
+    assert len(errs) == 10
+    check_chain_bursts(errs, "FM", what="C2")
+    assert d.GetSMeterAve() == pytest.approx(r.GetSMeterAve(), abs=0.02)
+    if not stereo:
+        d2, r2 = ca.CDemodulator(16384), oracle.CDemodulator(16384)
+        for obj, mod in ((d2, ca), (r2, oracle)):
+            obj.SetInputSampleRate(fs); obj.SetDemod(2, info(mod)); obj.SetDemodFreq(-100e3)
+        got, want = d2.process_append(x), r2.process_append(x)
+        assert len(got) == len(want) == 10 * 8192
+        check_chain_bursts(burst_errors(got, want, 8192), "FM", what="C2 append form")
 
 
 def test_demod_batch_mixed_modes(oracle):
@@ -209,14 +264,14 @@ def test_demod_batch_mixed_modes(oracle):
         assert b.output_rate(c) == refs[c].GetOutputRate()
     n = 19968 * 16
     x = np.stack([make_input(names[c], 2 * n, fs) * np.exp(2j * np.pi * 1000.0 * c * np.arange(2 * n) / fs) for c in range(C)])
+    first = [0] * C
     for part in (x[:, :n], x[:, n:]):
         got = b.process(part)
         for c in range(C):
             want = refs[c].process_append(part[c])
-            assert len(got[c]) == len(want), (c, names[c])
-            if part is not x[:, :n] or True:
-                k = min(len(want), 4096)
-                assert np.abs(got[c][-k:] - want[-k:]).max() <= 1e-3 * FULL_SCALE, (c, names[c])
+            assert len(got[c]) == len(want) and len(want) % 1024 == 0, (c, names[c])
+            check_chain_bursts(burst_errors(got[c], want), "FM" if names[c] == "FM" else "other", first[c], (c, names[c]))
+            first[c] += len(want) // 1024
     for c in range(C):
         assert b.smeter_ave(c) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02)
 
@@ -225,8 +280,8 @@ def test_demod_batch_mixed_modes(oracle):
 def test_batch_long_calls_fused_and_pipelined(oracle, pipeline, monkeypatch):
     """Long calls (>= 16 FastFIR hops) through the fused launch and through the optional stage
     pipeline (S-meter | AGC | demodulator as concurrent launches over burst groups, capi_demod.hip
-    ChainCore::post, CSDR_CHAIN_PIPELINE=1): same results as the oracle, whole second call compared
-    (the first one holds the lock-in transient).  The switch is read once per process, so the
+    ChainCore::post, CSDR_CHAIN_PIPELINE=1): same results as the oracle, every burst of both calls under
+    the chain rule.  The switch is read once per process, so the
     pipelined case runs in a child interpreter."""
     if pipeline == "1":
         import subprocess, sys, os
@@ -259,8 +314,8 @@ def test_batch_long_calls_fused_and_pipelined(oracle, pipeline, monkeypatch):
         for c in range(C):
             want = refs[c].process_append(part[c])
             assert len(got[c]) == len(want) >= 16 * 1024, (c, names[c])
-            if call == 1:
-                assert np.abs(got[c] - want).max() <= 1e-3 * FULL_SCALE, (c, names[c])
+            check_chain_bursts(burst_errors(got[c], want), "FM" if names[c] == "FM" else "other",
+                               call * (len(want) // 1024), (c, names[c], call))
     for c in range(C):
         assert b.smeter_ave(c) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02)
 
@@ -268,7 +323,8 @@ def test_batch_long_calls_fused_and_pipelined(oracle, pipeline, monkeypatch):
 def test_config_c5_10msps_fm_to_resampler(oracle):
     """BASELINE config 5: one channel at 10 MSPS -> CDownConvert -> CFastFIR -> CFmDemod ->
     CFractResampler to 48 kHz.  Decimated rate 78125 (chain 3,11,11,11,11,15,27), resampler rate
-    78125/48000; audio within 1e-3 of full scale after lock, sample counts exact at every step."""
+    78125/48000; every burst of the audio and of the resampled stream under the chain rule, sample counts exact at
+    every step."""
     import cutesdr_amd as ca
     fs = 10e6
     d, r = ca.CDemodulator(2048), oracle.CDemodulator(2048)
@@ -279,20 +335,22 @@ def test_config_c5_10msps_fm_to_resampler(oracle):
     rg, rr = ca.CFractResampler(), oracle.CFractResampler()
     rg.Init(8192); rr.Init(8192)
     rate = 78125.0 / 48000.0
-    n = d.buf_limit() * 24
+    n = d.buf_limit() * 24                                    # 18 bursts of 1024 at 78 125 S/s
     x = fm_carrier(n, fs, 1.2e6, fmod=1000.0, dev=3000.0, dbfs=-20.0)
-    outs_g, outs_r = [], []
+    outs_g, outs_r, audio_errs = [], [], []
     for k in range(0, n, d.buf_limit() * 4):
         a_g, a_r = d.process_append(x[k:k + d.buf_limit() * 4]), r.process_append(x[k:k + r.buf_limit() * 4])
         assert len(a_g) == len(a_r)
         for j in range(0, len(a_g), 1024):                    # the sound sink feeds the resampler hop by hop
+            audio_errs.append(np.abs(a_g[j:j + 1024] - a_r[j:j + 1024]).max())
             outs_g.append(rg.Resample(a_g[j:j + 1024], rate)); outs_r.append(rr.Resample(a_r[j:j + 1024], rate))
             assert len(outs_g[-1]) == len(outs_r[-1])
-    got, want = np.concatenate(outs_g), np.concatenate(outs_r)
-    assert len(got) == len(want) > 4000
-    skip = len(got) // 3                                      # PLL / AGC lock-in
-    assert np.abs(got[skip:] - want[skip:]).max() <= 1e-3 * FULL_SCALE
-    assert np.abs(want[skip:]).max() > 100.0                  # there is audio to compare
+    assert len(outs_r) >= 14 and sum(len(o) for o in outs_r) > 8000
+    check_chain_bursts(audio_errs, "FM", what="C5 audio")
+    # the resampled stream, burst by burst (one resampler call each), under the same rule: a 28-tap interpolator with
+    # unit gain neither amplifies the difference nor moves it by more than its 14-sample delay
+    check_chain_bursts([np.abs(g - w).max() for g, w in zip(outs_g, outs_r)], "FM", what="C5 resampled")
+    assert np.abs(np.concatenate(outs_r[6:])).max() > 100.0   # there is audio to compare
 
 
 def test_pll_unlockable_carrier_and_relock(oracle):
@@ -314,7 +372,7 @@ def test_pll_unlockable_carrier_and_relock(oracle):
             got, want = d.ProcessData(x[i * L:(i + 1) * L], 5000.0, stereo), r.ProcessData(x[i * L:(i + 1) * L], 5000.0, stereo)
             assert d.squelched() == r.squelched(), i
             if i % 12 >= 2:                                 # two hops after each frequency jump
-                assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, (stereo, i)
+                assert np.abs(got - want).max() <= STEADY, (stereo, i, np.abs(got - want).max() / FULL_SCALE)
     fs = 31250.0
     t = np.arange(3 * n) / fs
     for stereo in (False, True):
@@ -323,7 +381,7 @@ def test_pll_unlockable_carrier_and_relock(oracle):
         for i in range(3 * n // L):
             got, want = d.ProcessData(x[i * L:(i + 1) * L], stereo), r.ProcessData(x[i * L:(i + 1) * L], stereo)
             if i % 12 >= 4:
-                assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, (stereo, i)
+                assert np.abs(got - want).max() <= STEADY, (stereo, i, np.abs(got - want).max() / FULL_SCALE)
 
 
 def test_leaf_objects_ragged_call_lengths(oracle):
@@ -343,11 +401,10 @@ def test_leaf_objects_ragged_call_lengths(oracle):
         part = x[cuts[k]:cuts[k + 1]]
         got, want = g.ProcessData(part), r.ProcessData(part)
         assert len(got) == len(want) == len(part)
-        assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, ("agc", k)
-        assert np.abs(ga.ProcessData(part) - ra.ProcessData(part)).max() <= 1e-3 * FULL_SCALE, ("am", k)
+        assert np.abs(got - want).max() <= STEADY, ("agc", k, np.abs(got - want).max() / FULL_SCALE)
+        assert np.abs(ga.ProcessData(part) - ra.ProcessData(part)).max() <= STEADY, ("am", k)
         sg, sr = gs.ProcessData(part), rs.ProcessData(part)
-        if cuts[k] >= 4000:
-            assert np.abs(sg - sr).max() <= 1e-3 * FULL_SCALE, ("sam", k)
+        assert np.abs(sg - sr).max() <= STEADY, ("sam", k, np.abs(sg - sr).max() / FULL_SCALE)
         gm.ProcessData(part, fs); rm.ProcessData(part, fs)
         assert gm.GetAve() == pytest.approx(rm.GetAve(), abs=0.02), ("smeter", k)
     fs = 62500.0
@@ -358,8 +415,7 @@ def test_leaf_objects_ragged_call_lengths(oracle):
         part = x[cuts[k]:cuts[k + 1]]
         got, want = gf.ProcessData(part, 5000.0), rf.ProcessData(part, 5000.0)
         assert gf.squelched() == rf.squelched(), k
-        if cuts[k] >= 3000:
-            assert np.abs(got - want).max() <= 1e-3 * FULL_SCALE, ("fm", k)
+        assert np.abs(got - want).max() <= STEADY, ("fm", k, np.abs(got - want).max() / FULL_SCALE)
 
 
 def test_batch_above_1024_channels_takes_the_one_wave_kernel(oracle):
@@ -384,6 +440,5 @@ def test_batch_above_1024_channels_takes_the_one_wave_kernel(oracle):
         want = r.process_append(x1[call * n:(call + 1) * n].astype(np.complex128))
         for c in (0, 517, C - 1):
             assert len(got[c]) == len(want)
-            if call == 1:                                     # the last 2048 samples: AGC and PLL have settled
-                assert np.abs(got[c][-2048:] - want[-2048:]).max() <= 1e-3 * FULL_SCALE, c
+            check_chain_bursts(burst_errors(got[c], want), "FM", call * (len(want) // 1024), (c, call))
     assert b.smeter_ave(C - 1) == pytest.approx(r.GetSMeterAve(), abs=0.02)

@@ -2,16 +2,14 @@
 """The decimator plans (stage sequences of CDownConvert::SetDataRate, dsp/downconvert.cpp:127-166) behind the
 reference's radios: its sample-rate tables (interface/sdrinterface.cpp:75-114: SDR-IQ, NetSDR, SDR-IP) x the
 demodulators' maximum bandwidths (gui/mainwindow.cpp:1006-1050: AM/SAM 10 kHz, FM 15 kHz, SSB 20 kHz, CW 1 kHz),
-and with --more the same bandwidths at other common front-end rates.  The down-converter is compiled for EVERY
-sequence the selection rule can produce (cutesdr_amd/_build.py: all_dc_plans, 164 of them); this tool only shows
-which of them the usual rates use.  --all lists the whole set with a (rate, bandwidth) pair that selects each."""
+and with --more the same bandwidths at other common front-end rates.  The down-converter is compiled for these by default
+(cutesdr_amd/_build.py: default_dc_plans) and for EVERY sequence the selection rule can produce (all_dc_plans, 164
+of them) with CSDR_ALL_DC_PLANS=1; any other plan runs with the plan taken at run time.  --all lists the whole set with a (rate, bandwidth) pair that selects each."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cutesdr_amd import _build
 
-RATES = [66666666.6667 / d for d in (1200.0, 600.0, 420.0, 340.0)] + [80.0e6 / d for d in (1280.0, 320.0, 128.0, 130.0, 40.0)]
-MORE_RATES = [1.024e6, 2.048e6, 2.4e6, 2.5e6, 3.2e6, 8e6, 10e6]
-BWS = [1000.0, 10000.0, 15000.0, 20000.0]
+RATES, MORE_RATES, BWS = _build.RADIO_RATES, _build.MORE_RATES, _build.DEMOD_BWS
 plan = _build.dc_plan
 
 def table(rates, skip=()):
