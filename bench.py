@@ -4,9 +4,12 @@
 Workload c3 (default, the config BASELINE.json's metric is quoted on): 256 batched channels x 2^19 complex
 samples through the 16384-pt CFastFIR overlap-save on one MI355X, inputs and outputs resident in HBM.  One
 "step" = one pass of all channels through the filter.  The same run also reports, as secondary objects of the
-one JSON line: the distinct-filter variant of C3 (every channel its own H: +16 B/sample of filter traffic),
-the per-GPU share of config C4 (256 mixed AM/FM/USB receivers x 2^21 raw samples through the whole
-CDemodulator chain) and a post-timing parity spot check of the buffer that was just timed against the oracle.
+one JSON line: the distinct-filter variant of C3 (every channel its own H: +16 B/sample of filter traffic), a
+post-timing parity spot check of the buffer that was just timed against the oracle, and the other BASELINE
+configurations, each with the oracle's fp64 CPU path timed beside it on one host core (rank 0, N = 1, a bounded
+sample): `chain_c4` (the per-GPU share of C4: 256 mixed AM/FM/USB receivers x 2^21 raw samples through the whole
+CDemodulator chain, pipelined AND strict mode), `spectrum_c1` (4096-pt CFft display spectrum), `chain_c2` (one
+receiver through the 16384-pt filter and the FM chain) and `chain_c5` (one 10 MSPS receiver to 48 kHz audio).
 Workload c4 makes the chain the primary metric instead.
 
 Multi-GPU: channels are independent, so every rank owns its own channels (contiguous channel ranges, weak
@@ -59,11 +62,32 @@ def dist_init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             import torch
+            ndev = torch.cuda.device_count()
+            if ctx.local >= ndev:                     # fail before RCCL does, with a message that says why
+                raise SystemExit("bench.py: rank %d wants cuda:%d but this node shows %d device(s) -- run with "
+                                 "--gpus <= %d" % (ctx.rank, ctx.local, ndev, ndev))
             ctx.backend = "nccl"                      # = RCCL on ROCm
             dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.local))
         else:
             dist.init_process_group(backend)
     return ctx
+
+
+def rank_census(ctx):
+    """What the process group actually is, for the JSON line: backend, world size as the group reports it, and every
+    rank's device (index, name, PCI bus id, UUID where the runtime has one) gathered to rank 0 -- the driver can check
+    that RCCL saw N ranks on N different devices."""
+    import torch
+    me = {"rank": ctx.rank, "local_rank": ctx.local}
+    if torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(ctx.local)
+        me.update(device=ctx.local, name=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None),
+                  uuid=str(getattr(pr, "uuid", "")) or None)
+    if ctx.world == 1:
+        return {"backend": None, "world_size": 1, "ranks": [me]}
+    everyone = [None] * ctx.world
+    ctx.dist.all_gather_object(everyone, me)
+    return {"backend": ctx.dist.get_backend(), "world_size": ctx.dist.get_world_size(), "ranks": everyone}
 
 
 def shard_channels(ctx, total_channels):
@@ -104,12 +128,21 @@ def spawn_ranks(n, argv):
     """Start n rank processes of this script (one GPU each), relay rank 0's output, return the worst exit code.
     Runs before anything in this process has imported torch or touched HIP: the children are fresh
     interpreters, nothing is re-executed in place."""
+    if "--stub" not in argv and not os.environ.get("CSDR_BENCH_ONE_GPU"):
+        import torch                                  # counting devices does not initialise the GPU (no HIP call yet)
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            print("bench.py: --gpus %d but this node shows %d device(s); nothing started" % (n, ndev), file=sys.stderr)
+            return 2
     port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL between processes needs dmabuf IPC on this driver (HSA_ENABLE_IPC_MODE_LEGACY=0); the image exports it
+        # and the children inherit the environment as it is -- forcing it is opt-in
+        if os.environ.get("CSDR_BENCH_SET_IPC_MODE"):
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the one JSON line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
     rc = 0
@@ -254,6 +287,145 @@ def cpu_baseline(budget_s=18.0):
     }
 
 
+def cpu_rate(run_once, samples_per_call, budget_s):
+    """run_once() on this thread until budget_s has elapsed (at least once): (MSamples/s, samples processed)"""
+    n, t0 = 0, time.perf_counter()
+    while True:
+        run_once()
+        n += samples_per_call
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            return n / dt / 1e6, n
+
+
+def cpu_obj(value, samples, what):
+    return {"value": round(value, 3), "unit": "MSamples/s", "cores": 1, "kind": "port",
+            "sample": "%s: %d samples on one host core (fp64 oracle)" % (what, samples)}
+
+
+def gpu_ms(torch, fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def fm_defaults(mod):
+    return mod.DemodInfo(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                         FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
+                         AgcManualGain=30, AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+
+
+def fm_stream(torch, dev, n, fs, fc):
+    """a -20 dBFS carrier at fc, FM +-3 kHz / 1 kHz, AWGN -70 dBFS per component: [1, n, 2] fp32 on the device"""
+    t = torch.arange(n, device=dev, dtype=torch.float64) / fs
+    ph = 2 * torch.pi * fc * t + 3.0 * torch.sin(2 * torch.pi * 1000.0 * t)
+    x = torch.stack([(3276.7 * torch.cos(ph)).float(), (3276.7 * torch.sin(ph)).float()], dim=-1).reshape(1, n, 2).contiguous()
+    x += torch.randn_like(x) * (32767.0 * 10 ** (-70 / 20))
+    return x
+
+
+def to_c128(x_dev_row):
+    import numpy as np
+    a = x_dev_row.cpu().numpy().astype(np.float64)
+    return a[:, 0] + 1j * a[:, 1]
+
+
+def spectrum_c1(torch, ca, ctx, x, with_cpu):
+    """BASELINE config C1's transform (dsp/fft.cpp:267-288: 4096 points, Hann, ave 1) on every channel of the
+    resident buffer x [C, T, 2]: 512 frames per channel and launch.  SURVEY 8(d) prices a bin at 8 B in + 4 B out;
+    the kernel keeps the running sums in registers and writes only the LAST frame's bels, so both fractions are
+    given: at 12 B/bin and on the bytes it actually moves."""
+    C, T, N, frames = x.shape[0], x.shape[1], 4096, 512
+    fb = ca.FftBatch(C, device=ctx.local)
+    fb.set_params(N, False, 0.0, C4_FS)
+    fb.set_ave(1)
+    st = torch.cuda.current_stream().cuda_stream
+    ms = gpu_ms(torch, lambda: fb.put_display_ptr(x.data_ptr(), T, frames, st), 10, 20)
+    bins = C * frames * N
+    moved = bins * 8.0 + C * N * 4.0
+    out = {"config": "C1: 4096-pt CFft display spectrum (Hann, ave 1) @2 MSPS, %d channels x %d frames per launch" % (C, frames),
+           "kernel": "csdr::spectrum_kernel<12> (+ its frame-group combine)", "ms_per_launch": round(ms, 4),
+           "MSamples_per_s": round(bins / ms / 1e3, 1),
+           "algorithmic_GBps_at_12B_per_bin": round(bins * 12.0 / ms / 1e6, 1),
+           "frac_at_12B_per_bin": round(bins * 12.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
+           "bytes_moved_per_launch": moved, "GBps_on_bytes_moved": round(moved / ms / 1e6, 1),
+           "frac_on_bytes_moved": round(moved / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
+    if with_cpu:
+        from oracle import oracle as orc
+        f = orc.CFft()
+        f.SetFFTParams(N, False, 0.0, C4_FS)
+        f.SetFFTAve(1)
+        xs = to_c128(x[0, :64 * N])
+        def once():
+            for i in range(0, len(xs), N):
+                f.PutInDisplayFFT(xs[i:i + N])
+        v, n = cpu_rate(once, len(xs), 2.0)
+        out["cpu_baseline"] = cpu_obj(v, n, "CFft::PutInDisplayFFT, 4096-pt frames of channel 0 (BASELINE configs[0])")
+    del fb
+    return out
+
+
+def chain_one_receiver(torch, ca, ctx, with_cpu, name):
+    """BASELINE configs C2 (2 MSPS -> CDownConvert -> 16384-pt CFastFIR -> AGC -> FM) and C5 (10 MSPS -> ... 2048-pt
+    filter -> FM -> CFractResampler to 48 kHz): ONE receiver resident in HBM.  A single receiver cannot fill the
+    chip: these are latency-bound rates, reported as such (no roofline fraction is claimed for them)."""
+    dev = torch.device("cuda", ctx.local)
+    if name == "c2":
+        fs, fc, nfft, T = 2e6, 100e3, 16384, 1 << 23
+        label = "C2: 1 receiver, 2 MSPS -> CDownConvert -> 16384-pt CFastFIR -> AGC -> FM, 2^23 raw samples per call"
+    else:
+        fs, fc, nfft, T = 10e6, 1.2e6, 2048, 1 << 24
+        label = ("C5: 1 receiver, 10 MSPS -> CDownConvert (78 125 S/s) -> 2048-pt CFastFIR -> AGC -> FM -> "
+                 "CFractResampler to 48 kHz, 2^24 raw samples per call")
+    x = fm_stream(torch, dev, T, fs, fc)
+    b = ca.DemodBatch(1, nfft, device=ctx.local)
+    b.set_input_rate(fs); b.set_demod(0, ca.DEMOD_FM, fm_defaults(ca)); b.commit(); b.set_freq(0, -fc)
+    out_rate = b.output_rate(0)
+    dec = int(round(fs / out_rate))
+    cap = T // dec + nfft + 4096
+    aud = torch.zeros((1, cap), device=dev, dtype=torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    rs = ca.ResamplerBatch(1, device=ctx.local) if name == "c5" else None
+    rate = out_rate / 48000.0
+    pcm = torch.zeros((1, int(cap / rate) + 64), device=dev, dtype=torch.float32) if rs else None
+    n_aud = (T // dec // 1024) * 1024                            # whole hops: what every call delivers in steady state
+
+    def step():
+        b.process_ptr(x.data_ptr(), T, T, aud.data_ptr(), cap, st)
+        if rs:
+            rs.resample_ptr(aud.data_ptr(), cap, n_aud, rate, pcm.data_ptr(), pcm.shape[1], None, st)
+    ms = gpu_ms(torch, step, 4, 8)
+    out = {"config": label, "ms_per_call": round(ms, 3), "raw_input_MSamples_per_s": round(T / ms / 1e3, 1),
+           "x_real_time": round(T / ms / 1e3 / (fs / 1e6), 1), "output_rate": out_rate,
+           "bound": "latency of one receiver's sequential stages (one workgroup walks its bursts)", "cpu_baseline": None}
+    if with_cpu:
+        from oracle import oracle as orc
+        r = orc.CDemodulator(nfft)
+        r.SetInputSampleRate(fs); r.SetDemod(orc.DEMOD_FM, fm_defaults(orc)); r.SetDemodFreq(-fc)
+        lim = r.buf_limit()
+        xs = to_c128(x[0, :lim * 40])
+        q = orc.CFractResampler() if name == "c5" else None
+        if q:
+            q.Init(8192)
+        def once():
+            a = r.process_append(xs)
+            if q:
+                for j in range(0, len(a), 1024):
+                    q.Resample(a[j:j + 1024], rate)
+        v, n = cpu_rate(once, len(xs), 2.5)
+        out["cpu_baseline"] = cpu_obj(v, n, "CDemodulator::ProcessData%s on the same stream, m_InBufLimit windows"
+                                      % (" + CFractResampler::Resample" if q else ""))
+    del b, rs, x, aud
+    return out
+
+
 # ---------------------------------------------------------------- timing helpers
 def timed_steps(torch, ctx, step, steps, warmup, prewarm=True):
     """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides; returns
@@ -396,8 +568,10 @@ class C4Workload:
         b.commit()
         for c in range(C):
             b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)))
+        self.mode = "strict"
         if not os.environ.get("CSDR_BENCH_STRICT_CHAIN"):
             b.set_pipelined(True)        # streaming host: the post-chain of step k overlaps the down-converter of step k+1
+            self.mode = "pipelined"
         self.b = b
         self.cap = T // 16 + 4096                                  # audio row capacity (highest output rate: /32)
         self.aud = torch.zeros((C, self.cap), device=dev, dtype=torch.float32)
@@ -424,8 +598,15 @@ class C4Workload:
                     "smeter_db_first4": [round(float(v), 2) for v in self.sm[:4].cpu()]}
         on_gpu = ctx.backend == "nccl"                            # (gloo rehearsal: through host memory)
         wire = payload if on_gpu else payload.cpu()
-        dst = [torch.empty_like(wire) for _ in range(ctx.world)] if ctx.rank == 0 else None
-        ctx.dist.gather(wire, dst, dst=0)                          # warm (communicator setup)
+        # 64 receivers per message: 17 MB from every rank, 4 messages per step -- bounds rank 0's staging to
+        # world x 17 MB per message in flight; RCCL would cut one 67 MB message into pieces of its own anyway
+        rows = 64
+        parts = [wire[r0:r0 + rows] for r0 in range(0, self.C, rows)]
+        dsts = [[torch.empty_like(p) for _ in range(ctx.world)] if ctx.rank == 0 else None for p in parts]
+        def gather_all():
+            for p, d in zip(parts, dsts):
+                ctx.dist.gather(p, d, dst=0)
+        gather_all()                                               # warm (communicator setup)
         torch.cuda.synchronize()
         dist_barrier(ctx)
         t0 = time.perf_counter()
@@ -433,24 +614,64 @@ class C4Workload:
             pack()
             if not on_gpu:
                 wire.copy_(payload)
-            ctx.dist.gather(wire, dst, dst=0)
+            gather_all()
         torch.cuda.synchronize()
         dist_barrier(ctx)
         ms = dist_max(ctx, time.perf_counter() - t0) / reps * 1e3
         nbytes = payload.numel() * 4 * (ctx.world - 1)
         return {"ms": round(ms, 3), "bytes_to_rank0": nbytes, "GBps_into_rank0": round(nbytes / ms / 1e6, 1),
-                "collective": "torch.distributed.gather (RCCL send/recv over xGMI), S-meter + %d audio samples "
-                              "per channel" % n_aud}
+                "collective": "torch.distributed.gather (RCCL send/recv over xGMI) in messages of 64 receivers, "
+                              "S-meter + %d audio samples per receiver" % n_aud}
 
-    def summary(self, ctx, steps, warmup):
-        elapsed, ms = timed_steps(self.torch, ctx, self.step, steps, warmup, prewarm=False)
+    def set_mode(self, pipelined):
+        self.b.flush(self.stream)
+        self.torch.cuda.synchronize()
+        self.b.set_pipelined(bool(pipelined))
+        self.mode = "pipelined" if pipelined else "strict"
+
+    def cpu_baseline(self, budget_s=4.0):
+        """the oracle's CDemodulator on ONE host core over the first three receivers' own streams (AM, FM, USB by
+        turns, like the shard), m_InBufLimit windows: raw input samples per second and core"""
+        from oracle import oracle as orc
+        base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                    FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
+                    AgcManualGain=30, AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+        modes = [(orc.DEMOD_AM, dict(HiCutmin=500, HiCutmax=10000, LowCutmax=-500, LowCutmin=-10000)), (orc.DEMOD_FM, dict()),
+                 (orc.DEMOD_USB, dict(HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200, LowCutmin=0, Symetric=0))]
+        lo, _ = shard_channels(self.ctx, self.C * self.ctx.world)
+        chains, streams = [], []
+        for c in range(3):
+            m, kw = modes[(lo + c) % 3]
+            r = orc.CDemodulator(2048)
+            r.SetInputSampleRate(C4_FS); r.SetDemod(m, orc.DemodInfo(**dict(base, **kw)))
+            r.SetDemodFreq(-(100e3 + 500.0 * ((lo + c) % 1024)))
+            chains.append(r)
+            streams.append(to_c128(self.x[c, :19968 * 16]))
+        def once():
+            for r, xs in zip(chains, streams):
+                r.process_append(xs)
+        v, n = cpu_rate(once, 3 * len(streams[0]), budget_s)
+        return cpu_obj(v, n, "CDemodulator::ProcessData (dsp/demodulator.cpp:163-215) on receivers 0-2 of the shard")
+
+    def summary(self, ctx, steps, warmup, with_cpu=False):
+        """both modes of csdr_demod_batch: `pipelined` (successive calls overlapped, a call's results are complete one
+        call later: what a streaming host uses) is the headline of this object, `strict` (complete in stream order
+        when the call returns) is reported beside it"""
         n = self.C * self.T
-        return {"channels_per_gpu": self.C, "raw_samples_per_channel": self.T, "steps": steps,
-                "ms_per_step": round(elapsed / steps * 1e3, 4), "event_ms_per_step": round(ms, 4),
-                "raw_input_MSamples_per_s_all_gpus": round(n * steps * ctx.world / elapsed / 1e6, 1),
-                "algorithmic_GBps_per_gpu": round((8.0 + 4.0 / 32.0) * n / ms / 1e6, 1),
-                "frac_of_hbm_peak": round((8.0 + 4.0 / 32.0) * n / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "gather": self.gather()}
+        def one(pipelined):
+            self.set_mode(pipelined)
+            elapsed, ms = timed_steps(self.torch, ctx, self.step, steps, warmup, prewarm=False)
+            return {"mode": self.mode, "ms_per_step": round(elapsed / steps * 1e3, 4), "event_ms_per_step": round(ms, 4),
+                    "raw_input_MSamples_per_s_all_gpus": round(n * steps * ctx.world / elapsed / 1e6, 1),
+                    "algorithmic_GBps_per_gpu": round((8.0 + 4.0 / 32.0) * n / ms / 1e6, 1),
+                    "frac_of_hbm_peak": round((8.0 + 4.0 / 32.0) * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        strict = one(False)
+        out = {"channels_per_gpu": self.C, "raw_samples_per_channel": self.T, "steps": steps}
+        out.update(one(True))
+        out["strict"] = strict
+        out["gather"] = self.gather()
+        out["cpu_baseline"] = self.cpu_baseline() if with_cpu else None
+        return out
 
 
 class StubWorkload:
@@ -505,19 +726,30 @@ def run_rank(args):
         del w
         torch.cuda.empty_cache()
         if not args.no_secondary:
+            with_cpu = ctx.world == 1 and not args.no_cpu       # CPU legs: rank 0 at N = 1 only
             c4 = C4Workload(torch, ca, ctx, CHANNELS)
-            s = c4.summary(ctx, 30, 15)
+            s = c4.summary(ctx, 30, 15, with_cpu)
             if ctx.rank == 0:
                 extra["chain_c4"] = s
+            if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
+                extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu)
             del c4
+            torch.cuda.empty_cache()
+            if ctx.world == 1:
+                extra["chain_c2"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c2")
+                extra["chain_c5"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c5")
     else:
         w = C4Workload(torch, ca, ctx, args.channels)
         elapsed, kern_ms = timed_steps(torch, ctx, w.step, args.steps, args.warmup)
         g = w.gather()
         if ctx.rank == 0:
             extra["gather"] = g
+            extra["chain_mode"] = w.mode
         chans, samples = w.C, w.T
         del w
+    census = rank_census(ctx)
+    if ctx.rank == 0:
+        extra["ranks"] = census
 
     if ctx.rank == 0:
         traffic = profiled_traffic() if args.workload == "c3" else None
