@@ -15,6 +15,8 @@ using namespace csdr;
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
                                                     long long out_stride, void *stream, const void *d_packets, int pkt_len);
+extern "C" int csdr__downconvert_batch_copy_channel(csdr_downconvert_batch *dst, int dc, csdr_downconvert_batch *src, int sc);
+extern "C" int csdr__fastfir_batch_copy_row(csdr_fastfir_batch *dst, int dr, csdr_fastfir_batch *src, int sr);
 extern "C" int csdr__noiseproc_batch_process_packets(struct csdr_noiseproc_batch *b, const void *d_packets, int npackets,
                                                      int pkt_len, float *d_out, long long out_stride, void *stream);
 
@@ -346,7 +348,9 @@ struct csdr_demod_batch {
     std::vector<int> core_of, row_of;                 // channel -> (core, row)
     std::vector<ChainCore *> cores;                   // one per distinct decimator plan
     std::vector<std::vector<int>> members;            // core -> channel ids (row order)
-    std::vector<int *> d_rows;                        // core -> device array of channel ids
+    std::vector<int *> d_rows;                        // core -> device array of channel ids (input rows)
+    std::vector<int *> d_out_rows;                    // core -> the same for the outputs, -1 = muted row (its receiver has
+                                                      // moved to another plan group: csdr_demod_batch_set_demod)
     std::map<long long, int> core_by_bw;
     // the groups are independent: each runs on its own stream, forked from and joined to the caller's
     std::vector<hipStream_t> streams;
@@ -363,6 +367,7 @@ struct csdr_demod_batch {
     {
         for (auto *k : cores) delete k;
         for (auto *p : d_rows) if (p) (void)hipFree(p);
+        for (auto *p : d_out_rows) if (p) (void)hipFree(p);
         if (d_blank) (void)hipFree(d_blank);
         for (auto st : streams) (void)hipStreamDestroy(st);
         for (auto ev : joins) (void)hipEventDestroy(ev);
@@ -370,6 +375,94 @@ struct csdr_demod_batch {
         if (fork) (void)hipEventDestroy(fork);
     }
 };
+
+// The group whose post-chain is the longest pole (FM: PLL + squelch filters, at the highest decimated rate) goes
+// first: its down-converter should not share the chip with the other groups' while its demodulators wait.
+static void batch_order(csdr_demod_batch *b)
+{
+    std::vector<double> weight(b->cores.size(), 0.0);
+    for (int c = 0; c < b->channels; c++) {
+        if (b->core_of[c] < 0) continue;
+        const int m = b->cfg[c].mode;
+        const double w = (m == PC_MODE_FM ? 3.0 : m == PC_MODE_SAM ? 2.5 : m == PC_MODE_AM ? 1.5 : 1.0) * b->cfg[c].out_rate;
+        weight[b->core_of[c]] = std::max(weight[b->core_of[c]], w);
+    }
+    b->order.resize(b->cores.size());
+    for (size_t i = 0; i < b->order.size(); i++) b->order[i] = (int)i;
+    std::stable_sort(b->order.begin(), b->order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+}
+// one stream and two events per plan group, the fork event: whatever is still missing
+static int batch_plumbing(csdr_demod_batch *b)
+{
+    if (!b->fork) CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+    int pr_lo = 0, pr_hi = 0;                          // numerically lower = higher priority
+    CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+    while (b->streams.size() < b->cores.size()) {
+        const size_t ki = b->streams.size();
+        size_t rank = 0;
+        while (rank < b->order.size() && b->order[rank] != (int)ki) rank++;
+        int pr = pr_hi + (int)rank;
+        if (pr > pr_lo) pr = pr_lo;
+        hipStream_t st;
+        CSDR_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr));
+        b->streams.push_back(st);
+    }
+    while (b->joins.size() < b->cores.size()) {
+        hipEvent_t ev;
+        CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->joins.push_back(ev);
+    }
+    while (b->dc_done.size() < b->cores.size()) {
+        hipEvent_t ev;
+        CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->dc_done.push_back(ev);
+    }
+    b->prev_post.resize(b->cores.size(), -1);
+    b->prev_join.resize(b->cores.size(), 0);
+    return CSDR_OK;
+}
+
+/* CDemodulator::SetDemod with a mode whose maximum bandwidth -- hence decimator chain and output rate -- differs from
+ * the receiver's present one, on a committed batch (dsp/demodulator.cpp:107-157).  The receiver leaves its plan group
+ * (whose rows share one decimation, hop count and staging fill) and continues in a group of its own, with everything
+ * the reference keeps across SetDemod: the down-converter's oscillator, the filter's overlap AND its partly filled
+ * input (samples at the OLD rate: fastfir.cpp:278-285 never resets m_InBufInPos), AGC and S-meter objects; the new
+ * demodulator starts fresh and the rebuilt decimator from zero histories, as there.  Its old row stays in the old
+ * group, muted (no output, no S-meter; the group still filters it).  A receiver already alone in its group changes
+ * in place, exactly like the single-channel object. */
+static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const DemodInfo &di)
+{
+    CSDR_HIP(hipDeviceSynchronize());                  // control plane: nothing of this batch in flight from here on
+    const int ka = b->core_of[channel], r = b->row_of[channel];
+    ChainCore &A = *b->cores[ka];
+    if (A.rows == 1) return apply_set_demod(A, 0, b->cfg[channel], b->in_rate, mode, di);
+    ChainCore *S = new ChainCore();
+    int rc = S->init(b->device, 1, b->fft_n);
+    if (rc == CSDR_OK && b->pipelined) rc = S->pipelined_init();
+    if (rc == CSDR_OK) rc = csdr__downconvert_batch_copy_channel(S->dc, 0, A.dc, r);
+    if (rc == CSDR_OK) rc = csdr__fastfir_batch_copy_row(S->ff, 0, A.ff, r);
+    if (rc == CSDR_OK) rc = S->pc.import_channel(0, A.pc, r);
+    if (rc == CSDR_OK) rc = S->ensure((long)A.pending + 1);
+    if (rc != CSDR_OK) { delete S; return rc; }
+    if (A.pending > 0) {
+        const float *cur = (A.stage_cur ? A.d_stage2 : A.d_stage) + (size_t)r * A.cap * 2;
+        CSDR_HIP(hipMemcpy(S->d_stage, cur, (size_t)A.pending * 8, hipMemcpyDeviceToDevice));
+    }
+    S->pending = A.pending;
+    int *dr = nullptr, *dor = nullptr;
+    CSDR_HIP(hipMalloc((void **)&dr, sizeof(int)));
+    CSDR_HIP(hipMalloc((void **)&dor, sizeof(int)));
+    CSDR_HIP(hipMemcpy(dr, &channel, sizeof(int), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(dor, &channel, sizeof(int), hipMemcpyHostToDevice));
+    const int muted = -1;                              // the old row: keeps reading its input, writes nothing
+    CSDR_HIP(hipMemcpy(b->d_out_rows[ka] + r, &muted, sizeof(int), hipMemcpyHostToDevice));
+    b->cores.push_back(S);
+    b->members.push_back(std::vector<int>(1, channel));
+    b->d_rows.push_back(dr); b->d_out_rows.push_back(dor);
+    b->core_of[channel] = (int)b->cores.size() - 1; b->row_of[channel] = 0;
+    rc = apply_set_demod(*S, 0, b->cfg[channel], b->in_rate, mode, di);
+    if (rc) return rc;
+    batch_order(b);
+    return batch_plumbing(b);
+}
 
 extern "C" {
 
@@ -500,11 +593,12 @@ int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const
         return fail(CSDR_EINVAL, "bad argument");
     ChanCfg &c = b->cfg[channel];
     if (b->core_of[channel] >= 0) {
-        // already committed: only parameter changes that keep the decimator chain are accepted
+        // already committed: a change that keeps the decimator chain stays in its row; one that alters it moves the
+        // receiver to a plan group of its own (batch_move_channel)
         DemodInfo di; memcpy(&di, info, sizeof(di));
+        if (!device_ok(b->device)) return CSDR_EHIP;
         const double bw = (mode == PC_MODE_LSB || mode == PC_MODE_CWL) ? -di.LowCutmin : di.HiCutmax;
-        if (bw != c.want_bw) return fail(CSDR_ESTATE, "channel %d: a mode change that alters the decimator "
-                                         "chain needs a new batch object", channel);
+        if (bw != c.want_bw) return batch_move_channel(b, channel, mode, di);
         return apply_set_demod(*b->cores[b->core_of[channel]], b->row_of[channel], c, b->in_rate, mode, di);
     }
     memcpy(&c.info, info, sizeof(DemodInfo));
@@ -533,6 +627,10 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
         CSDR_HIP(hipMalloc((void **)&dr, sizeof(int) * g.second.size()));
         CSDR_HIP(hipMemcpy(dr, g.second.data(), sizeof(int) * g.second.size(), hipMemcpyHostToDevice));
         b->d_rows.push_back(dr);
+        int *dor = nullptr;
+        CSDR_HIP(hipMalloc((void **)&dor, sizeof(int) * g.second.size()));
+        CSDR_HIP(hipMemcpy(dor, g.second.data(), sizeof(int) * g.second.size(), hipMemcpyHostToDevice));
+        b->d_out_rows.push_back(dor);
         for (size_t r = 0; r < g.second.size(); r++) {
             const int c = g.second[r];
             b->core_of[c] = ki; b->row_of[c] = (int)r;
@@ -543,35 +641,10 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
             if (rc) return rc;
         }
     }
-    // The group whose post-chain is the longest pole (FM: PLL + squelch filters, at the highest
-    // decimated rate) goes first and on the highest-priority stream: its down-converter should not
-    // share the chip with the other groups' while its demodulators wait.
-    std::vector<double> weight(b->cores.size(), 0.0);
-    for (int c = 0; c < b->channels; c++) {
-        const int m = b->cfg[c].mode;
-        const double w = (m == PC_MODE_FM ? 3.0 : m == PC_MODE_SAM ? 2.5 : m == PC_MODE_AM ? 1.5 : 1.0) * b->cfg[c].out_rate;
-        weight[b->core_of[c]] = std::max(weight[b->core_of[c]], w);
-    }
-    b->order.resize(b->cores.size());
-    for (size_t i = 0; i < b->order.size(); i++) b->order[i] = (int)i;
-    std::sort(b->order.begin(), b->order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    batch_order(b);                                    // heaviest post-chain first, and on the highest-priority stream
     if (b->cores.size() > 1) {
-        CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
-        int pr_lo = 0, pr_hi = 0;                       // numerically lower = higher priority
-        CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        b->streams.resize(b->cores.size());
-        for (size_t rank = 0; rank < b->order.size(); rank++) {
-            int pr = pr_hi + (int)rank;
-            if (pr > pr_lo) pr = pr_lo;
-            CSDR_HIP(hipStreamCreateWithPriority(&b->streams[b->order[rank]], hipStreamNonBlocking, pr));
-        }
-        for (size_t ki = 0; ki < b->cores.size(); ki++) {
-            hipEvent_t ev;
-            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            b->joins.push_back(ev);
-            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            b->dc_done.push_back(ev);
-        }
+        int rc = batch_plumbing(b);
+        if (rc) return rc;
     }
     return CSDR_OK;
 }
@@ -584,15 +657,9 @@ int csdr_demod_batch_set_pipelined(csdr_demod_batch *b, int on)
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
     if (!device_ok(b->device)) return CSDR_EHIP;
     CSDR_HIP(hipDeviceSynchronize());
-    if (on && b->streams.empty()) {                    // a single plan group normally runs on the caller's stream
-        CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
-        b->streams.resize(b->cores.size());
-        for (size_t ki = 0; ki < b->cores.size(); ki++) {
-            CSDR_HIP(hipStreamCreateWithFlags(&b->streams[ki], hipStreamNonBlocking));
-            hipEvent_t ev;
-            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->joins.push_back(ev);
-            CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->dc_done.push_back(ev);
-        }
+    if (on) {                                          // a single plan group normally runs on the caller's stream
+        int rc = batch_plumbing(b);
+        if (rc) return rc;
     }
     if (on) for (auto *k : b->cores) { int rc = k->pipelined_init(); if (rc) return rc; }
     b->prev_post.assign(b->cores.size(), -1);
@@ -644,7 +711,7 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
     int rcf = csdr_demod_batch_flush(b, stream);         // pipelined mode: behind the last call's post-chain
     if (rcf) return rcf;
     for (size_t ki = 0; ki < b->cores.size(); ki++)
-        CSDR_HIP(smeter_collect_launch(b->cores[ki]->pc.d_chan, b->cores[ki]->rows, b->d_rows[ki], d_ave, d_peak,
+        CSDR_HIP(smeter_collect_launch(b->cores[ki]->pc.d_chan, b->cores[ki]->rows, b->d_out_rows[ki], d_ave, d_peak,
                                        (hipStream_t)stream));
     return CSDR_OK;
 }
@@ -681,10 +748,10 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         // overlap comes from the next call
         int rc;
         if (k.s_post)
-            rc = k.step_pipelined(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_rows[ki], stereo,
+            rc = k.step_pipelined(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_out_rows[ki], stereo,
                                   st, !b->pipelined && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, b->dc_done[ki]);
         else
-            rc = k.step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_rows[ki], stereo, st,
+            rc = k.step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_out_rows[ki], stereo, st,
                         forked && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, forked ? b->dc_done[ki] : nullptr);
         if (rc < 0 && !err) err = rc;
         if (forked) {                                   // join even after an error: the caller's stream stays ordered

@@ -54,6 +54,28 @@ static int find_plan(csdr_downconvert_batch *b, double in_rate, double max_bw)
     return (int)b->plans.size() - 1;
 }
 
+/* internal (csdr_demod_batch_set_demod moving a receiver to another plan group): channel `sc` of `src` continues as
+ * channel `dc` of `dst` -- the whole CDownConvert object: rates, NCO frequency and CW offset, oscillator phase and
+ * age, decimator chain and its stage histories.  Both handles idle (the caller has synchronised). */
+extern "C" int csdr__downconvert_batch_copy_channel(csdr_downconvert_batch *dst, int dc, csdr_downconvert_batch *src, int sc)
+{
+    if (!dst || !src || dc < 0 || dc >= dst->channels || sc < 0 || sc >= src->channels) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(dst->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    dst->ch[dc] = src->ch[sc];
+    const DcPlan &sp = src->plans[src->plan_of[sc]];
+    dst->plan_of[dc] = find_plan(dst, sp.in_rate, sp.max_bw);
+    dst->state_dirty = true; dst->lists_dirty = true;
+    int rc = ensure_hist(dst);
+    if (rc) return rc;
+    const int w = src->hist_stride < dst->hist_stride ? src->hist_stride : dst->hist_stride;
+    const size_t shalf = (size_t)src->channels * src->hist_stride * 2, dhalf = (size_t)dst->channels * dst->hist_stride * 2;
+    CSDR_HIP(hipMemcpy(dst->d_hist + dst->hist_cur * dhalf + (size_t)dc * dst->hist_stride * 2,
+                       src->d_hist + src->hist_cur * shalf + (size_t)sc * src->hist_stride * 2, (size_t)w * 8,
+                       hipMemcpyDeviceToDevice));
+    return CSDR_OK;
+}
+
 /* internal (tests): 1 = every down-converter launch takes the run-time-plan kernel, 0 = precompiled plans where
  * they exist, -1 = query only; returns the number of precompiled plans in the library */
 extern "C" int csdr__downconv_force_dynamic(int on) { return downconv_force_dynamic(on); }

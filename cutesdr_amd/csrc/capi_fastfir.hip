@@ -3,6 +3,7 @@
 #include <algorithm>
 #include "fastfir_kernels.h"
 #include "host_math.hpp"
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -259,6 +260,29 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     }
     else CSDR_HIP(fastfir_launch(b->log2n, a, s));
     b->hist_cur ^= 1;        // the kernel left this call's tail in the other half
+    return CSDR_OK;
+}
+
+/* internal (csdr_demod_batch_set_demod moving a receiver to another plan group): row `sr` of `src` continues as row
+ * `dr` of `dst` -- the overlap of the stream so far and the frequency response in use (a later SetupParameters with a
+ * parameter error keeps it, fastfir.cpp:195-203).  Same FFT size, both handles idle. */
+int csdr__fastfir_batch_copy_row(csdr_fastfir_batch *dst, int dr, csdr_fastfir_batch *src, int sr)
+{
+    if (!dst || !src || dst->n != src->n || dr < 0 || dr >= dst->channels || sr < 0 || sr >= src->channels)
+        return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(dst->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    const int L = dst->n / 2;
+    const size_t shalf = (size_t)src->channels * L * 2, dhalf = (size_t)dst->channels * L * 2;
+    CSDR_HIP(hipMemcpy(dst->d_hist + dst->hist_cur * dhalf + (size_t)dr * L * 2,
+                       src->d_hist + src->hist_cur * shalf + (size_t)sr * L * 2, (size_t)L * 8, hipMemcpyDeviceToDevice));
+    const std::vector<cd> &H = src->resp[src->per_channel ? sr : 0];
+    if (dst->channels > 1 && !dst->per_channel) return fail(CSDR_ESTATE, "destination rows share one filter");
+    const int slot = dst->per_channel ? dr : 0;
+    int rc = upload_response(dst, slot, H);
+    if (rc) return rc;
+    dst->resp[slot] = H;
+    dst->flo = dst->fhi = dst->off = dst->fs = std::nan("");      // parameters unknown: the next setup always designs
     return CSDR_OK;
 }
 

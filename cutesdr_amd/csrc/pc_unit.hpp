@@ -67,6 +67,20 @@ struct PcUnit {
         CSDR_HIP(hipMemcpy(d_mag + (size_t)c * PC_AGC_RING, m16.data(), m16.size() * 4, hipMemcpyHostToDevice));
         return CSDR_OK;
     }
+    // channel `sc` of `src` continues as channel `c` here: S-meter, AGC (rings included) and demodulator objects
+    // with all their state (csdr_demod_batch_set_demod moving a receiver to another plan group)
+    int import_channel(int c, PcUnit &src, int sc)
+    {
+        int rc = src.pull(sc);
+        if (rc) return rc;
+        h[c] = src.h[sc]; hagc[c] = src.hagc[sc];
+        fir_am[c] = src.fir_am[sc]; fir_sam[c] = src.fir_sam[sc]; fir_fm[c] = src.fir_fm[sc];
+        CSDR_HIP(hipMemcpy(d_dly + (size_t)c * 2 * PC_AGC_RING, src.d_dly + (size_t)sc * 2 * PC_AGC_RING,
+                           sizeof(float) * 2 * PC_AGC_RING, hipMemcpyDeviceToDevice));
+        CSDR_HIP(hipMemcpy(d_mag + (size_t)c * PC_AGC_RING, src.d_mag + (size_t)sc * PC_AGC_RING,
+                           sizeof(float) * PC_AGC_RING, hipMemcpyDeviceToDevice));
+        return push(c);
+    }
     // CAgc::SetParameters
     int agc_set(int c, int on, int hang, int thresh, int manual, int slope, int decay, double fs)
     {

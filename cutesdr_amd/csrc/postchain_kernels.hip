@@ -895,6 +895,7 @@ void postchain_kernel(PcArgs a)
     // in the batch chain it shares CUs with the down-converter of other groups / the next call, whose 12-16 waves
     // per CU would otherwise take most issue slots.  Highest issue priority for these few waves costs the
     // streaming kernel next to nothing and keeps the walk at the speed it has alone.
+    if (a.out_rows && a.out_rows[ch] < 0) return;      // muted row (its receiver has moved on): uniform per workgroup
     __builtin_amdgcn_s_setprio(3);
     const G g{t, t & 63, t >> 6, &S};
     PcChannel &C = a.chan[ch];
@@ -1347,6 +1348,7 @@ __global__ void smeter_collect_kernel(PcChannel *chan, int channels, const int *
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= channels) return;
     const int o = rows ? rows[c] : c;
+    if (o < 0) return;                  // a row whose receiver has moved to another plan group (csdr_demod_batch_set_demod)
     if (ave) ave[o] = (T)(chan[c].sm.ave_mag + 5.0);
     if (peak) {
         peak[o] = (T)(chan[c].sm.peak_mag + 5.0);
