@@ -560,19 +560,21 @@ class C4Workload:
                  (ca.DEMOD_FM, dict()),
                  (ca.DEMOD_USB, dict(HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200,
                                      LowCutmin=0, Symetric=0))]
-        b = ca.DemodBatch(C, 2048, device=ctx.local)
-        b.set_input_rate(C4_FS)
-        for c in range(C):
-            m, kw = modes[(lo + c) % 3]
-            b.set_demod(c, m, ca.DemodInfo(**dict(base, **kw)))
-        b.commit()
-        for c in range(C):
-            b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)))
-        self.mode = "strict"
-        if not os.environ.get("CSDR_BENCH_STRICT_CHAIN"):
-            b.set_pipelined(True)        # streaming host: the post-chain of step k overlaps the down-converter of step k+1
-            self.mode = "pipelined"
-        self.b = b
+        def make_batch(pipelined):
+            b = ca.DemodBatch(C, 2048, device=ctx.local)
+            b.set_input_rate(C4_FS)
+            for c in range(C):
+                m, kw = modes[(lo + c) % 3]
+                b.set_demod(c, m, ca.DemodInfo(**dict(base, **kw)))
+            b.commit()
+            for c in range(C):
+                b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)))
+            if pipelined:
+                b.set_pipelined(True)    # streaming host: the post-chain of step k overlaps the down-converter of step k+1
+            return b
+        self.make_batch = make_batch
+        self.mode = "strict" if os.environ.get("CSDR_BENCH_STRICT_CHAIN") else "pipelined"
+        self.b = make_batch(self.mode == "pipelined")
         self.cap = T // 16 + 4096                                  # audio row capacity (highest output rate: /32)
         self.aud = torch.zeros((C, self.cap), device=dev, dtype=torch.float32)
         self.sm = torch.zeros((C,), device=dev, dtype=torch.float32)
@@ -624,10 +626,16 @@ class C4Workload:
                               "S-meter + %d audio samples per receiver" % n_aud}
 
     def set_mode(self, pipelined):
+        """a fresh batch object in the wanted mode (a strict-mode object never creates the pipelined mode's streams
+        and second buffers: that is the path a host that never asks for pipelining runs)"""
+        want = "pipelined" if pipelined else "strict"
+        if want == self.mode:
+            return
         self.b.flush(self.stream)
         self.torch.cuda.synchronize()
-        self.b.set_pipelined(bool(pipelined))
-        self.mode = "pipelined" if pipelined else "strict"
+        del self.b
+        self.b = self.make_batch(pipelined)
+        self.mode = want
 
     def cpu_baseline(self, budget_s=4.0):
         """the oracle's CDemodulator on ONE host core over the first three receivers' own streams (AM, FM, USB by

@@ -1,13 +1,20 @@
 // capi_soundsink.hip -- C ABI of the sound-sink adaptation: the queue and the rate-error
-// loop of CSoundOut (reference interface/soundout.cpp:155-468, non-blocking mode) around the device resampler.
+// loop of CSoundOut (reference interface/soundout.cpp:155-468, both modes) around the device resampler.
 // The step after the path in a live receiver: PutOutQueue resamples the demodulator's audio to the sound-card
 // rate with Rate = m_OutRatio (1 + m_RateCorrection) (CFractResampler on the GPU, csdr_resampler_*), the audio
 // thread pops with GetOutQueue, and once per second of consumed samples the P-controller CalcError (:456-468)
 // turns the average queue fill into the next correction.  The queue, the fill average and the controller are
-// scalar host logic; only the resampling is device work.
+// scalar host logic; only the resampling is device work.  Blocking mode (Start(..., BlockingMode = true), :86-90):
+// PutOutQueue never drops -- it waits, 10 ms at a time, while the queue is full (:209-220, :267-278) -- and GetOutQueue
+// returns right after popping, without the fill average and the rate controller (:354-358, :428-432): the producer is
+// paced by the sound card instead of being resampled to it.  put and get may come from two threads, as in the
+// reference (the IQ thread and the audio thread): both run under the sink's mutex (m_Mutex).
 #include "capi_common.hpp"
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -23,6 +30,9 @@ struct csdr_soundsink {
     bool startup = true;                  // m_Startup
     double user_rate = kRate, out_ratio = 1.0, rate_corr = 0.0, gain = 1.0, ave_level = 0.0;
     int head = 0, tail = 0, level = 0, rate_count = 0, ppm = 0;
+    bool blocking = false;                // m_BlockingMode
+    std::mutex mu;                        // m_Mutex
+    std::condition_variable cv;           // wakes a put that waits for room (the reference sleeps 10 ms and looks again)
     std::vector<short> q, r;              // the ring (2 shorts per entry when stereo), resampler output
 };
 
@@ -46,10 +56,20 @@ void csdr_soundsink_destroy(csdr_soundsink *s)
     csdr_resampler_destroy(s->rs);
     delete s;
 }
+/* CSoundOut::Start's BlockingMode argument (:86-90) */
+int csdr_soundsink_set_blocking(csdr_soundsink *s, int on)
+{
+    if (!s) return csdr::fail(CSDR_EINVAL, "bad handle");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->blocking = on != 0;
+    s->cv.notify_all();
+    return CSDR_OK;
+}
 /* CSoundOut::ChangeUserDataRate (:155-175) */
 int csdr_soundsink_change_user_data_rate(csdr_soundsink *s, double rate)
 {
     if (!s || !(rate > 0.0)) return csdr::fail(CSDR_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (s->user_rate != rate) {
         s->user_rate = rate;
         std::fill(s->q.begin(), s->q.end(), (short)0);
@@ -80,6 +100,20 @@ int csdr_soundsink_put(csdr_soundsink *s, int n, const double *in)
     const int k = s->stereo ? csdr_resampler_resample_cpx_i16(s->rs, n, rate, in, s->r.data(), s->gain)
                             : csdr_resampler_resample_real_i16(s->rs, n, rate, in, s->r.data(), s->gain);
     if (k < 0) return k;
+    std::unique_lock<std::mutex> lock(s->mu);
+    if (s->blocking) {                                  // :209-220 / :267-278: wait while the queue is full, drop nothing
+        for (int i = 0; i < k; i++) {
+            while (((s->head + 1) & (kQ - 1)) == s->tail) {
+                if (!s->blocking) break;                // the mode was switched off while waiting
+                s->cv.wait_for(lock, std::chrono::milliseconds(10));
+            }
+            if (s->stereo) { s->q[2 * s->head] = s->r[2 * i]; s->q[2 * s->head + 1] = s->r[2 * i + 1]; }
+            else s->q[s->head] = s->r[i];
+            s->head = (s->head + 1) & (kQ - 1);
+            s->level++;
+        }
+        return k;
+    }
     bool overflow = false;
     for (int i = 0; i < k; i++) {
         if (s->stereo) { s->q[2 * s->head] = s->r[2 * i]; s->q[2 * s->head + 1] = s->r[2 * i + 1]; }
@@ -101,6 +135,7 @@ int csdr_soundsink_put(csdr_soundsink *s, int n, const double *in)
 int csdr_soundsink_get(csdr_soundsink *s, int n, short *out)
 {
     if (!s || n < 0 || (n > 0 && !out)) return csdr::fail(CSDR_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     const int w = s->stereo ? 2 : 1;
     if (s->startup) {                                   // silence until the queue is half full (:316-333)
         std::memset(out, 0, sizeof(short) * (size_t)w * n);
@@ -126,6 +161,8 @@ int csdr_soundsink_get(csdr_soundsink *s, int n, short *out)
             underflow = true;
         }
     }
+    s->cv.notify_all();                                 // room for a waiting put
+    if (s->blocking) return n;                          // :354-358 / :428-432: no fill average, no rate controller
     s->ave_level = (1.0 - kAlpha) * s->ave_level + kAlpha * s->level;
     if (underflow) s->ave_level = s->level;
     s->rate_count += n;
@@ -138,7 +175,12 @@ int csdr_soundsink_get(csdr_soundsink *s, int n, short *out)
 }
 double csdr_soundsink_get_rate_correction(csdr_soundsink *s) { return s ? s->rate_corr : 0.0; }
 double csdr_soundsink_get_ave_level(csdr_soundsink *s) { return s ? s->ave_level : 0.0; }
-int csdr_soundsink_get_level(csdr_soundsink *s) { return s ? s->level : csdr::fail(CSDR_EINVAL, "bad handle"); }
+int csdr_soundsink_get_level(csdr_soundsink *s)
+{
+    if (!s) return csdr::fail(CSDR_EINVAL, "bad handle");
+    std::lock_guard<std::mutex> lock(s->mu);
+    return s->level;
+}
 int csdr_soundsink_get_ppm_error(csdr_soundsink *s) { return s ? s->ppm : 0; }
 
 }  // extern "C"

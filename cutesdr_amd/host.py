@@ -797,7 +797,7 @@ class ResamplerBatch(_Obj):
 
 
 class CSoundOut(_Obj):
-    """interface/soundout.cpp -- queue and rate-error loop of the sound sink (non-blocking mode) around the
+    """interface/soundout.cpp -- queue and rate-error loop of the sound sink (both modes) around the
     device resampler; PutOutQueue / GetOutQueue / ChangeUserDataRate / SetVolume as in the reference"""
     _destroy = "csdr_soundsink_destroy"
 
@@ -810,6 +810,10 @@ class CSoundOut(_Obj):
 
     def SetVolume(self, vol):
         check(lib().csdr_soundsink_set_volume(self.h, vol))
+
+    def SetBlocking(self, on):
+        """CSoundOut::Start's BlockingMode: PutOutQueue waits while the queue is full, GetOutQueue skips the rate loop"""
+        check(lib().csdr_soundsink_set_blocking(self.h, int(on)))
 
     def PutOutQueue(self, x):
         a = _c128(x) if self.stereo else _f64(x)

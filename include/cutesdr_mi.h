@@ -354,7 +354,7 @@ int csdr_resampler_batch_resample(csdr_resampler_batch *b, const float *d_in, lo
 
 /* ----------------------------------------------------------------------------------------
  * Sound-sink adaptation: the queue and rate-error loop of CSoundOut
- * (interface/soundout.cpp, non-blocking mode) around the device resampler -- the step right after the path in
+ * (interface/soundout.cpp, both modes) around the device resampler -- the step right after the path in
  * a live receiver.  put = PutOutQueue (:196-305): resample to 48 kHz int16 with Rate = m_OutRatio *
  * (1 + m_RateCorrection) and the volume gain, queue (16384 entries; overflow drops a quarter); get = GetOutQueue
  * (:311-445) for the audio thread (silence until half full, underflow backs up a quarter); every second of
@@ -365,6 +365,7 @@ typedef struct csdr_soundsink csdr_soundsink;
 csdr_soundsink *csdr_soundsink_create(int device, int stereo);               /* soundout.cpp:60-76 */
 void csdr_soundsink_destroy(csdr_soundsink *s);
 int csdr_soundsink_change_user_data_rate(csdr_soundsink *s, double rate);    /* :155-175 */
+int csdr_soundsink_set_blocking(csdr_soundsink *s, int on);                  /* Start(..., BlockingMode) :86-90: put waits while the queue is full (:209-220), get skips the rate loop (:354-358) */
 int csdr_soundsink_set_volume(csdr_soundsink *s, int vol);                   /* :180-189 */
 /* in: n doubles (mono sink) or n interleaved double pairs (stereo sink), at most 8192 samples; returns the
  * resampled samples produced */

@@ -1404,7 +1404,11 @@ void orc_spurcal(double *dc, int n_doubles, const double *data)
 /* ==================================================================================== */
 /* CSoundOut queue + rate-error loop (interface/soundout.cpp)  -- SURVEY 8(f) row f3        */
 /* ==================================================================================== */
-/* The non-blocking mode of the sound sink: PutOutQueue resamples to the sound-card rate with
+/* Blocking mode (Start(..., BlockingMode), :86-90): PutOutQueue waits (msleep(10)) while the queue is full and
+ * drops nothing (:209-220, :267-278); GetOutQueue returns right after popping (:354-358, :428-432).  This
+ * single-threaded restatement cannot wait: its blocking put queues what fits and returns -1 - (samples left over)
+ * when the reference would have started to sleep -- the tests drive it so that this never happens.
+ * The non-blocking mode of the sound sink: PutOutQueue resamples to the sound-card rate with
  * Rate = m_OutRatio * (1 + m_RateCorrection) and the volume gain, pushes into a 16384-entry ring
  * (overflow: drop a quarter of the queue), GetOutQueue pops for the audio thread (start-up silence
  * until the queue is half full, underflow: back up a quarter), both track the average fill level,
@@ -1415,7 +1419,7 @@ void orc_spurcal(double *dc, int n_doubles, const double *data)
 #define SS_PGAIN 2.38e-7                /* soundout.cpp:52 */
 struct orc_soundsink {
     orc_resampler *rs;
-    int stereo, startup;
+    int stereo, startup, blocking;
     double user_rate, out_ratio, rate_corr, gain, ave_level;
     int head, tail, level, rate_count, ppm;
     short q[2 * SS_OUTQSIZE];
@@ -1440,6 +1444,7 @@ void orc_soundsink_change_rate(orc_soundsink *s, double rate)   /* ChangeUserDat
         s->startup = 1;
     }
 }
+void orc_soundsink_set_blocking(orc_soundsink *s, int on) { s->blocking = on != 0; }      /* Start :86-90 */
 void orc_soundsink_set_volume(orc_soundsink *s, int vol)        /* SetVolume :180-189 */
 {
     if (vol == 0) s->gain = 0.0;
@@ -1462,6 +1467,16 @@ int orc_soundsink_put(orc_soundsink *s, int n, const double *in)
     if (n == 0) return 0;
     k = s->stereo ? orc_resampler_cpx_i16(s->rs, n, rate, (const orc_cpx *)in, r, s->gain)
                   : orc_resampler_real_i16(s->rs, n, rate, in, r, s->gain);
+    if (s->blocking) {                                           /* :209-220 / :267-278 */
+        for (i = 0; i < k; i++) {
+            if (((s->head + 1) & (SS_OUTQSIZE - 1)) == s->tail) return -1 - (k - i);     /* the reference sleeps here */
+            if (s->stereo) { s->q[2 * s->head] = r[2 * i]; s->q[2 * s->head + 1] = r[2 * i + 1]; }
+            else s->q[s->head] = r[i];
+            s->head = (s->head + 1) & (SS_OUTQSIZE - 1);
+            s->level++;
+        }
+        return k;
+    }
     for (i = 0; i < k; i++) {
         if (s->stereo) { s->q[2 * s->head] = r[2 * i]; s->q[2 * s->head + 1] = r[2 * i + 1]; }
         else s->q[s->head] = r[i];
@@ -1506,6 +1521,7 @@ void orc_soundsink_get(orc_soundsink *s, int n, short *out)
             underflow = 1;
         }
     }
+    if (s->blocking) return;                                     /* :354-358 / :428-432 */
     s->ave_level = (1.0 - SS_ALPHA) * s->ave_level + SS_ALPHA * s->level;
     if (underflow) s->ave_level = s->level;
     s->rate_count += n;

@@ -189,6 +189,7 @@ orc_soundsink *orc_soundsink_new(int stereo);
 void orc_soundsink_free(orc_soundsink *s);
 void orc_soundsink_change_rate(orc_soundsink *s, double rate);
 void orc_soundsink_set_volume(orc_soundsink *s, int vol);
+void orc_soundsink_set_blocking(orc_soundsink *s, int on);
 int orc_soundsink_put(orc_soundsink *s, int n, const double *in);
 void orc_soundsink_get(orc_soundsink *s, int n, short *out);
 double orc_soundsink_rate_correction(const orc_soundsink *s);

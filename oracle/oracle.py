@@ -91,6 +91,7 @@ def _declare(L):
     f("orc_unpack_packet", I, P, I, P); f("orc_spurcal", None, P, I, P)
     f("orc_soundsink_new", P, I); f("orc_soundsink_free", None, P)
     f("orc_soundsink_change_rate", None, P, D); f("orc_soundsink_set_volume", None, P, I)
+    f("orc_soundsink_set_blocking", None, P, I)
     f("orc_soundsink_put", I, P, I, P); f("orc_soundsink_get", None, P, I, P)
     f("orc_soundsink_rate_correction", D, P); f("orc_soundsink_ave_level", D, P)
     f("orc_soundsink_level", I, P); f("orc_soundsink_ppm", I, P)
@@ -543,7 +544,8 @@ def fm_defaults():
 
 
 class CSoundOut(_Handle):
-    """interface/soundout.cpp:155-468, non-blocking mode: queue + rate-error loop around CFractResampler"""
+    """interface/soundout.cpp:155-468: queue + rate-error loop around CFractResampler (blocking mode: the put that
+    would have to wait returns a negative count)"""
     _free = "orc_soundsink_free"
 
     def __init__(self, stereo=False):
@@ -555,6 +557,9 @@ class CSoundOut(_Handle):
 
     def SetVolume(self, vol):
         lib().orc_soundsink_set_volume(self.h, vol)
+
+    def SetBlocking(self, on):
+        lib().orc_soundsink_set_blocking(self.h, int(on))
 
     def PutOutQueue(self, x):
         a = _c128(x) if self.stereo else np.ascontiguousarray(x, dtype=np.float64)
