@@ -91,6 +91,17 @@ __device__ __forceinline__ void lds_barrier()
 #endif
 static_assert(DC_T == 64, "lds_barrier() relies on a single-wave workgroup");
 
+// the raw samples are read once: non-temporal loads keep them from displacing what the chip re-reads (K1 measured
+// -1.2 % for the same change; here A/B'd with tools/bench_k2_plans.py)
+__device__ __forceinline__ v4f dc_stream_load(const v4f *p)
+{
+#ifdef CSDR_NO_NT
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+
 // e^{j * 2*pi * phase/2^64}
 __device__ __forceinline__ v2f phasor_of(unsigned long long phase)
 {
@@ -267,7 +278,7 @@ void downconv_kernel(DcArgs a)
                     const wf4 w = wire_pair_fetch(pk, a.wire.pkt_len, p + i);          // raw words; p + i is even
                     raw[r] = v4f{w.x, w.y, w.z, w.w};
                 } else {
-                    raw[r] = *reinterpret_cast<const v4f *>(in + p + i);
+                    raw[r] = dc_stream_load(reinterpret_cast<const v4f *>(in + p + i));
                 }
             }
         }
@@ -333,7 +344,7 @@ void downconv_kernel(DcArgs a)
                             const wf4 wv = wire_pair_fetch(pk, fmt, i);
                             raw[r] = v4f{wv.x, wv.y, wv.z, wv.w};
                         } else {
-                            raw[r] = *reinterpret_cast<const v4f *>(in + i);
+                            raw[r] = dc_stream_load(reinterpret_cast<const v4f *>(in + i));
                         }
                     }
                 } else {
