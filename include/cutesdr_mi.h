@@ -246,6 +246,12 @@ typedef struct csdr_demod_batch csdr_demod_batch;
 csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_n);
 void csdr_demod_batch_destroy(csdr_demod_batch *b);
 int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate);
+/* CDemodulator::SetDemod (dsp/demodulator.cpp:107-157) of one receiver.  Before commit(): recorded.  After commit():
+ * applied at once, like the reference between two ProcessData calls -- also a mode whose maximum bandwidth (hence
+ * decimator chain and output rate) differs from the present one: the receiver then continues in a plan group of its
+ * own with everything the reference keeps across SetDemod (oscillator, filter overlap and partly filled filter input,
+ * AGC, S-meter; new demodulator, decimator from zero histories); nothing else of the batch is disturbed.  The call
+ * synchronises the device. */
 int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const csdr_demod_info *info);
 int csdr_demod_batch_commit(csdr_demod_batch *b);
 int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq);
