@@ -150,12 +150,12 @@ int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long i
     a.sum = f->d_sum; a.pwr = f->d_pwr; a.ave = f->d_ave; a.counters = f->d_cnt; a.overload = f->d_over;
     a.channels = f->channels; a.nframes = nframes; a.ave_size = f->ave_size;
     // long calls on few channels: cut each channel's frames into groups so that ~1024 workgroups exist
-    a.nparts = 1; a.part = nullptr;
+    a.nparts = 1; a.part = nullptr; a.alpha = nullptr;
     {
         long np = (1024 + f->channels - 1) / f->channels;
         if (np > nframes / 8) np = nframes / 8;
         if (np > 1) {
-            const size_t need = (size_t)f->channels * np * f->size;
+            const size_t need = (size_t)f->channels * np * f->size + (size_t)f->channels * (np + 1);   // + the group weights
             if (need > f->part_cap) {
                 CSDR_HIP(hipStreamSynchronize((hipStream_t)stream));
                 if (f->d_part) (void)hipFree(f->d_part);
@@ -164,6 +164,7 @@ int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long i
                 f->part_cap = need;
             }
             a.nparts = (int)np; a.part = f->d_part;
+            a.alpha = f->d_part + (size_t)f->channels * np * f->size;
         }
     }
     a.kc = (float)f->kc; a.kb = f->kb;

@@ -55,18 +55,6 @@ namespace csdr {
 #define CSDR_STAMP(i) do { } while (0)
 #endif
 
-// 8-byte LDS access that stays a single ds_read_b64 / ds_write_b64 in program order
-__device__ __forceinline__ v2f lds_ld8(const v2f *p)
-{
-    return __builtin_bit_cast(v2f, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WAVEFRONT));
-}
-__device__ __forceinline__ void lds_st8(v2f *p, v2f v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
 // Priority ladder.  The two waves of a SIMD (w and w+4) run the same code between two workgroup barriers, and
 // the SIMD issues by priority, then age: left alone, the older wave takes every slot it can use, reaches the
 // barrier thousands of cycles early and waits while the younger one runs alone at a single wave's issue

@@ -414,6 +414,19 @@ __host__ __device__ __forceinline__ v2f opaque(v2f v)
     return v;
 }
 
+// 8-byte LDS access that stays a single ds_read_b64 / ds_write_b64 in program order
+__device__ __forceinline__ v2f lds_ld8(const v2f *p)
+{
+    return __builtin_bit_cast(v2f, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WAVEFRONT));
+}
+__device__ __forceinline__ void lds_st8(v2f *p, v2f v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+
 // LDS index padding: 2 elements (16 B) every 32 elements keeps float4 alignment and makes the
 // stride-32 / stride-1024 access patterns of the three passes bank-conflict free.
 __host__ __device__ __forceinline__ int lds_pad(int pos) { return pos + ((pos >> 5) << 1); }

@@ -15,6 +15,7 @@ struct SpectrumArgs {
     int channels, nframes, ave_size;
     int nparts;                         // frame groups per channel (1: the frames of a channel run in one workgroup)
     float *part;                        // [channels][nparts][N] partial sums, nparts > 1 only
+    float *alpha;                       // [channels][nparts] group weights + [channels] average count after the call (nparts > 1)
     float kc; double kb;
 };
 hipError_t spectrum_launch(int log2n, const SpectrumArgs &a, hipStream_t stream);

@@ -4,13 +4,17 @@
 // transform) together with the tail of CFft::CpxFFT (:562-589: |X|^2, running mean over AveSize
 // frames, log10, fft-shifted into display order), and CFft::FwdFFT / RevFFT (:416-426).
 // One workgroup of N/32 threads per channel walks that channel's frames in order (the running
-// mean makes frames sequential); the transform is the same three-pass decimation-in-frequency
-// FFT as the overlap-save kernel (fft_core.hpp), its digit-reversed output is scattered straight
+// mean makes frames sequential); the transform is a three-pass decimation-in-time FFT with the FMA
+// butterflies of the overlap-save kernel (fft_core.hpp), its output is scattered straight
 // into display order.  8 B in + 4 B out per bin.
+#define CSDR_FMA_BFLY 1          // FMA-form decimation-in-time butterflies (fft_core.hpp)
+#define CSDR_PLAIN_CONST_FMA 1
 #include "fft_core.hpp"
 #include "spectrum_kernels.h"
 
 namespace csdr {
+
+#define K3_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int LOG2N>
 struct SpecCfg {
@@ -20,53 +24,108 @@ struct SpecCfg {
 };
 
 // forward (positive exponent) transform of the block held as x[e*R0+n1] <-> sample 1024*n1+G*t+e;
-// on return x[r] is spectrum bin  (t>>5) + R0*((t&31) + 32*bitrev5(r))
+// on return x[k2] is spectrum bin  (t>>5) + R0*((t&31) + 32*k2).
+// Three decimation-in-time passes with FMA-form butterflies (fft_core.hpp, as in the round-2 overlap-save kernel):
+// the bit-reversed input order a DIT network wants costs nothing -- pass A's samples sit in registers, passes B and C
+// read their points from LDS in any order -- and its outputs come out in natural order.  The 1024-point
+// sub-transform k0 lives in ONE half-wave (threads 32 k0 .. 32 k0 + 31), so the exchange between passes B and C needs
+// no workgroup barrier, only the wave's own program order.
 template <int LOG2N>
 __device__ __forceinline__ void fft_fwd_passes(v2f (&x)[32], v2f *lds, const v2f *tw2, const v2f *w1)
 {
     using Cfg = SpecCfg<LOG2N>;
     constexpr int R0 = Cfg::R0, G = Cfg::G;
     const int t = threadIdx.x;
+    // ---- pass A: radix-R0 over the rows n1 of column G t + e, outer twiddle W_N^{(G t + e) k0}
 #pragma unroll
     for (int e = 0; e < G; e++) {
         v2f y[R0];
-#pragma unroll
-        for (int i = 0; i < R0; i++) y[i] = x[e * R0 + i];
-        dft_dif<R0, +1>(y);
+        static_for<0, R0>([&](auto N1) { y[bitrev<R0>(N1.value)] = x[e * R0 + N1.value]; });
+        dft_dit<R0, +1>(y);
         v2f pw[R0];
         twiddle_powers<R0>(opaque(w1[e]), pw);
-        static_for<0, R0>([&](auto Rr) {
-            constexpr int r = Rr.value, k0 = bitrev<R0>(r);
-            if constexpr (k0 != 0) y[r] = cmul(y[r], pw[k0]);
-        });
+        static_for<1, R0>([&](auto K0) { y[K0.value] = cmul(y[K0.value], pw[K0.value]); });
 #pragma unroll
         for (int i = 0; i < R0; i++) x[e * R0 + i] = y[i];
     }
-    __syncthreads();
-    static_for<0, R0>([&](auto Rr) {
-        constexpr int r = Rr.value, k0 = bitrev<R0>(r);
+    __syncthreads();                       // the previous transform's pass C has read its rows
+    static_for<0, R0>([&](auto K0) {
+        constexpr int k0 = K0.value;
         const int base = lds_pad(1024 * k0 + G * t);
 #pragma unroll
-        for (int e = 0; e < G; e++) lds[base + e] = x[e * R0 + r];      // 8-byte stores
+        for (int e = 0; e < G; e++) lds[base + e] = x[e * R0 + k0];      // 8-byte stores
     });
     __syncthreads();
+    // ---- pass B: radix-32 over the 32 points of column sn of sub-transform sb, twiddle W_1024^{sn k1}, in place.
+    // Cut into groups of four points like the passes of the overlap-save kernel (fft_core.hpp: head4 / tail): the
+    // points are fetched in the order the first stages need them, three groups ahead of the butterflies; a tail
+    // group's results are stored while the next group's butterflies issue; sched_barrier pins that order.
     const int sb = t >> 5, sn = t & 31;
-    const int base = lds_pad(1024 * sb) + sn;
-#pragma unroll
-    for (int n1 = 0; n1 < 32; n1++) x[n1] = lds[base + 34 * n1];
-    dft_dif<32, +1>(x);
-    static_for<1, 32>([&](auto Rr) {
-        constexpr int r = Rr.value, k1 = bitrev<32>(r);
-        x[r] = cmul(x[r], tw2[k1 * 32 + sn]);
-    });
-    static_for<0, 32>([&](auto Rr) {
-        constexpr int r = Rr.value, k1 = bitrev<32>(r);
-        lds[base + 34 * k1] = x[r];
-    });
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < 32; n++) x[n] = lds[34 * t + n];
-    dft_dif<32, +1>(x);
+    v2f *const col = lds + lds_pad(1024 * sb) + sn;          // point n1 at col[34 * n1]
+    const v2f *const twc = tw2 + sn;                         // twiddle k1 at twc[32 * k1]
+    {
+        auto fetch = [&](auto Gg) {
+            static_for<0, 4>([&](auto Q) {
+                constexpr int p = 4 * Gg.value + Q.value;
+                x[p] = lds_ld8(col + 34 * bitrev<32>(p));
+            });
+        };
+        static_for<0, 3>(fetch);
+        K3_SB();
+        static_for<0, 8>([&](auto Gg) {
+            if constexpr (Gg.value + 3 < 8) fetch(std::integral_constant<int, Gg.value + 3>{});
+            dit_head4<Gg.value, 32, +1>(x);
+            if constexpr ((Gg.value & 1) == 1) K3_SB();
+        });
+        dit_single<8, 32, +1>(x);
+        K3_SB();
+        v2f tw[2][4];
+        static_for<1, 4>([&](auto P) { tw[0][P.value] = lds_ld8(twc + 32 * (8 * P.value)); });
+        K3_SB();
+        static_for<0, 9>([&](auto Ii) {
+            constexpr int i = Ii.value;                      // tail group i finishes k1 = i, i+8, i+16, i+24
+            if constexpr (i < 7)
+                static_for<0, 4>([&](auto P) { tw[(i + 1) & 1][P.value] = lds_ld8(twc + 32 * (i + 1 + 8 * P.value)); });
+            if constexpr (i < 8) {
+                dit_tail<i, 32, +1>(x);
+                static_for<0, 4>([&](auto P) {
+                    constexpr int k1 = i + 8 * P.value;
+                    if constexpr (k1 != 0) x[k1] = cmul(x[k1], tw[i & 1][P.value]);
+                });
+            }
+            if constexpr (i > 0)
+                static_for<0, 4>([&](auto P) {
+                    constexpr int k1 = (i - 1) + 8 * P.value;
+                    lds_st8(col + 34 * k1, x[k1]);
+                });
+            K3_SB();
+        });
+    }
+    // B -> C stays inside the half-wave that owns sub-transform sb
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- pass C: radix-32 over the 32 consecutive points of row t, read as 16-byte pairs: rows q, q+4, q+8, q+12 of
+    // pairs hold the inputs of head groups bitrev3(2q) and bitrev3(2q+1)
+    {
+        const v2f *const rowp = lds + 34 * t;
+        static_for<0, 4>([&](auto Q) {
+            static_for<0, 4>([&](auto P) {
+                constexpr int j = Q.value + 4 * P.value;
+                const v4f v = *reinterpret_cast<const v4f *>(rowp + 2 * j);
+                x[bitrev<32>(2 * j)] = v2f{v.x, v.y};
+                x[bitrev<32>(2 * j + 1)] = v2f{v.z, v.w};
+            });
+        });
+        K3_SB();
+        static_for<0, 4>([&](auto Q) {
+            dit_head4<bitrev<8>(2 * Q.value), 32, +1>(x);
+            dit_head4<bitrev<8>(2 * Q.value + 1), 32, +1>(x);
+            K3_SB();
+        });
+        dit_single<8, 32, +1>(x);
+        static_for<0, 8>([&](auto Ii) { dit_tail<Ii.value, 32, +1>(x); });
+    }
 }
 
 #ifndef CSDR_SPEC_WAVES
@@ -103,7 +162,7 @@ void spectrum_kernel(SpectrumArgs a)
     const int k0 = tt >> 5, k1 = tt & 31;
     float sm[32];                             // the mean is sum / count: recomputed, not carried
     static_for<0, 32>([&](auto Rr) {
-        constexpr int r = Rr.value, k2 = bitrev<32>(r);
+        constexpr int r = Rr.value, k2 = r;
         const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);     // display order, fft.cpp:564-589
         sm[r] = a.nparts == 1 ? sum[j] : 0.f;
     });
@@ -134,8 +193,7 @@ void spectrum_kernel(SpectrumArgs a)
         const float prev_count = (float)ave_count;
         total++;                                                  // CpxFFT counters, fft.cpp:515-517
         if (ave_count < a.ave_size) ave_count++;
-        __syncthreads();
-        fft_fwd_passes<LOG2N>(x, lds, tw2, w1);
+        fft_fwd_passes<LOG2N>(x, lds, tw2, w1);        // (its own barrier keeps it behind the previous frame's pass C)
         static_for<0, 32>([&](auto Rr) {
             constexpr int r = Rr.value;
             const float p = x[r].x * x[r].x + x[r].y * x[r].y;
@@ -146,12 +204,12 @@ void spectrum_kernel(SpectrumArgs a)
     if (a.nparts > 1) {
         float *dst = a.part + ((long)ch * a.nparts + part) * N;
         static_for<0, 32>([&](auto Rr) {
-            constexpr int r = Rr.value, k2 = bitrev<32>(r);
+            constexpr int r = Rr.value, k2 = r;
             dst[((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1)] = sm[r];
         });
     } else if (a.nframes > 0) {
         static_for<0, 32>([&](auto Rr) {
-            constexpr int r = Rr.value, k2 = bitrev<32>(r);
+            constexpr int r = Rr.value, k2 = r;
             const int j = ((k0 + R0 * (k1 + 32 * k2)) + N / 2) & (N - 1);
             const float m = sm[r] / (float)ave_count;
             sum[j] = sm[r]; pwr[j] = m;
@@ -192,19 +250,19 @@ void fft_plain_kernel(const v2f *in, v2f *out, const v2f *tw1g, const v2f *tw2g,
     const int k0 = t >> 5, k1 = t & 31;
     __syncthreads();                       // in == out allowed: every input was read before pass 1
     static_for<0, 32>([&](auto Rr) {
-        constexpr int r = Rr.value, k2 = bitrev<32>(r);
+        constexpr int r = Rr.value, k2 = r;
         out[k0 + R0 * (k1 + 32 * k2)] = v2f{x[r].x, cj * x[r].y};
     });
 }
 
-// folds the frame groups of spectrum_kernel (nparts > 1) into the running sum, writes mean and bels,
-// advances the counters
-__global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
+// The weight alpha_g = product of the per-frame factors (1 - 1/count once the average is full) of every frame group,
+// and the average count after the call: the same for all bins of a channel, so one thread per channel walks the
+// frames ONCE (the combine kernel used to do this walk in each of its channels x N threads: 0.18 of K3's 1.6 ms).
+__global__ void spectrum_alpha_kernel(SpectrumArgs a)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
-    if (j >= n) return;
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.channels) return;
     int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
-    float sm = a.sum[(long)ch * n + j];
     for (int g = 0; g < a.nparts; g++) {
         const int f0 = (int)((long)a.nframes * g / a.nparts), f1 = (int)((long)a.nframes * (g + 1) / a.nparts);
         float al = 1.f;                                            // product of the group's alpha_f
@@ -214,9 +272,19 @@ __global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
             if (ave_count < a.ave_size) ave_count++;
             if (total > a.ave_size) al = al - al / prev;
         }
-        sm = al * sm + a.part[((long)ch * a.nparts + g) * n + j];
+        a.alpha[(long)ch * a.nparts + g] = al;
     }
-    const float m = sm / (float)ave_count;
+    a.alpha[(long)a.channels * a.nparts + ch] = (float)ave_count;
+}
+// folds the frame groups of spectrum_kernel (nparts > 1) into the running sum, writes mean and bels
+__global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (j >= n) return;
+    float sm = a.sum[(long)ch * n + j];
+    for (int g = 0; g < a.nparts; g++)
+        sm = a.alpha[(long)ch * a.nparts + g] * sm + a.part[((long)ch * a.nparts + g) * n + j];
+    const float m = sm / a.alpha[(long)a.channels * a.nparts + ch];
     a.sum[(long)ch * n + j] = sm; a.pwr[(long)ch * n + j] = m;
     a.ave[(long)ch * n + j] = (float)((double)log10f(m + a.kc) + a.kb);
 }
@@ -239,6 +307,7 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
     if (a.nparts > 1) {
+        hipLaunchKernelGGL(spectrum_alpha_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
         hipLaunchKernelGGL(spectrum_combine_kernel, dim3(Cfg::N / 256, a.channels), dim3(256), 0, s, a, (int)Cfg::N);
         hipLaunchKernelGGL(spectrum_count_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
     }
