@@ -9,7 +9,8 @@ post-timing parity spot check of the buffer that was just timed against the orac
 configurations, each with the oracle's fp64 CPU path timed beside it on one host core (rank 0, N = 1, a bounded
 sample): `chain_c4` (the per-GPU share of C4: 256 mixed AM/FM/USB receivers x 2^21 raw samples through the whole
 CDemodulator chain, pipelined AND strict mode), `spectrum_c1` (4096-pt CFft display spectrum), `chain_c2` (one
-receiver through the 16384-pt filter and the FM chain) and `chain_c5` (one 10 MSPS receiver to 48 kHz audio).
+receiver through the 16384-pt filter and the FM chain), `chain_c5` (one 10 MSPS receiver to 48 kHz audio), and the two
+input-rate kernels alone: `downconv_k2`, `blanker_k6`.
 Workload c4 makes the chain the primary metric instead.
 
 Multi-GPU: channels are independent, so every rank owns its own channels (contiguous channel ranges, weak
@@ -369,6 +370,49 @@ def spectrum_c1(torch, ca, ctx, x, with_cpu):
         v, n = cpu_rate(once, len(xs), 2.0)
         out["cpu_baseline"] = cpu_obj(v, n, "CFft::PutInDisplayFFT, 4096-pt frames of channel 0 (BASELINE configs[0])")
     del fb
+    return out
+
+
+def input_rate_kernels(torch, ca, ctx, x, with_cpu):
+    """The two input-rate kernels of the path alone on the resident buffer x [C, T, 2]: K2, the down-converter (one plan
+    group of all C receivers: 2 MSPS, FM bandwidth -> chain 11,11,15,19,31, 62.5 kS/s; 8 B in + 8 B out / 32 per
+    sample) and K6, the noise blanker (8 B in + 8 B out per sample), each with the oracle on one host core."""
+    C, T = x.shape[0], x.shape[1]
+    dev = x.device
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    dc = ca.DownConvertBatch(C, device=ctx.local)
+    dc.set_data_rate(C4_FS, 15000.0)
+    for c in range(C):
+        dc.set_frequency(-100e3 - 500.0 * c, channel=c)
+    y = torch.empty((C, T // 16, 2), device=dev, dtype=torch.float32)
+    ms = gpu_ms(torch, lambda: dc.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T // 16, st), 10, 20)
+    alg = C * T * (8.0 + 8.0 / 32.0)
+    out["downconv_k2"] = {"config": "K2 alone: %d receivers x 2^%d samples @2 MSPS, chain 11,11,15,19,31 -> 62.5 kS/s" % (C, T.bit_length() - 1),
+                          "kernel": "csdr::downconv_kernel<DcPlanT<11,11,15,19,31>>", "ms_per_launch": round(ms, 4),
+                          "raw_input_MSamples_per_s": round(C * T / ms / 1e3, 1), "algorithmic_GBps": round(alg / ms / 1e6, 1),
+                          "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
+    del y, dc
+    nb = ca.NoiseProcBatch(C, device=ctx.local)
+    nb.setup(True, 50.0, 2.0, C4_FS)
+    xb = torch.empty_like(x)
+    ms = gpu_ms(torch, lambda: nb.process_ptr(x.data_ptr(), T, T, xb.data_ptr(), T, st), 5, 10)
+    out["blanker_k6"] = {"config": "K6 alone: CNoiseProc::ProcessBlanker (threshold 50, width 2 us) on %d receivers x 2^%d samples" % (C, T.bit_length() - 1),
+                         "kernel": "csdr::noiseblank_kernel", "ms_per_launch": round(ms, 4),
+                         "MSamples_per_s": round(C * T / ms / 1e3, 1), "algorithmic_GBps": round(C * T * 16.0 / ms / 1e6, 1),
+                         "frac_of_hbm_peak": round(C * T * 16.0 / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
+    del xb, nb
+    if with_cpu:
+        from oracle import oracle as orc
+        xs = to_c128(x[1, :19968 * 16])
+        d = orc.CDownConvert()
+        d.SetDataRate(C4_FS, 15000.0); d.SetFrequency(-100.5e3)
+        v, n = cpu_rate(lambda: [d.ProcessData(xs[i:i + 19968]) for i in range(0, len(xs), 19968)], len(xs), 2.0)
+        out["downconv_k2"]["cpu_baseline"] = cpu_obj(v, n, "CDownConvert::ProcessData, 19968-sample calls, receiver 1's stream")
+        q = orc.CNoiseProc()
+        q.SetupBlanker(True, 50.0, 2.0, C4_FS)
+        v, n = cpu_rate(lambda: [q.ProcessBlanker(xs[i:i + 256]) for i in range(0, len(xs), 256)], len(xs), 2.0)
+        out["blanker_k6"]["cpu_baseline"] = cpu_obj(v, n, "CNoiseProc::ProcessBlanker, 256-sample calls (one datagram each)")
     return out
 
 
@@ -741,6 +785,7 @@ def run_rank(args):
                 extra["chain_c4"] = s
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
                 extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu)
+                extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu))
             del c4
             torch.cuda.empty_cache()
             if ctx.world == 1:
