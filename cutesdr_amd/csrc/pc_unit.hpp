@@ -3,17 +3,26 @@
 #pragma once
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include "capi_common.hpp"
 #include "postchain.h"
 #include "pc_host.hpp"
 
 namespace csdr {
 
+// CSDR_FM_DEFER=0 keeps the squelch inside the walk (A/B runs, diagnostics)
+inline bool defer_fm_squelch()
+{
+    static const bool on = !(getenv("CSDR_FM_DEFER") && atoi(getenv("CSDR_FM_DEFER")) == 0);
+    return on;
+}
+
 struct PcUnit {
     int device = 0, channels = 0;
     PcChannel *d_chan = nullptr;
     float *d_dly = nullptr, *d_mag = nullptr, *d_scratch = nullptr;
     long scratch_cap = 0;
+    double *d_sqbuf = nullptr; long sqbuf_cap = 0;       // per-burst records of the deferred FM squelch (fm_squelch_launch)
     bool no_output = false;
     std::vector<PcChannel> h;            // host mirror (authoritative for parameters)
     std::vector<HostAgc> hagc;
@@ -25,6 +34,7 @@ struct PcUnit {
         if (d_dly) (void)hipFree(d_dly);
         if (d_mag) (void)hipFree(d_mag);
         if (d_scratch) (void)hipFree(d_scratch);
+        if (d_sqbuf) (void)hipFree(d_sqbuf);
         if (d_sm) (void)hipFree(d_sm);
     }
     int init(int dev, int nch)
@@ -139,7 +149,27 @@ struct PcUnit {
         a.out = no_output ? nullptr : d_out; a.out_stride = out_stride; a.out_rows = d_out_rows;
         a.scratch = d_scratch; a.scratch_stride = scratch_cap;
         a.channels = channels; a.nbursts = nbursts; a.burst = burst; a.flags = flags;
+        a.sqbuf = nullptr;
+        // FM receivers in a call of several bursts (the chain): the squelch half of CFmDemod -- high-pass, average,
+        // decision, low-pass -- leaves the sequential walk and follows as burst-parallel launches; same words out
+        bool defer = (flags & PC_DO_DEMOD) && nbursts >= 4 && burst >= PC_FIR_MAX && burst <= 16384 && a.out && defer_fm_squelch();
+        if (defer) {
+            defer = false;
+            for (int c = 0; c < channels; c++) if (h[c].mode == PC_MODE_FM) { defer = true; break; }
+        }
+        if (defer) {
+            const long need = (long)channels * nbursts * PC_SQ_REC;
+            if (need > sqbuf_cap) {
+                CSDR_HIP(hipStreamSynchronize(stream));              // an earlier launch may still be using the old buffer
+                if (d_sqbuf) (void)hipFree(d_sqbuf);
+                d_sqbuf = nullptr; sqbuf_cap = 0;
+                CSDR_HIP(hipMalloc((void **)&d_sqbuf, sizeof(double) * need));
+                sqbuf_cap = need;
+            }
+            a.flags |= PC_FM_DEFER; a.sqbuf = d_sqbuf;
+        }
         CSDR_HIP(postchain_launch(a, stream));
+        if (defer) CSDR_HIP(fm_squelch_launch(a, stream));
         return CSDR_OK;
     }
 };

@@ -80,7 +80,16 @@ constexpr int BQ_TAB = (LCMAX + 1) * 4 + LCMAX * 2;   // biquad chunk tables: M^
 constexpr double kInvTwoPiD = 1.0 / (2.0 * 3.14159265358979323846);
 constexpr float kNegBig = -1.0e30f;
 
+// what a workgroup's scans and broadcasts exchange through LDS (Wg<NW> holds a pointer to it)
+struct PcSync {
+    double xch[2][8][8];                 // per-wave totals of a workgroup scan; two banks used in turn, so that a scan
+                                         // needs ONE workgroup barrier (the next scan's writes go to the other bank)
+    double bc[4];                        // broadcast slot (thread 0 -> workgroup)
+    int flag;                            // workgroup-wide "any"
+};
+
 struct PcLds {
+    PcSync sy;
     float2 dl[PH + PT];                  // [last dly_n inputs | tile]: delay line, then the AGC output in place
     float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile]
     float pk[PT + 16];                   // sliding peak, then the log gain argument
@@ -93,10 +102,16 @@ struct PcLds {
     double pw_sm[LCMAX + 1], pw_dc[LCMAX + 1], pw_sq[LCMAX + 1], pw_fd[LCMAX + 1];   // powers of the averager coefficients
     double bq[BQ_TAB];                   // biquad chunk tables
     double pm[(LCMAX + 1) * 4];          // PLL transition-matrix powers
-    double xch[2][8][8];                 // per-wave totals of a workgroup scan; two banks used in turn, so that a scan
-                                         // needs ONE workgroup barrier (the next scan's writes go to the other bank)
-    double bc[4];                        // broadcast slot (thread 0 -> workgroup)
-    int flag;                            // workgroup-wide "any"
+};
+
+// the squelch kernels' image (fm_squelch_*): a quarter of PcLds, so that eight of their workgroups share a CU
+struct SqLds {
+    PcSync sy;
+    float w0[PT + PC_FIR_MAX + 17];      // [FIR history | tile] audio
+    float h0[PC_FIR_MAX + 17];           // high-pass taps, reversed and zero padded
+    float w2[PT + 16];                   // |hp| / audio being low-passed
+    double pw_sq[LCMAX + 1];
+    double bq[BQ_TAB];
 };
 
 __device__ __forceinline__ double wrap_turn(double a) { return a - rint(a); }    // [-0.5, 0.5]
@@ -122,7 +137,7 @@ template <int NW>
 struct Wg {
     static constexpr int NT = 64 * NW, LC = PT / NT;
     int t, lane, w;
-    PcLds *S;
+    PcSync *S;
     mutable int bank = 0;                // exchange bank of the next workgroup scan (uniform)
     __device__ __forceinline__ double (*xbank() const)[8] { double (*b)[8] = S->xch[bank]; bank ^= 1; return b; }
     __device__ __forceinline__ void sync() const
@@ -897,7 +912,7 @@ void postchain_kernel(PcArgs a)
     // streaming kernel next to nothing and keeps the walk at the speed it has alone.
     if (a.out_rows && a.out_rows[ch] < 0) return;      // muted row (its receiver has moved on): uniform per workgroup
     __builtin_amdgcn_s_setprio(3);
-    const G g{t, t & 63, t >> 6, &S};
+    const G g{t, t & 63, t >> 6, &S.sy};
     PcChannel &C = a.chan[ch];
     float *g_dly = a.agc_dly + (long)ch * PC_AGC_RING * 2;      // linear: last dly_n inputs, oldest first
     float *g_mag = a.agc_mag + (long)ch * PC_AGC_RING;          // linear: last win_n-1 magnitudes
@@ -909,6 +924,8 @@ void postchain_kernel(PcArgs a)
     const int mode = (a.flags & PC_DO_DEMOD) ? C.mode : PC_MODE_NONE;
     const bool do_sm = a.flags & PC_DO_SMETER, do_agc = a.flags & PC_DO_AGC, agc_real = a.flags & PC_AGC_REAL;
     const bool cpx_out = stereo || mode == PC_MODE_NONE;
+    // FM with the squelch deferred: this walk ends at the raw audio (fm_squelch_launch does the rest, burst-parallel)
+    const bool defer = (a.flags & PC_FM_DEFER) && mode == PC_MODE_FM && a.burst <= 16384;
 
     // scalar state, identical on every thread
     PcSMeter sm = C.sm;
@@ -1163,9 +1180,9 @@ void postchain_kernel(PcArgs a)
                     PC_TICK(9);
                     // raw audio to the output row; squelch is decided at the end of the burst (a burst of one tile
                     // keeps it in LDS instead: the low-pass at the end of the burst reads it from there)
-                    if (a.burst > PT)
+                    if (a.burst > PT || defer)
                         for (int i = t; i < n; i += NT) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
-                    if (a.burst <= 16384) {                               // MAX_SQBUF_SIZE
+                    if (a.burst <= 16384 && !defer) {                     // MAX_SQBUF_SIZE
                         float acc[LC];
                         fir_blk<NW>(S.h0, nt, S.w0, t, acc);
 #pragma unroll
@@ -1182,8 +1199,10 @@ void postchain_kernel(PcArgs a)
                     }
                     g.sync();
                     PC_TICK(10);
-                    slide(g, S.w0, nt - 1, n);
-                    g.sync();
+                    if (!defer) {
+                        slide(g, S.w0, nt - 1, n);
+                        g.sync();
+                    }
                     PC_TICK(11);
                 } else {                                                  // SAM, samdemod.cpp:78-158
                     const PcSam &M = C.sam;
@@ -1248,7 +1267,7 @@ void postchain_kernel(PcArgs a)
             }
         }
         // ---------------- end of burst: FM squelch decision (fmdemod.cpp:128-151) ----------------
-        if (mode == PC_MODE_FM && a.burst <= 16384) {
+        if (mode == PC_MODE_FM && a.burst <= 16384 && !defer) {
             const PcFm &F = C.fm;
             if (0 == F.sq_thresh) fm_squelched = 1;
             else if (fm_squelched) { if (fm_sq < (F.sq_thresh - 100.0)) fm_squelched = 0; }
@@ -1291,7 +1310,7 @@ void postchain_kernel(PcArgs a)
         for (int i = t; i < D; i += NT) { g_dly[2 * i] = S.dl[i].x; g_dly[2 * i + 1] = S.dl[i].y; }
         for (int i = t; i < W1; i += NT) g_mag[i] = S.mg[i];
     }
-    if (fir) {
+    if (fir && !defer) {
         PcFir *fw = const_cast<PcFir *>(fir);
         for (int i = t; i < nt - 1; i += NT) {
             if (mode == PC_MODE_FM || (mode == PC_MODE_AM && !stereo)) fw->zreal[i] = S.w0[i];
@@ -1306,10 +1325,245 @@ void postchain_kernel(PcArgs a)
         if (mode == PC_MODE_AM) C.am.z1 = am_z1;
         if (mode == PC_MODE_SAM) { C.sam.z1 = sam_z1; C.sam.y1 = sam_y1; C.sam.phase = sam_ph; C.sam.freq = sam_fr; }
         if (mode == PC_MODE_FM) {
-            C.fm.phase = fm_ph; C.fm.freq = fm_fr; C.fm.err_dc = fm_dc; C.fm.sq_ave = fm_sq; C.fm.squelched = fm_squelched;
-            C.fm.lp = lp;
+            C.fm.phase = fm_ph; C.fm.freq = fm_fr; C.fm.err_dc = fm_dc;
+            if (!defer) { C.fm.sq_ave = fm_sq; C.fm.squelched = fm_squelched; C.fm.lp = lp; }   // else: fm_squelch_decide_kernel's
         }
     }
+}
+
+// =====================================================================================================
+// The squelch half of CFmDemod (fmdemod.cpp:113-152), deferred out of the walk (PC_FM_DEFER).  None of it feeds
+// back into the loop: the high-pass CFir over the audio, the average of its magnitude, the once-per-burst hysteresis
+// decision and the CIir low-pass of the bursts that stay open are post-processing of the raw audio the walk leaves in
+// the output rows -- a fifth of an FM tile's time in the sequential walk, a few microseconds as burst-parallel work:
+//   1. fm_squelch_maps_kernel, one workgroup per (channel, burst): the burst's high-pass + |.| + average and its
+//      low-pass, both from a ZERO start state, reduced to their affine maps (average: s -> A s + B; filter state:
+//      s -> M s + v) -- the same scans the walk used, so the same words come out;
+//   2. fm_squelch_decide_kernel, one workgroup per channel: the maps chained through the bursts in order (64 small
+//      steps), the decision of every burst, the filter state each open burst starts from; the channel's state;
+//   3. fm_squelch_apply_kernel, one workgroup per (channel, burst): zeros, or the low-pass from that start state.
+// =====================================================================================================
+template <int NW>
+__device__ __forceinline__ void sq_lp_maps(const Wg<NW> &g, const float *sq, const float *x, int n, double a, double gn,
+                                           const double *apw, const PcIir &f, const double *tab,
+                                           double &At, double &Bt, double (&mt)[4], double (&vt)[2])
+{
+    constexpr int LC = Wg<NW>::LC;
+    const int base = LC * g.t;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    double p = 0.0, w1 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        const float sv = j < cnt ? sq[base + j] : 0.f;
+        p = j < cnt ? a * p + gn * (double)sv : p;
+        const double xv = j < cnt ? (double)x[base + j] : 0.0;
+        const double w0 = xv - f.a1 * w1 - f.a2 * w2;
+        if (j < cnt) { w2 = w1; w1 = w0; }
+    }
+    double A = apw[cnt], B = p;
+    double m[4] = {tab[4 * cnt], tab[4 * cnt + 1], tab[4 * cnt + 2], tab[4 * cnt + 3]}, v[2] = {w1, w2};
+    g.scan1_2(A, B, At, Bt, m, v, mt, vt);
+}
+
+
+__global__ __launch_bounds__(256)
+void fm_squelch_maps_kernel(PcArgs a)
+{
+    using G = Wg<4>;
+    constexpr int NT = G::NT, LC = G::LC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+    SqLds &S = *reinterpret_cast<SqLds *>(pc_smem);
+    const int ngrp = (a.nbursts + a.sq_bpw - 1) / a.sq_bpw;
+    const int t = threadIdx.x, ch = blockIdx.x / ngrp, b0 = (blockIdx.x % ngrp) * a.sq_bpw;
+    const int b1 = b0 + a.sq_bpw < a.nbursts ? b0 + a.sq_bpw : a.nbursts;
+    if (a.out_rows && a.out_rows[ch] < 0) return;
+    const PcChannel &C = a.chan[ch];
+    if (C.mode != PC_MODE_FM) return;                    // uniform per workgroup
+    const G g{t, t & 63, t >> 6, &S.sy};
+    const bool stereo = a.flags & PC_STEREO;
+    const long orow = (long)(a.out_rows ? a.out_rows[ch] : ch) * a.out_stride;
+    const float *outm = a.out + orow;
+    const float2 *outs = reinterpret_cast<const float2 *>(a.out) + orow;
+    auto raw = [&](long i) -> float { return stereo ? outs[i].x : outm[i]; };
+    const PcFir &fir = C.fm.hp;
+    const int nt = fir.ntaps;
+    for (int i = t; i < PC_FIR_MAX + 17; i += NT) {
+        const int k = nt - 1 - (i - 4);                  // reversed, four zeros in front, zeros behind (as in the walk)
+        S.h0[i] = (k >= 0 && k < nt) ? fir.coef[k] : 0.f;
+    }
+    for (int i = t; i < PT + PC_FIR_MAX + 17; i += NT) S.w0[i] = 0.f;
+    pow_table(S.pw_sq, 1.0 - C.fm.sq_alpha, t);
+    PcIir lp = C.fm.lp;
+    biquad_table(S.bq, lp, t);
+    g.sync();
+    // the high-pass delay line at the start of this group's first burst: the audio in front of it (still raw: the apply
+    // kernel runs after every maps workgroup has finished), the saved delay line in front of the call
+    {
+        const long g0 = (long)b0 * a.burst;
+        for (int i = t; i < nt - 1; i += NT) {
+            const long k = g0 - (nt - 1) + i;
+            S.w0[i] = k >= 0 ? raw(k) : fir.zreal[i];    // (k < 0 only for burst 0: burst >= PC_FIR_MAX > ntaps - 1)
+        }
+    }
+    float *au = S.w0 + (nt - 1);
+    // the audio of the next tile is fetched while the current one goes through its filter and scan
+    float nx[LC];
+    const long first = (long)b0 * a.burst, end = (long)b1 * a.burst;
+    auto fetch = [&](long p) {
+#pragma unroll
+        for (int j = 0; j < LC; j++) { const long i = p + t + NT * j; nx[j] = i < end ? raw(i) : 0.f; }
+    };
+    fetch(first);
+    for (int b = b0; b < b1; b++) {
+        const long g0 = (long)b * a.burst;
+        double A_tot = 1.0, B_tot = 0.0, M_tot[4] = {1.0, 0.0, 0.0, 1.0}, v_tot[2] = {0.0, 0.0};
+        for (int t0 = 0; t0 < a.burst; t0 += PT) {
+            const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
+#pragma unroll
+            for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < n) au[i] = nx[j]; }
+            fetch(g0 + t0 + n);                          // bursts are contiguous: the next tile follows
+            g.sync();
+            float acc[LC];
+            fir_blk<4>(S.h0, nt, S.w0, t, acc);
+#pragma unroll
+            for (int j = 0; j < LC; j++) S.w2[pc_out_index<4>(t, j) & (PT - 1)] = fabsf(acc[j]);
+            g.sync();
+            double At, Bt, mt[4], vt[2];
+            sq_lp_maps(g, S.w2, au, n, 1.0 - C.fm.sq_alpha, C.fm.sq_alpha, S.pw_sq, lp, S.bq, At, Bt, mt, vt);
+            // this tile's maps behind what the burst has so far
+            B_tot = At * B_tot + Bt; A_tot = At * A_tot;
+            const double n0 = mt[0] * M_tot[0] + mt[1] * M_tot[2], n1 = mt[0] * M_tot[1] + mt[1] * M_tot[3];
+            const double n2 = mt[2] * M_tot[0] + mt[3] * M_tot[2], n3 = mt[2] * M_tot[1] + mt[3] * M_tot[3];
+            const double u0 = mt[0] * v_tot[0] + mt[1] * v_tot[1] + vt[0], u1 = mt[2] * v_tot[0] + mt[3] * v_tot[1] + vt[1];
+            M_tot[0] = n0; M_tot[1] = n1; M_tot[2] = n2; M_tot[3] = n3; v_tot[0] = u0; v_tot[1] = u1;
+            g.sync();
+            slide(g, S.w0, nt - 1, n);                   // the next tile's / burst's delay line
+            g.sync();
+        }
+        if (t == 0) {
+            double *r = a.sqbuf + ((long)ch * a.nbursts + b) * PC_SQ_REC;
+            r[0] = A_tot; r[1] = B_tot; r[2] = M_tot[0]; r[3] = M_tot[1]; r[4] = M_tot[2]; r[5] = M_tot[3]; r[6] = v_tot[0]; r[7] = v_tot[1];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64)
+void fm_squelch_decide_kernel(PcArgs a)
+{
+    const int t = threadIdx.x, ch = blockIdx.x;
+    if (a.out_rows && a.out_rows[ch] < 0) return;
+    PcChannel &C = a.chan[ch];
+    if (C.mode != PC_MODE_FM) return;
+    const bool stereo = a.flags & PC_STEREO;
+    const long orow = (long)(a.out_rows ? a.out_rows[ch] : ch) * a.out_stride;
+    const float *outm = a.out + orow;
+    const float2 *outs = reinterpret_cast<const float2 *>(a.out) + orow;
+    PcFm &F = C.fm;
+    // the high-pass delay line after the call: the last ntaps-1 raw audio samples (the apply kernel has not run yet)
+    const int nt = F.hp.ntaps;
+    const long total = (long)a.nbursts * a.burst;
+    float keep = 0.f;
+    if (t < nt - 1) {
+        const long k = total - (nt - 1) + t;
+        keep = k >= 0 ? (stereo ? outs[k].x : outm[k]) : F.hp.zreal[t + (int)total];
+    }
+    __syncthreads();
+    if (t < nt - 1) F.hp.zreal[t] = keep;
+    // the bursts' maps come in 64 at a time, one record per thread (a walk over global memory would pay a dependent
+    // miss per burst); thread 0 chains them
+    __shared__ double rec[64][8];
+    __shared__ double res[64][3];
+    double sq = F.sq_ave, w1 = F.lp.w1a, w2 = F.lp.w2a;
+    int sqd = F.squelched;
+    for (int c0 = 0; c0 < a.nbursts; c0 += 64) {
+        const int cn = a.nbursts - c0 < 64 ? a.nbursts - c0 : 64;
+        __syncthreads();
+        if (t < cn) {
+            const double *r = a.sqbuf + ((long)ch * a.nbursts + c0 + t) * PC_SQ_REC;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rec[t][k] = r[k];
+        }
+        __syncthreads();
+        if (t == 0) {
+            for (int b = 0; b < cn; b++) {
+                const double *r = rec[b];
+                sq = r[0] * sq + r[1];
+                if (0 == F.sq_thresh) sqd = 1;                                  // fmdemod.cpp:128-151
+                else if (sqd) { if (sq < (F.sq_thresh - 100.0)) sqd = 0; }
+                else { if (sq >= (F.sq_thresh + 100.0)) sqd = 1; }
+                res[b][0] = (double)sqd; res[b][1] = w1; res[b][2] = w2;
+                if (!sqd) {                                                     // the low-pass runs on open bursts only
+                    const double nw1 = r[2] * w1 + r[3] * w2 + r[6], nw2 = r[4] * w1 + r[5] * w2 + r[7];
+                    w1 = nw1; w2 = nw2;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < cn) {
+            double *r = a.sqbuf + ((long)ch * a.nbursts + c0 + t) * PC_SQ_REC;
+            r[8] = res[t][0]; r[9] = res[t][1]; r[10] = res[t][2];
+        }
+    }
+    if (t == 0) { F.sq_ave = sq; F.squelched = sqd; F.lp.w1a = w1; F.lp.w2a = w2; }
+}
+
+__global__ __launch_bounds__(256)
+void fm_squelch_apply_kernel(PcArgs a)
+{
+    using G = Wg<4>;
+    constexpr int NT = G::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+    SqLds &S = *reinterpret_cast<SqLds *>(pc_smem);
+    const int ngrp = (a.nbursts + a.sq_bpw - 1) / a.sq_bpw;
+    const int t = threadIdx.x, ch = blockIdx.x / ngrp, b0 = (blockIdx.x % ngrp) * a.sq_bpw;
+    const int b1 = b0 + a.sq_bpw < a.nbursts ? b0 + a.sq_bpw : a.nbursts;
+    if (a.out_rows && a.out_rows[ch] < 0) return;
+    const PcChannel &C = a.chan[ch];
+    if (C.mode != PC_MODE_FM) return;
+    const G g{t, t & 63, t >> 6, &S.sy};
+    const bool stereo = a.flags & PC_STEREO;
+    const long orow = (long)(a.out_rows ? a.out_rows[ch] : ch) * a.out_stride;
+    float *outm = a.out + orow;
+    float2 *outs = reinterpret_cast<float2 *>(a.out) + orow;
+    PcIir lp = C.fm.lp;
+    biquad_table(S.bq, lp, t);
+    g.sync();
+    for (int b = b0; b < b1; b++) {
+        const double *r = a.sqbuf + ((long)ch * a.nbursts + b) * PC_SQ_REC;
+        const long g0 = (long)b * a.burst;
+        if (r[8] != 0.0) {                               // squelched: zeros (fmdemod.cpp:139-143); uniform per workgroup
+            for (int i = t; i < a.burst; i += NT) { if (stereo) outs[g0 + i] = make_float2(0.f, 0.f); else outm[g0 + i] = 0.f; }
+            continue;
+        }
+        lp.w1a = r[9]; lp.w2a = r[10];
+        for (int t0 = 0; t0 < a.burst; t0 += PT) {
+            const int n = (a.burst - t0) < PT ? (a.burst - t0) : PT;
+            for (int i = t; i < n; i += NT) S.w2[i] = stereo ? outs[g0 + t0 + i].x : outm[g0 + t0 + i];
+            g.sync();
+            biquad_scan(g, S.w2, n, lp, S.bq);
+            g.sync();
+            for (int i = t; i < n; i += NT) { const float y = S.w2[i]; if (stereo) outs[g0 + t0 + i] = make_float2(y, y); else outm[g0 + t0 + i] = y; }
+            g.sync();
+        }
+    }
+}
+
+hipError_t fm_squelch_launch(const PcArgs &a, hipStream_t stream)
+{
+    static_assert(sizeof(SqLds) <= 20 * 1024, "eight squelch workgroups per CU");
+    // bursts per workgroup: as few as still give every workgroup a slot in ONE round (four 256-thread workgroups per
+    // CU at these kernels' 105-122 registers), so that taps, tables and zeroing are paid once per slot
+    PcArgs b = a;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long slots = 4L * (cus > 0 ? cus : 256);
+    b.sq_bpw = (int)(((long)a.channels * a.nbursts + slots - 1) / slots);
+    if (b.sq_bpw < 1) b.sq_bpw = 1;
+    const int ngrp = (a.nbursts + b.sq_bpw - 1) / b.sq_bpw;
+    hipLaunchKernelGGL(fm_squelch_maps_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(SqLds), stream, b);
+    hipLaunchKernelGGL(fm_squelch_decide_kernel, dim3(a.channels), dim3(64), 0, stream, b);
+    hipLaunchKernelGGL(fm_squelch_apply_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(SqLds), stream, b);
+    return hipGetLastError();
 }
 
 // stand-alone CFir / CIir objects (one lane each): op 0 FIR real, 1 FIR complex, 2 IIR real, 3 IIR complex

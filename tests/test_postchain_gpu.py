@@ -442,3 +442,47 @@ def test_batch_above_1024_channels_takes_the_one_wave_kernel(oracle):
             assert len(got[c]) == len(want)
             check_chain_bursts(burst_errors(got[c], want), "FM", call * (len(want) // 1024), (c, call))
     assert b.smeter_ave(C - 1) == pytest.approx(r.GetSMeterAve(), abs=0.02)
+
+
+def _fm_batch_words(path, fastfir_n):
+    """FM receivers with open, closed and toggling squelch through csdr_demod_batch, three calls; audio words -> path"""
+    import cutesdr_amd as ca
+    fs, C = 2e6, 6
+    n = 19968 * (16 if fastfir_n == 2048 else 72)
+    b = ca.DemodBatch(C, fastfir_n); b.set_input_rate(fs)
+    for c in range(C):
+        b.set_demod(c, 2, info(ca, SquelchValue=[0, 40, 99, 70, 0, 55][c]))
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -100e3 - 800.0 * c)
+    rng = np.random.default_rng(77)
+    x = np.stack([make_input("FM", 3 * n, fs) * np.exp(2j * np.pi * 800.0 * c * np.arange(3 * n) / fs) for c in range(C)])
+    x[4] = 300.0 * (rng.standard_normal(3 * n) + 1j * rng.standard_normal(3 * n))      # no carrier at all
+    x[5, n:2 * n] = 3000.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))    # the carrier drowns in noise, then returns
+    outs = []
+    for k in range(3):
+        outs.append(b.process(x[:, k * n:(k + 1) * n]))
+    words = np.concatenate([np.concatenate([o[c] for o in outs]) for c in range(C)])
+    np.save(path, words)
+    return [sum(len(o[c]) for o in outs) for c in range(C)], [np.concatenate([o[c] for o in outs]) for c in range(C)]
+
+
+@pytest.mark.parametrize("fastfir_n", [2048, 16384])
+def test_fm_squelch_deferred_out_of_the_walk_gives_the_same_words(tmp_path, fastfir_n):
+    """The squelch half of CFmDemod (high-pass, average, once-per-burst decision, low-pass: fmdemod.cpp:113-152) runs
+    as burst-parallel launches behind the post-chain walk (PC_FM_DEFER) when a call holds several bursts.  Same scans,
+    same arithmetic: every audio word equals what the walk itself produces (CSDR_FM_DEFER=0, in a child process: the
+    switch is read once) -- receivers whose squelch is open, shut, and opening / closing mid-stream, one-tile bursts
+    (2048-point filter) and eight-tile bursts (16384-point filter)."""
+    import subprocess, sys, os
+    lens, got = _fm_batch_words(str(tmp_path / "deferred.npy"), fastfir_n)
+    assert min(lens) > 4 * 1024
+    assert np.abs(got[0]).max() > 100.0 and not got[2].any()          # open squelch / threshold 0: forced mute (:129-132)
+    opened = [bool(got[5][j:j + 1024].any()) for j in range(0, len(got[5]) - 1023, 1024)]
+    assert any(opened) and not all(opened)                             # the fading receiver's squelch moves
+    code = ("import sys; sys.path.insert(0, %r); import test_postchain_gpu as T; T._fm_batch_words(%r, %d)"
+            % (os.path.dirname(__file__), str(tmp_path / "walk.npy"), fastfir_n))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSDR_FM_DEFER="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, w = np.load(tmp_path / "deferred.npy"), np.load(tmp_path / "walk.npy")
+    assert a.shape == w.shape and np.array_equal(a.view(np.uint32), w.view(np.uint32))
