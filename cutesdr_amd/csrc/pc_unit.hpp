@@ -17,12 +17,27 @@ inline bool defer_fm_squelch()
     return on;
 }
 
+// CSDR_AGC_PRE=0 keeps the AGC's magnitudes and sliding maximum inside the walk (A/B runs, diagnostics)
+inline bool agc_prepass()
+{
+    static const bool on = !(getenv("CSDR_AGC_PRE") && atoi(getenv("CSDR_AGC_PRE")) == 0);
+    return on;
+}
+
+// CSDR_PLL_OVERLAP=0: an FM tile whose PLL is not locked is walked by one thread, as before pll_overlap (A/B, tests)
+inline bool pll_overlap_on()
+{
+    static const bool on = !(getenv("CSDR_PLL_OVERLAP") && atoi(getenv("CSDR_PLL_OVERLAP")) == 0);
+    return on;
+}
+
 struct PcUnit {
     int device = 0, channels = 0;
     PcChannel *d_chan = nullptr;
     float *d_dly = nullptr, *d_mag = nullptr, *d_scratch = nullptr;
     long scratch_cap = 0;
     double *d_sqbuf = nullptr; long sqbuf_cap = 0;       // per-burst records of the deferred FM squelch (fm_squelch_launch)
+    float *d_pkbuf = nullptr, *d_magtail = nullptr; long pkbuf_cap = 0;   // AGC peaks of a call (agc_peaks_launch)
     bool no_output = false;
     std::vector<PcChannel> h;            // host mirror (authoritative for parameters)
     std::vector<HostAgc> hagc;
@@ -35,6 +50,8 @@ struct PcUnit {
         if (d_mag) (void)hipFree(d_mag);
         if (d_scratch) (void)hipFree(d_scratch);
         if (d_sqbuf) (void)hipFree(d_sqbuf);
+        if (d_pkbuf) (void)hipFree(d_pkbuf);
+        if (d_magtail) (void)hipFree(d_magtail);
         if (d_sm) (void)hipFree(d_sm);
     }
     int init(int dev, int nch)
@@ -167,6 +184,27 @@ struct PcUnit {
                 sqbuf_cap = need;
             }
             a.flags |= PC_FM_DEFER; a.sqbuf = d_sqbuf;
+        }
+        if (!pll_overlap_on()) a.flags |= PC_PLL_SEQ;
+        // the AGC's log magnitudes and sliding maximum of the whole call: burst-parallel, in front of the walk
+        a.pkbuf = nullptr; a.magtail = nullptr;
+        bool pre = (flags & PC_DO_AGC) && !(flags & PC_AGC_REAL) && nbursts >= 4 && agc_prepass();
+        if (pre) {
+            pre = false;
+            for (int c = 0; c < channels; c++) if (h[c].agc.on) { pre = true; break; }
+        }
+        if (pre) {
+            const long need = (long)channels * nbursts * burst;
+            if (need > pkbuf_cap) {
+                CSDR_HIP(hipStreamSynchronize(stream));
+                if (d_pkbuf) (void)hipFree(d_pkbuf);
+                d_pkbuf = nullptr; pkbuf_cap = 0;
+                CSDR_HIP(hipMalloc((void **)&d_pkbuf, sizeof(float) * need));
+                pkbuf_cap = need;
+            }
+            if (!d_magtail) CSDR_HIP(hipMalloc((void **)&d_magtail, sizeof(float) * PC_AGC_RING * channels));
+            a.flags |= PC_AGC_PRE; a.pkbuf = d_pkbuf; a.magtail = d_magtail;
+            CSDR_HIP(agc_peaks_launch(a, stream));
         }
         CSDR_HIP(postchain_launch(a, stream));
         if (defer) CSDR_HIP(fm_squelch_launch(a, stream));

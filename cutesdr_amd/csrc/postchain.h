@@ -65,8 +65,11 @@ struct PcChannel {                      // everything CDemodulator owns after th
 
 // stage selection of one launch
 enum { PC_DO_SMETER = 1, PC_DO_AGC = 2, PC_DO_DEMOD = 4, PC_STEREO = 8, PC_AGC_REAL = 16,
-       PC_FM_DEFER = 32 };              // FM: the walk leaves the raw audio in the output rows; squelch filter, decision
+       PC_FM_DEFER = 32,                // FM: the walk leaves the raw audio in the output rows; squelch filter, decision
                                         // and audio low-pass follow as their own burst-parallel launches (fm_squelch_launch)
+       PC_AGC_PRE = 64,               // AGC: the log magnitudes and their sliding maximum (agc.cpp:196-231) come from a
+                                        // burst-parallel launch in front of the walk (agc_peaks_launch), in pkbuf
+       PC_PLL_SEQ = 128 };              // FM: an unlocked tile is walked by one thread (no overlapped walks; A/B, tests)
 
 struct PcArgs {
     PcChannel *chan;                    // [channels]
@@ -80,12 +83,17 @@ struct PcArgs {
     int flags;
     double *sqbuf;                      // PC_FM_DEFER: [channels][nbursts][PC_SQ_REC] doubles of scratch
     int sq_bpw;                         // PC_FM_DEFER: bursts per workgroup of the maps / apply kernels
+    float *pkbuf;                       // PC_AGC_PRE: [channels][nbursts * burst] sliding peak of the log magnitudes
+    float *magtail;                     // PC_AGC_PRE: [channels][PC_AGC_RING] the call's last win_n-1 log magnitudes
+    int pre_bpw;                        // PC_AGC_PRE: bursts per workgroup of the peaks kernel
 };
 constexpr int PC_SQ_REC = 12;           // per burst: squelch-average map (2), low-pass state map (4 + 2), decision, start state (2)
 
 hipError_t postchain_launch(const PcArgs &a, hipStream_t stream);
 // the deferred part of CFmDemod (fmdemod.cpp:113-152) for the FM channels of a launch made with PC_FM_DEFER
 hipError_t fm_squelch_launch(const PcArgs &a, hipStream_t stream);
+// CAgc's log magnitudes and sliding maximum of every sample of the call, for the walk that follows (PC_AGC_PRE)
+hipError_t agc_peaks_launch(const PcArgs &a, hipStream_t stream);
 hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, float *ave, float *peak, hipStream_t stream);
 hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, double *ave, double *peak, hipStream_t stream);
 hipError_t filter_leaf_launch(PcFir *fir, PcIir *iir, const float *in, float *out, int n, int op, hipStream_t stream);

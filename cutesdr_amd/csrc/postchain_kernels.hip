@@ -78,6 +78,7 @@ constexpr int PC_NCHUNK = (PC_AGC_RING + PT) / 16, PC_RLEVELS = 8;
 constexpr int LCMAX = 16;                // samples per thread at NW = 1
 constexpr int BQ_TAB = (LCMAX + 1) * 4 + LCMAX * 2;   // biquad chunk tables: M^k (k <= 16), c M^k (k < 16)
 constexpr double kInvTwoPiD = 1.0 / (2.0 * 3.14159265358979323846);
+constexpr int PC_PLL_WARM_MAX = 192;     // longest warm-up of the overlapped PLL walks (pll_overlap) worth running
 constexpr float kNegBig = -1.0e30f;
 
 // what a workgroup's scans and broadcasts exchange through LDS (Wg<NW> holds a pointer to it)
@@ -97,11 +98,22 @@ struct PcLds {
     float w1[PT + PC_FIR_MAX + 17];      // second work array (theta / Q)
     float h0[PC_FIR_MAX + 17], h1[PC_FIR_MAX + 17]; // FIR taps of the active demodulator, reversed and zero padded:
                                                     // h[4 + r] = tap ntaps-1-r (16-byte aligned rows of four)
-    float w2[PT + 16];                   // third work array (S-meter dB, attack average, PLL phase, |hp|)
-    float rt[PC_RLEVELS][PC_NCHUNK];     // log table over the chunk maxima of the sliding peak
+    alignas(16) float w2[PT + 16];       // third work array (S-meter dB, attack average, PLL phase, |hp|)
+    alignas(16) float rt[PC_RLEVELS][PC_NCHUNK];   // log table over the chunk maxima of the sliding peak
     double pw_sm[LCMAX + 1], pw_dc[LCMAX + 1], pw_sq[LCMAX + 1], pw_fd[LCMAX + 1];   // powers of the averager coefficients
     double bq[BQ_TAB];                   // biquad chunk tables
     double pm[(LCMAX + 1) * 4];          // PLL transition-matrix powers
+};
+
+// the image of the AGC peaks kernel (agc_peaks_kernel)
+static_assert(sizeof(float) * PC_RLEVELS * PC_NCHUNK >= 8 * 512 && sizeof(float) * (PT + 16) >= 8 * 512,
+              "pll_overlap keeps one double per thread in PcLds::rt and in PcLds::w2");
+struct PreLds {
+    PcSync sy;
+    float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile]
+    float pk[PT + 16];
+    float w2[PT + 16];
+    float rt[PC_RLEVELS][PC_NCHUNK];
 };
 
 // the squelch kernels' image (fm_squelch_*): a quarter of PcLds, so that eight of their workgroups share a CU
@@ -829,12 +841,71 @@ __device__ __forceinline__ bool pll_scan(const Wg<NW> &g, const float *th, int n
     return true;
 }
 
+// The same loop where that guess does not hold for a whole tile -- no carrier (an idle channel: the phase is noise),
+// cycle slips, the frequency clamp at work.  Every thread walks the EXACT recurrence over its LC samples, started
+// `warm` samples early from a zero state.  The loop is a contraction: a state error shrinks by its spectral radius
+// rho every sample (CFmDemod at 62.5 kHz: 0.47), a wrap moves the phase by whole turns only and a clamped frequency
+// is exact at once -- so by its first own sample a thread's state has met the sequential one.  That is checked, not
+// assumed: a thread's start state must equal its predecessor's end state to 1e-9 turns (the first threads start
+// from the true state at sample 0), and then by induction every state is the sequential one to that bound.  Any
+// mismatch -> false, and the caller walks the tile.  warm = pll_warm_len() samples: rho^(warm-8) < 1e-13; the eight
+// on top are for a wrap decision that differs late in the warm-up (measured on noise: 32 samples at rho = 0.47 sent
+// a quarter of the tiles to the one-thread walk, 48 none: 1.92 -> 0.45 ms for 85 idle receivers x 2^20 samples, against
+// 0.34 ms with carriers).
+// xp, xf: NT doubles of LDS each.  emit(i, phase_before, freq_after).
+__device__ __forceinline__ int pll_warm_len(double alpha, double beta)
+{
+    const double tr = 2.0 - alpha - beta, det = 1.0 - alpha, disc = tr * tr - 4.0 * det;
+    const double rho = disc < 0.0 ? sqrt(fabs(det)) : 0.5 * (fabs(tr) + sqrt(disc));
+    if (!(rho > 0.0)) return 8;
+    if (!(rho < 0.98)) return 1 << 20;
+    return (int)(-30.0 / log(rho)) + 10;
+}
+template <int NW, class F>
+__device__ __forceinline__ bool pll_overlap(const Wg<NW> &g, const float *th, int n, int warm, double alpha, double beta, double lo,
+                                            double hi, double &ph, double &fr, double *xp, double *xf, F emit)
+{
+    constexpr int LC = Wg<NW>::LC;
+    const int base = LC * g.t;
+    int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
+    int i = base - warm;
+    double p = 0.0, f = 0.0;
+    const bool exact = i <= 0;
+    if (exact) { i = 0; p = ph; f = fr; }
+    auto step = [&](float v) {                                  // fmdemod.cpp:166-177, in turns
+        const double err = -wrap_turn((double)v + p);
+        f = fmin(fmax(f + beta * err, lo), hi);
+        p = wrap_turn(p + f + alpha * err);
+    };
+    if (cnt > 0) {
+        float v = th[i];
+        for (; i < base; i++) { const float vn = th[i + 1]; step(v); v = vn; }
+    }
+    const double ps = p, fs = f;
+#pragma unroll
+    for (int j = 0; j < LC; j++) {
+        if (j < cnt) { const double pb = p; step(th[base + j]); emit(base + j, pb, f); }
+    }
+    xp[g.t] = p; xf[g.t] = f;
+    g.sync();
+    bool bad = false;
+    if (cnt > 0 && !exact) {
+        const double dp = ps - xp[g.t - 1], df = fs - xf[g.t - 1];
+        bad = !(fabs(dp - rint(dp)) < 1e-9) || !(fabs(df) < 1e-9);
+    }
+    const int tl = n > 0 ? (n - 1) / LC : 0;
+    const double pe = xp[tl], fe = xf[tl];
+    if (g.any(bad)) return false;
+    if (n > 0) { ph = pe; fr = fe; }
+    return true;
+}
+
 // pk[i] = max(E[i .. i+W1]), i < n, for E = S.mg[0 .. W1+n).  Chunks of 16: per-chunk prefix and
 // suffix maxima (registers), a log table over the <= 192 chunk maxima for the chunks strictly
 // inside a window, then window = suffix(first chunk) | inner chunks | prefix(last chunk).
 // Only prefix values at tile positions (-> S.pk) and suffix values at i < n (-> S.w2) are kept.
-template <int NW>
-__device__ __forceinline__ void sliding_max(const Wg<NW> &g, PcLds &S, int W1, int n)
+template <int NW, class L>
+__device__ __forceinline__ void sliding_max(const Wg<NW> &g, L &S, int W1, int n)
 {
     constexpr int NT = Wg<NW>::NT;
     const int len = W1 + n, t = g.t;
@@ -926,6 +997,9 @@ void postchain_kernel(PcArgs a)
     const bool cpx_out = stereo || mode == PC_MODE_NONE;
     // FM with the squelch deferred: this walk ends at the raw audio (fm_squelch_launch does the rest, burst-parallel)
     const bool defer = (a.flags & PC_FM_DEFER) && mode == PC_MODE_FM && a.burst <= 16384;
+    // AGC peaks from agc_peaks_kernel: the walk neither computes nor keeps the window's log magnitudes
+    const bool pre = (a.flags & PC_AGC_PRE) && do_agc && C.agc.on && !agc_real;
+    const float *pkrow = pre ? a.pkbuf + (long)ch * a.nbursts * a.burst : nullptr;
 
     // scalar state, identical on every thread
     PcSMeter sm = C.sm;
@@ -936,11 +1010,12 @@ void postchain_kernel(PcArgs a)
     double fm_ph = C.fm.phase, fm_fr = C.fm.freq, fm_dc = C.fm.err_dc, fm_sq = C.fm.sq_ave;
     int fm_squelched = C.fm.squelched;
     PcIir lp = C.fm.lp;
+    const int fm_warm = mode == PC_MODE_FM ? pll_warm_len(C.fm.alpha, C.fm.beta) : 0;
 
     // histories -> LDS
     if (do_agc && agc.on) {
         for (int i = t; i < D; i += NT) S.dl[i] = make_float2(g_dly[2 * i], g_dly[2 * i + 1]);
-        for (int i = t; i < W1; i += NT) S.mg[i] = g_mag[i];
+        if (!pre) for (int i = t; i < W1; i += NT) S.mg[i] = g_mag[i];
     }
     const PcFir *fir = mode == PC_MODE_AM ? &C.am.fir : mode == PC_MODE_SAM ? &C.sam.fir : mode == PC_MODE_FM ? &C.fm.hp : nullptr;
     const int nt = fir ? fir->ntaps : 1;
@@ -1021,6 +1096,10 @@ void postchain_kernel(PcArgs a)
                     for (int i = t; i < n; i += NT) { x[i].x *= gm; x[i].y *= gm; }
                     g.sync();
                 } else {
+                  if (pre) {
+                    for (int i = t; i < n; i += NT) S.pk[i] = pkrow[gi + i];
+                    g.sync();
+                  } else {
                     float *mg = S.mg + W1;
                     for (int i = t; i < n; i += NT) {
                         float m = fabsf(x[i].x);
@@ -1042,6 +1121,7 @@ void postchain_kernel(PcArgs a)
                         for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) S.mg[i] = keepm[j]; }
                         g.sync();
                     }
+                  }
                     PC_TICK(4);
                     // attack / decay averagers -> log gain argument max(att, dec) per sample in S.pk
                     {
@@ -1151,6 +1231,15 @@ void postchain_kernel(PcArgs a)
                         double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD;
                         scanned = pll_scan(g, th, n, F.alpha, F.beta, F.lo * kInvTwoPiD, F.hi * kInvTwoPiD, ph, fr, S.pm,
                                            [&](int i, double, double f) { au[i] = (float)f; });
+                        if (scanned) { fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD; }
+                    }
+                    if (!scanned && fm_warm <= PC_PLL_WARM_MAX && !(a.flags & PC_PLL_SEQ)) {       // unlocked: overlapped exact walks, verified
+                        g.sync();
+                        double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD;
+                        ph = wrap_turn(ph);
+                        scanned = pll_overlap(g, th, n, fm_warm, F.alpha, F.beta, F.lo * kInvTwoPiD, F.hi * kInvTwoPiD, ph, fr,
+                                              reinterpret_cast<double *>(&S.rt[0][0]), reinterpret_cast<double *>(S.w2),
+                                              [&](int i, double, double f) { au[i] = (float)f; });
                         if (scanned) { fm_ph = ph * kTwoPiD; fm_fr = fr * kTwoPiD; }
                     }
                     if (!scanned) {
@@ -1308,7 +1397,8 @@ void postchain_kernel(PcArgs a)
     g.sync();
     if (do_agc && agc.on) {
         for (int i = t; i < D; i += NT) { g_dly[2 * i] = S.dl[i].x; g_dly[2 * i + 1] = S.dl[i].y; }
-        for (int i = t; i < W1; i += NT) g_mag[i] = S.mg[i];
+        if (pre) { const float *tail = a.magtail + (long)ch * PC_AGC_RING; for (int i = t; i < W1; i += NT) g_mag[i] = tail[i]; }
+        else for (int i = t; i < W1; i += NT) g_mag[i] = S.mg[i];
     }
     if (fir && !defer) {
         PcFir *fw = const_cast<PcFir *>(fir);
@@ -1329,6 +1419,82 @@ void postchain_kernel(PcArgs a)
             if (!defer) { C.fm.sq_ave = fm_sq; C.fm.squelched = fm_squelched; C.fm.lp = lp; }   // else: fm_squelch_decide_kernel's
         }
     }
+}
+
+// =====================================================================================================
+// CAgc's log magnitudes and their sliding maximum (agc.cpp:196-231) for every sample of a call, ahead of the walk
+// (PC_AGC_PRE).  Neither needs state from the loop -- only the win_n-1 magnitudes in front of a burst, which are
+// the input's own -- so they leave the sequential walk (a fifth of an FM tile, a third of an SSB one) for one
+// workgroup per (channel, group of bursts).  The same fp32 operations in the same order: the peaks, and with them
+// every audio word, are what the walk computes itself.
+// =====================================================================================================
+__global__ __launch_bounds__(256)
+void agc_peaks_kernel(PcArgs a)
+{
+    using G = Wg<4>;
+    constexpr int NT = G::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
+    PreLds &S = *reinterpret_cast<PreLds *>(pc_smem);
+    const int ngrp = (a.nbursts + a.pre_bpw - 1) / a.pre_bpw;
+    const int t = threadIdx.x, ch = blockIdx.x / ngrp, b0 = (blockIdx.x % ngrp) * a.pre_bpw;
+    const int b1 = b0 + a.pre_bpw < a.nbursts ? b0 + a.pre_bpw : a.nbursts;
+    if (a.out_rows && a.out_rows[ch] < 0) return;
+    const PcChannel &C = a.chan[ch];
+    if (!C.agc.on) return;                               // uniform per workgroup
+    const G g{t, t & 63, t >> 6, &S.sy};
+    const int W1 = C.agc.win_n > 0 ? C.agc.win_n - 1 : 0;
+    const float2 *in = reinterpret_cast<const float2 *>(a.in) + (long)ch * a.in_stride;
+    const float *g_mag = a.agc_mag + (long)ch * PC_AGC_RING;   // the last W1 magnitudes of the previous call
+    float *pkrow = a.pkbuf + (long)ch * a.nbursts * a.burst;
+    auto logmag = [](float2 v) {
+        float m = fabsf(v.x);
+        const float mi = fabsf(v.y);
+        if (mi > m) m = mi;
+        return log10f(m + 3.2767e-4f) - 4.51543987f;     // agc.cpp:196-201
+    };
+    const long p0 = (long)b0 * a.burst, p1 = (long)b1 * a.burst, total = (long)a.nbursts * a.burst;
+    // the window in front of this group's first sample
+    for (int i = t; i < W1; i += NT) {
+        const long k = p0 - W1 + i;
+        S.mg[i] = k >= 0 ? logmag(in[k]) : g_mag[W1 + (int)k];
+    }
+    for (long pos = p0; pos < p1; ) {
+        const long bend = (pos / a.burst + 1) * a.burst;  // tiles do not straddle bursts (as in the walk)
+        const int n = (int)((bend - pos) < PT ? (bend - pos) : PT);
+        float *mg = S.mg + W1;
+        for (int i = t; i < n; i += NT) mg[i] = logmag(in[pos + i]);
+        g.sync();
+        sliding_max(g, S, W1, n);
+        for (int i = t; i < n; i += NT) pkrow[pos + i] = S.pk[i];
+        {   // the last W1 magnitudes are the next tile's window: read all, one barrier, write all
+            float keepm[PH / NT];
+#pragma unroll
+            for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) keepm[j] = S.mg[n + i]; }
+            g.sync();
+#pragma unroll
+            for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) S.mg[i] = keepm[j]; }
+            g.sync();
+        }
+        pos += n;
+    }
+    if (p1 == total) {                                   // the window the next call starts with
+        float *tail = a.magtail + (long)ch * PC_AGC_RING;
+        for (int i = t; i < W1; i += NT) tail[i] = S.mg[i];
+    }
+}
+
+hipError_t agc_peaks_launch(const PcArgs &a, hipStream_t stream)
+{
+    static_assert(sizeof(PreLds) <= 40 * 1024, "four peaks workgroups per CU");
+    PcArgs b = a;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long slots = 4L * (cus > 0 ? cus : 256);
+    b.pre_bpw = (int)(((long)a.channels * a.nbursts + slots - 1) / slots);
+    if (b.pre_bpw < 1) b.pre_bpw = 1;
+    const int ngrp = (a.nbursts + b.pre_bpw - 1) / b.pre_bpw;
+    hipLaunchKernelGGL(agc_peaks_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(PreLds), stream, b);
+    return hipGetLastError();
 }
 
 // =====================================================================================================

@@ -486,3 +486,88 @@ def test_fm_squelch_deferred_out_of_the_walk_gives_the_same_words(tmp_path, fast
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     a, w = np.load(tmp_path / "deferred.npy"), np.load(tmp_path / "walk.npy")
     assert a.shape == w.shape and np.array_equal(a.view(np.uint32), w.view(np.uint32))
+
+
+def _agc_batch_words(path, fastfir_n):
+    """Receivers of every mode and AGC setting through csdr_demod_batch, three calls; audio words + S-meters -> path"""
+    import cutesdr_amd as ca
+    fs = 2e6
+    cases = [("USB", dict()), ("USB", dict(AgcHangOn=1, AgcDecay=500, AgcThresh=-60)), ("AM", dict(AgcSlope=6, AgcDecay=50)),
+             ("SAM", dict(AgcThresh=-40)), ("CWU", dict(AgcDecay=1000)), ("FM", dict()), ("LSB", dict(AgcOn=0, AgcManualGain=40)),
+             ("AM", dict(AgcDecay=2000, AgcThresh=-120))]
+    C = len(cases)
+    n = 19968 * (16 if fastfir_n == 2048 else 72)
+    b = ca.DemodBatch(C, fastfir_n); b.set_input_rate(fs)
+    for c, (mode, kw) in enumerate(cases):
+        m, base = MODES[mode]
+        b.set_demod(c, m, info(ca, **dict(base, **kw)))
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -100e3)
+    rng = np.random.default_rng(78)
+    x = np.stack([make_input(mode, 3 * n, fs) for mode, _ in cases])
+    x[1, n // 2: n] *= 0.01                                        # a fade: the hang timer holds, then the decay runs
+    x[2, n: 2 * n] += 8000.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * (rng.random(n) < 1e-3)   # impulses
+    outs = []
+    for k in range(3):
+        outs.append(b.process(x[:, k * n:(k + 1) * n]))
+    per = [np.concatenate([np.asarray(o[c]).ravel() for o in outs]) for c in range(C)]
+    np.save(path, np.concatenate(per))
+    return per
+
+
+@pytest.mark.parametrize("fastfir_n", [2048, 16384])
+def test_agc_peaks_ahead_of_the_walk_give_the_same_words(tmp_path, fastfir_n):
+    """CAgc's log magnitudes and their sliding maximum (agc.cpp:196-231) need nothing from the loop, so a call of several
+    bursts computes them burst-parallel in front of the walk (PC_AGC_PRE).  Same fp32 operations: every audio word equals
+    the walk's own (CSDR_AGC_PRE=0, in a child process: the switch is read once) -- every mode, hang timer on and off,
+    a fade, impulses, AGC off beside AGC on, one-tile and eight-tile bursts, state carried over three calls."""
+    import subprocess, sys, os
+    got = _agc_batch_words(str(tmp_path / "pre.npy"), fastfir_n)
+    assert all(len(g) > 1024 and np.abs(g).max() > 10.0 for g in got)
+    code = ("import sys; sys.path.insert(0, %r); import test_postchain_gpu as T; T._agc_batch_words(%r, %d)"
+            % (os.path.dirname(__file__), str(tmp_path / "walk.npy"), fastfir_n))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSDR_AGC_PRE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, w = np.load(tmp_path / "pre.npy"), np.load(tmp_path / "walk.npy")
+    assert a.shape == w.shape and np.array_equal(a.view(np.uint32), w.view(np.uint32))
+
+
+def _fm_unlocked_words(path, fastfir_n):
+    """FM receivers that hear noise only, a carrier at the edge of lock, and a clean carrier; squelch open -> path"""
+    import cutesdr_amd as ca
+    fs, C = 2e6, 6
+    n = 19968 * (16 if fastfir_n == 2048 else 72)
+    b = ca.DemodBatch(C, fastfir_n); b.set_input_rate(fs)
+    for c in range(C):
+        b.set_demod(c, 2, info(ca, SquelchValue=-160))            # threshold far up: the squelch stays open
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -100e3)
+    rng = np.random.default_rng(79)
+    noise = lambda a: a * (rng.standard_normal(2 * n) + 1j * rng.standard_normal(2 * n))
+    car = make_input("FM", 2 * n, fs)
+    x = np.stack([noise(300.0), noise(3000.0), car + noise(1500.0), car + noise(4000.0), car, 0.02 * car + noise(30.0)])
+    outs = [b.process(x[:, k * n:(k + 1) * n]) for k in range(2)]
+    per = [np.concatenate([o[c] for o in outs]) for c in range(C)]
+    np.save(path, np.concatenate(per))
+    return per
+
+
+@pytest.mark.parametrize("fastfir_n", [2048, 16384])
+def test_fm_unlocked_pll_overlapped_walks_equal_the_sequential_walk(tmp_path, fastfir_n):
+    """A tile of CFmDemod's PLL (fmdemod.cpp:166-177) that is not locked -- an idle channel, a carrier in the noise --
+    cannot be solved as one linear system; it used to fall to one thread walking 1024 samples.  pll_overlap runs the
+    exact recurrence on every thread over its own samples, started early from a zero state, and checks that neighbours
+    meet to 1e-9 turns.  Its audio must be the sequential walk's (CSDR_PLL_OVERLAP=0, child process) to 1e-6 of full
+    scale on every sample: noise only, weak and strong carriers, two calls."""
+    import subprocess, sys, os
+    got = _fm_unlocked_words(str(tmp_path / "overlap.npy"), fastfir_n)
+    assert all(np.abs(g).max() > 100.0 for g in got)                 # squelch open everywhere: there is audio to compare
+    code = ("import sys; sys.path.insert(0, %r); import test_postchain_gpu as T; T._fm_unlocked_words(%r, %d)"
+            % (os.path.dirname(__file__), str(tmp_path / "seq.npy"), fastfir_n))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSDR_PLL_OVERLAP="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, w = np.load(tmp_path / "overlap.npy"), np.load(tmp_path / "seq.npy")
+    assert a.shape == w.shape
+    assert np.abs(a - w).max() <= 1e-6 * FULL_SCALE, np.abs(a - w).max()
