@@ -25,6 +25,7 @@ struct csdr_fft_batch {
     float *d_work;                               // transform work space of the multi-launch sizes
     float *d_part = nullptr; size_t part_cap = 0; // frame-group partial sums
     int *d_cnt, *d_over;
+    int *d_scr = nullptr; size_t scr_cap = 0;           // levels of a waterfall line (csdr_fft_batch_get_waterfall_all)
     std::vector<float> h_ave;
     std::vector<int> h_over;
 };
@@ -114,6 +115,7 @@ void csdr_fft_batch_destroy(csdr_fft_batch *f)
     fft_free_dev(f);
     if (f->d_cnt) (void)hipFree(f->d_cnt);
     if (f->d_over) (void)hipFree(f->d_over);
+    if (f->d_scr) (void)hipFree(f->d_scr);
     if (f->d_part) (void)hipFree(f->d_part);
     delete f;
 }
@@ -269,6 +271,33 @@ int csdr_fft_batch_get_screen_all(csdr_fft_batch *f, int max_h, int max_w, doubl
     CSDR_HIP(screen_launch(a, (hipStream_t)stream));
     if (d_overload)
         CSDR_HIP(hipMemcpyAsync(d_overload, f->d_over, sizeof(int) * f->channels, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CSDR_OK;
+}
+
+void csdr_plotter_color_table(unsigned int *out256)
+{
+    if (out256) for (int i = 0; i < 256; i++) out256[i] = plotter_color(i);
+}
+
+int csdr_fft_batch_get_waterfall_all(csdr_fft_batch *f, int max_w, double max_db, double min_db, int start_hz,
+                                     int stop_hz, unsigned int *d_rgb, long long out_stride, int *d_overload,
+                                     void *stream)
+{
+    if (!f || !d_rgb || max_w < 0 || out_stride < max_w) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(f->device)) return CSDR_EHIP;
+    if (max_w == 0) return CSDR_OK;
+    const size_t need = (size_t)f->channels * max_w;
+    if (need > f->scr_cap) {                             // the levels of the line, [channels][max_w]
+        CSDR_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (f->d_scr) (void)hipFree(f->d_scr);
+        f->d_scr = nullptr; f->scr_cap = 0;
+        CSDR_HIP(hipMalloc((void **)&f->d_scr, need * sizeof(int)));
+        f->scr_cap = need;
+    }
+    CSDR_HIP(hipMemsetAsync(f->d_scr, 0xff, need * sizeof(int), (hipStream_t)stream));     // -1: not touched
+    int rc = csdr_fft_batch_get_screen_all(f, 255, max_w, max_db, min_db, start_hz, stop_hz, f->d_scr, max_w, d_overload, stream);
+    if (rc < 0) return rc;
+    CSDR_HIP(waterfall_color_launch(f->d_scr, max_w, d_rgb, out_stride, max_w, f->channels, (hipStream_t)stream));
     return CSDR_OK;
 }
 

@@ -152,4 +152,34 @@ hipError_t screen_launch(const ScreenArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+// ---------------- waterfall line: CPlotter::draw's palette look-up (gui/plotter.cpp:436-441) ----------------
+__host__ __device__ static inline unsigned plotter_color_of(int i)
+{   // the constructor's ramp (gui/plotter.cpp:67-83): blue -> cyan -> green -> yellow -> red -> magenta-ish
+    int r = 0, g = 0, b = 0;
+    if (i < 43) { b = 255 * i / 43; }
+    else if (i < 87) { g = 255 * (i - 43) / 43; b = 255; }
+    else if (i < 120) { g = 255; b = 255 - (255 * (i - 87) / 32); }
+    else if (i < 154) { r = 255 * (i - 120) / 33; g = 255; }
+    else if (i < 217) { r = 255; g = 255 - (255 * (i - 154) / 62); }
+    else { r = 255; b = 128 * (i - 217) / 38; }
+    return 0xff000000u | ((unsigned)(r & 255) << 16) | ((unsigned)(g & 255) << 8) | (unsigned)(b & 255);
+}
+unsigned plotter_color(int i) { return plotter_color_of(i < 0 ? 0 : (i > 255 ? 255 : i)); }
+
+__global__ void waterfall_color_kernel(const int *levels, long stride, unsigned *rgb, long rgb_stride, int w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (x >= w) return;
+    const int y = levels[(long)ch * stride + x];
+    if (y < 0) return;                                   // no bin maps to this pixel
+    rgb[(long)ch * rgb_stride + x] = plotter_color_of(255 - (y > 255 ? 255 : y));
+}
+hipError_t waterfall_color_launch(const int *levels, long stride, unsigned *rgb, long rgb_stride, int w, int channels,
+                                  hipStream_t st)
+{
+    if (w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(waterfall_color_kernel, dim3((w + 255) / 256, channels), dim3(256), 0, st, levels, stride, rgb, rgb_stride, w);
+    return hipGetLastError();
+}
+
 }  // namespace csdr

@@ -32,6 +32,11 @@ struct ScreenArgs {
     double off, gain;                   // MaxdB/10 and -10/(MaxdB-MindB)
 };
 hipError_t screen_launch(const ScreenArgs &a, hipStream_t stream);
+// CPlotter's palette entry i (gui/plotter.cpp:67-83) as 0xFFRRGGBB
+unsigned plotter_color(int i);
+// levels [channels][stride] (0..255, or < 0 = pixel not touched) -> palette[255 - level] in rgb [channels][rgb_stride]
+hipError_t waterfall_color_launch(const int *levels, long stride, unsigned *rgb, long rgb_stride, int w, int channels,
+                                  hipStream_t stream);
 
 // sizes outside 2048..16384 (512, 1024, 32768, 65536): multi-launch transform through HBM.
 // work: [2][channels][N] complex for the spectrum, [2][N] for the plain transform

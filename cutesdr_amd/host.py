@@ -732,6 +732,22 @@ class FftBatch(_Obj):
         return (dov.download(np.int32, self.channels) != 0,
                 dout.download(np.int32, self.channels * max(MaxWidth, 1)).reshape(self.channels, -1))
 
+    def waterfall_all(self, MaxWidth, MaxdB, MindB, StartFreq, StopFreq, fill=0):
+        """The new waterfall line of every channel (CPlotter::draw, gui/plotter.cpp:425-441) on the device ->
+        (overload [C], 0xFFRRGGBB pixels [C, MaxWidth]); pixels no bin maps to come back as `fill`"""
+        w = max(MaxWidth, 1)
+        dout = DeviceBuffer(self.channels * w * 4, self.device)
+        dov = DeviceBuffer(self.channels * 4, self.device)
+        dout.upload(np.full(self.channels * w, fill, dtype=np.uint32))
+        check(lib().csdr_fft_batch_get_waterfall_all(self.h, MaxWidth, C.c_double(MaxdB), C.c_double(MindB), StartFreq, StopFreq,
+                                                     C.c_void_p(dout.ptr), C.c_longlong(w), C.c_void_p(dov.ptr), None),
+              "csdr_fft_batch_get_waterfall_all")
+        sync(self.device)
+        ov = dov.download(np.int32, self.channels) != 0
+        pix = dout.download(np.uint32, self.channels * w).reshape(self.channels, -1)
+        dout.free(); dov.free()
+        return ov, pix
+
     def total_count(self, channel):
         return check(lib().csdr_fft_batch_get_total_count(self.h, channel))
 

@@ -332,6 +332,15 @@ int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max
 int csdr_fft_batch_get_screen_all(csdr_fft_batch *f, int max_h, int max_w, double max_db, double min_db,
                                   int start_hz, int stop_hz, int *d_out, long long out_stride, int *d_overload,
                                   void *stream);
+/* CPlotter's waterfall palette (gui/plotter.cpp:67-83): 256 colours, 0xFFRRGGBB each (QRgb order) */
+void csdr_plotter_color_table(unsigned int *out256);
+/* The new top line of the waterfall of every channel (CPlotter::draw, gui/plotter.cpp:425-441):
+ * GetScreenIntegerFFTData(255, max_w, ...) and, per pixel, the palette entry 255 - y.  d_rgb is
+ * [channels][out_stride] 0xFFRRGGBB on the device, out_stride >= max_w; pixels that no bin maps to keep what
+ * d_rgb held (the reference paints them from an uninitialised buffer).  d_overload as above.  Asynchronous. */
+int csdr_fft_batch_get_waterfall_all(csdr_fft_batch *f, int max_w, double max_db, double min_db, int start_hz,
+                                     int stop_hz, unsigned int *d_rgb, long long out_stride, int *d_overload,
+                                     void *stream);
 
 /* ----------------------------------------------------------------------------------------
  * CFractResampler (dsp/fractresampler.h:17-33)

@@ -251,6 +251,37 @@ int orc_cfft_get_screen(orc_cfft *f, int max_h, int max_w, double max_db, double
     return f->overload;
 }
 
+/* CPlotter's palette (gui/plotter.cpp:67-83), QColor::setRgb(r, g, b) as 0xFFRRGGBB */
+void orc_plotter_color_table(unsigned int *out256)
+{
+    int i;
+    for (i = 0; i < 256; i++) {
+        int r = 0, g = 0, b = 0;
+        if (i < 43) { r = 0; g = 0; b = 255 * (i) / 43; }
+        if ((i >= 43) && (i < 87)) { r = 0; g = 255 * (i - 43) / 43; b = 255; }
+        if ((i >= 87) && (i < 120)) { r = 0; g = 255; b = 255 - (255 * (i - 87) / 32); }
+        if ((i >= 120) && (i < 154)) { r = (255 * (i - 120) / 33); g = 255; b = 0; }
+        if ((i >= 154) && (i < 217)) { r = 255; g = 255 - (255 * (i - 154) / 62); b = 0; }
+        if (i >= 217) { r = 255; g = 0; b = 128 * (i - 217) / 38; }
+        out256[i] = 0xff000000u | ((unsigned)r << 16) | ((unsigned)g << 8) | (unsigned)b;
+    }
+}
+/* the new top line of the waterfall (CPlotter::draw, gui/plotter.cpp:425-441): levels at MaxHeight 255, pixel i
+ * painted m_ColorTbl[255 - fftbuf[i]].  levels: max_w + 1 ints of work space (the reference's stack buffer), pre-set
+ * by the caller; rgb[i] is written for i < max_w.  Returns the overload flag. */
+int orc_plotter_waterfall_line(orc_cfft *f, int max_w, double max_db, double min_db, int start_hz, int stop_hz,
+                               int *levels, unsigned int *rgb)
+{
+    unsigned int tbl[256];
+    int i, ov = orc_cfft_get_screen(f, 255, max_w, max_db, min_db, start_hz, stop_hz, levels);
+    orc_plotter_color_table(tbl);
+    for (i = 0; i < max_w; i++) {
+        int y = levels[i];
+        if (y >= 0 && y <= 255) rgb[i] = tbl[255 - y];
+    }
+    return ov;
+}
+
 /* ==================================================================================== */
 /* CFastFIR                                                                              */
 /* ==================================================================================== */

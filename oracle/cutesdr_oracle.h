@@ -40,6 +40,9 @@ void orc_cfft_set_params(orc_cfft *f, int size, int invert, double db_comp, doub
 void orc_cfft_set_ave(orc_cfft *f, int ave);
 void orc_cfft_reset(orc_cfft *f);
 int  orc_cfft_put_display(orc_cfft *f, int n, const orc_cpx *in);
+void orc_plotter_color_table(unsigned int *out256);
+int  orc_plotter_waterfall_line(orc_cfft *f, int max_w, double max_db, double min_db, int start_hz, int stop_hz,
+                                int *levels, unsigned int *rgb);
 int  orc_cfft_get_screen(orc_cfft *f, int max_h, int max_w, double max_db, double min_db,
                          int start_hz, int stop_hz, int *out);
 void orc_cfft_fwd(orc_cfft *f, orc_cpx *a);      /* includes the power/log10 side effect */

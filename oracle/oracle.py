@@ -55,6 +55,8 @@ def _declare(L):
     f("orc_cfft_set_ave", None, P, I); f("orc_cfft_reset", None, P)
     f("orc_cfft_put_display", I, P, I, P)
     f("orc_cfft_get_screen", I, P, I, I, D, D, I, I, P)
+    f("orc_plotter_color_table", None, P)
+    f("orc_plotter_waterfall_line", I, P, I, D, D, I, I, P, P)
     f("orc_cfft_fwd", None, P, P); f("orc_cfft_rev", None, P, P)
     f("orc_cfft_size", I, P); f("orc_cfft_avebuf", P, P)
     f("orc_fastfir_new", P, I); f("orc_fastfir_free", None, P)
@@ -160,6 +162,13 @@ class _Handle:
             self.h = None
 
 
+def plotter_color_table():
+    """CPlotter's 256-entry waterfall palette (gui/plotter.cpp:67-83) as 0xFFRRGGBB"""
+    t = np.zeros(256, dtype=np.uint32)
+    lib().orc_plotter_color_table(_ptr(t))
+    return t
+
+
 class CFft(_Handle):
     _free = "orc_cfft_free"
 
@@ -183,6 +192,14 @@ class CFft(_Handle):
         out = np.zeros(max(max_w, 1) + 1, dtype=np.int32)     # the reference's loop writes OutBuf[MaxWidth] too
         ov = lib().orc_cfft_get_screen(self.h, max_h, max_w, max_db, min_db, start_hz, stop_hz, _ptr(out))
         return bool(ov), out[:max(max_w, 1)].copy()
+
+    def WaterfallLine(self, max_w, max_db, min_db, start_hz, stop_hz, fill=0):
+        """CPlotter::draw's new waterfall line (gui/plotter.cpp:425-441) -> (overload, 0xFFRRGGBB pixels); pixels no
+        bin maps to come back as `fill`"""
+        lv = np.full(max(max_w, 1) + 1, -1, dtype=np.int32)
+        rgb = np.full(max(max_w, 1), fill, dtype=np.uint32)
+        ov = lib().orc_plotter_waterfall_line(self.h, max_w, max_db, min_db, start_hz, stop_hz, _ptr(lv), _ptr(rgb))
+        return bool(ov), rgb
 
     def FwdFFT(self, x):
         a = _c128(x).copy(); lib().orc_cfft_fwd(self.h, _ptr(a)); return a

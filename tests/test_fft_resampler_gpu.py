@@ -194,6 +194,42 @@ def test_screen_mapping_on_device_for_all_channels(oracle, invert):
         assert not ov.any()
 
 
+@pytest.mark.parametrize("invert", [False, True])
+def test_waterfall_line_on_device_for_all_channels(oracle, invert):
+    """the new top line of CPlotter's waterfall (gui/plotter.cpp:425-441: levels at MaxHeight 255, then
+    m_ColorTbl[255 - y]) for every channel on the device against the oracle -- wide span (more bins than pixels), narrow
+    span (fewer), and the palette itself entry by entry."""
+    import ctypes as C
+    import cutesdr_amd as ca
+    tbl = np.zeros(256, dtype=np.uint32)
+    ca.lib().csdr_plotter_color_table(tbl.ctypes.data_as(C.c_void_p))
+    want_tbl = oracle.plotter_color_table()
+    assert np.array_equal(tbl, want_tbl)
+    assert tbl[0] == 0xff000000 and tbl[255] == 0xffff0080 and len(set(tbl.tolist())) > 200
+    n, Cn, fs = 4096, 3, 2e6
+    b = ca.FftBatch(Cn)
+    b.set_params(n, invert, 0.0, fs); b.set_ave(1)
+    x = np.stack([tones_plus_noise(170 + c, n, fs, [150e3 * (c + 1), -333e3]) for c in range(Cn)])
+    b.put_display(x)
+    refs = []
+    for c in range(Cn):
+        r = oracle.CFft(); r.SetFFTParams(n, invert, 0.0, fs); r.SetFFTAve(1); r.PutInDisplayFFT(x[c]); refs.append(r)
+    for (w, lo, hi) in ((700, -900000, 900000), (3000, -250000, 250000), (300, 100000, 180000)):
+        ov, pix = b.waterfall_all(w, 0.0, -160.0, lo, hi, fill=0x12345678)
+        _, lev = b.screen_all(255, w, 0.0, -160.0, lo, hi)
+        for c in range(Cn):
+            _, want = refs[c].WaterfallLine(w, 0.0, -160.0, lo, hi, fill=0x12345678)
+            touched = lev[c] >= 0
+            assert np.array_equal(pix[c][~touched], np.full((~touched).sum(), 0x12345678, dtype=np.uint32))
+            assert np.array_equal(pix[c][touched], tbl[255 - lev[c][touched]])            # the palette of the device's own levels
+            # against the oracle: levels may differ by one count (fp32 bels), i.e. by one palette step
+            idx_want = np.array([int(np.nonzero(want_tbl == v)[0][0]) if v != 0x12345678 else -1 for v in want[touched]])
+            assert (idx_want >= 0).all()
+            assert np.abs(idx_want - (255 - lev[c][touched])).max() <= 1, (c, w)
+            assert (pix[c][touched] == want[touched]).mean() > 0.9
+        assert not ov.any()
+
+
 @pytest.mark.parametrize("ave", [1, 3, 10])
 def test_fft_batch_many_frames_are_split_into_groups(oracle, ave):
     """Calls with many frames on few channels cut each channel's frames into groups (one workgroup

@@ -128,6 +128,30 @@ def test_display_fft_anchor(oracle):
     assert np.argmin(pix) == 2560
 
 
+def test_waterfall_palette_and_line(oracle):
+    """CPlotter's palette as its constructor writes it (gui/plotter.cpp:67-83: the six ramps' end points) and the
+    waterfall line of CPlotter::draw (:425-441) = palette[255 - GetScreenIntegerFFTData(255, w, ...)]"""
+    t = oracle.plotter_color_table()
+    rgb = lambda v: ((int(v) >> 16) & 255, (int(v) >> 8) & 255, int(v) & 255)
+    assert rgb(t[0]) == (0, 0, 0) and rgb(t[42]) == (0, 0, 255 * 42 // 43)
+    assert rgb(t[43]) == (0, 0, 255) and rgb(t[86]) == (0, 255 * 43 // 43, 255)
+    assert rgb(t[87]) == (0, 255, 255) and rgb(t[119]) == (0, 255, 0)
+    assert rgb(t[120]) == (0, 255, 0) and rgb(t[153]) == (255, 255, 0)
+    assert rgb(t[154]) == (255, 255, 0) and rgb(t[216]) == (255, 0, 0)
+    assert rgb(t[217]) == (255, 0, 0) and rgb(t[255]) == (255, 0, 128)
+    assert (t >> 24 == 0xff).all()
+    n, fs = 4096, 2e6
+    f = oracle.CFft()
+    f.SetFFTParams(n, False, 0.0, fs)
+    f.SetFFTAve(1)
+    f.PutInDisplayFFT(3276.7 * np.exp(2j * np.pi * 250e3 * np.arange(n) / fs))
+    for (w, lo, hi) in ((800, -1000000, 1000000), (3000, 200000, 300000)):
+        _, lev = f.GetScreenIntegerFFTData(255, w, 0.0, -160.0, lo, hi)
+        _, line = f.WaterfallLine(w, 0.0, -160.0, lo, hi)
+        assert np.array_equal(line, t[255 - lev])
+        assert rgb(line[np.argmin(lev)])[0] == 255 or rgb(line[np.argmin(lev)])[1] == 255   # the carrier is the hottest pixel
+
+
 def test_fm_chain_rate_and_smeter_anchor(oracle):
     # section 8c: 2 MSPS / FM -> output rate 62500; 10000-amplitude carrier -> S-meter -5.55 dB
     d = oracle.CDemodulator(2048)
