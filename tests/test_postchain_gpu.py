@@ -571,3 +571,23 @@ def test_fm_unlocked_pll_overlapped_walks_equal_the_sequential_walk(tmp_path, fa
     a, w = np.load(tmp_path / "overlap.npy"), np.load(tmp_path / "seq.npy")
     assert a.shape == w.shape
     assert np.abs(a - w).max() <= 1e-6 * FULL_SCALE, np.abs(a - w).max()
+
+
+@pytest.mark.parametrize("waves", [1, 8])
+def test_chain_kernels_with_one_and_eight_waves_per_receiver(tmp_path, waves):
+    """postchain_kernel<1> (launches of more than 1024 receivers) and <8> (CSDR_POSTCHAIN_WAVES) walk the same chain as
+    the four-wave kernel the other tests run -- AGC peaks taken from the pre-pass, squelch deferred, unlocked FM tiles by
+    overlapped walks.  Same words up to the rounding of their differently shaped scans (1e-5 of full scale); on
+    receivers whose PLL is not locked a last-bit difference may send the two walks apart for a few samples, so
+    there the bound holds for 99.9 % of the samples."""
+    import subprocess, sys, os
+    ref_a = np.concatenate(_agc_batch_words(str(tmp_path / "a4.npy"), 2048))
+    ref_u = np.concatenate(_fm_unlocked_words(str(tmp_path / "u4.npy"), 2048))
+    code = ("import sys; sys.path.insert(0, %r); import test_postchain_gpu as T; T._agc_batch_words(%r, 2048); T._fm_unlocked_words(%r, 2048)"
+            % (os.path.dirname(__file__), str(tmp_path / "a.npy"), str(tmp_path / "u.npy")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSDR_POSTCHAIN_WAVES=str(waves)), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, u = np.load(tmp_path / "a.npy"), np.load(tmp_path / "u.npy")
+    assert a.shape == ref_a.shape and u.shape == ref_u.shape
+    assert np.abs(a - ref_a).max() <= 1e-5 * FULL_SCALE, np.abs(a - ref_a).max()
+    assert (np.abs(u - ref_u) <= 1e-5 * FULL_SCALE).mean() >= 0.999
