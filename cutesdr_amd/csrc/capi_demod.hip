@@ -346,6 +346,7 @@ struct csdr_demod_batch {
     double in_rate = 0.0;
     std::vector<ChanCfg> cfg;
     std::vector<int> core_of, row_of;                 // channel -> (core, row)
+    std::vector<int> in_row;                          // channel -> row of the caller's input it reads (csdr_demod_batch_set_input_rows)
     std::vector<ChainCore *> cores;                   // one per distinct decimator plan
     std::vector<std::vector<int>> members;            // core -> channel ids (row order)
     std::vector<int *> d_rows;                        // core -> device array of channel ids (input rows)
@@ -450,7 +451,7 @@ static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const 
     int *dr = nullptr, *dor = nullptr;
     CSDR_HIP(hipMalloc((void **)&dr, sizeof(int)));
     CSDR_HIP(hipMalloc((void **)&dor, sizeof(int)));
-    CSDR_HIP(hipMemcpy(dr, &channel, sizeof(int), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(dr, &b->in_row[channel], sizeof(int), hipMemcpyHostToDevice));
     CSDR_HIP(hipMemcpy(dor, &channel, sizeof(int), hipMemcpyHostToDevice));
     const int muted = -1;                              // the old row: keeps reading its input, writes nothing
     CSDR_HIP(hipMemcpy(b->d_out_rows[ka] + r, &muted, sizeof(int), hipMemcpyHostToDevice));
@@ -574,6 +575,8 @@ csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_
     b->device = device; b->channels = channels; b->fft_n = fastfir_n;
     b->cfg.assign(channels, ChanCfg());
     b->core_of.assign(channels, -1); b->row_of.assign(channels, -1);
+    b->in_row.resize(channels);
+    for (int c = 0; c < channels; c++) b->in_row[c] = c;
     return b;
 }
 void csdr_demod_batch_destroy(csdr_demod_batch *b) { delete b; }
@@ -606,6 +609,28 @@ int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const
     c.want_bw = (mode == PC_MODE_LSB || mode == PC_MODE_CWL) ? -c.info.LowCutmin : c.info.HiCutmax;
     return CSDR_OK;
 }
+// device copies of every group's input-row list, from members[] and in_row[]
+static int batch_upload_input_rows(csdr_demod_batch *b)
+{
+    std::vector<int> rows;
+    for (size_t ki = 0; ki < b->cores.size(); ki++) {
+        rows.clear();
+        for (int c : b->members[ki]) rows.push_back(b->in_row[c]);
+        CSDR_HIP(hipMemcpy(b->d_rows[ki], rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
+    }
+    return CSDR_OK;
+}
+int csdr_demod_batch_set_input_rows(csdr_demod_batch *b, const int *input_row)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (input_row)
+        for (int c = 0; c < b->channels; c++)
+            if (input_row[c] < 0 || input_row[c] >= b->channels) return fail(CSDR_EINVAL, "input row %d of receiver %d", input_row[c], c);
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());                  // control plane: a call in flight still reads the old lists
+    for (int c = 0; c < b->channels; c++) b->in_row[c] = input_row ? input_row[c] : c;
+    return b->cores.empty() ? CSDR_OK : batch_upload_input_rows(b);
+}
 int csdr_demod_batch_commit(csdr_demod_batch *b)
 {
     if (!b) return fail(CSDR_EINVAL, "bad handle");
@@ -625,8 +650,7 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
         b->members.push_back(g.second);
         int *dr = nullptr;
         CSDR_HIP(hipMalloc((void **)&dr, sizeof(int) * g.second.size()));
-        CSDR_HIP(hipMemcpy(dr, g.second.data(), sizeof(int) * g.second.size(), hipMemcpyHostToDevice));
-        b->d_rows.push_back(dr);
+        b->d_rows.push_back(dr);                       // filled by batch_upload_input_rows below
         int *dor = nullptr;
         CSDR_HIP(hipMalloc((void **)&dor, sizeof(int) * g.second.size()));
         CSDR_HIP(hipMemcpy(dor, g.second.data(), sizeof(int) * g.second.size(), hipMemcpyHostToDevice));
@@ -640,6 +664,10 @@ int csdr_demod_batch_commit(csdr_demod_batch *b)
             int rc = apply_set_demod(*k, (int)r, b->cfg[c], b->in_rate, mode, di);
             if (rc) return rc;
         }
+    }
+    {
+        int rc = batch_upload_input_rows(b);
+        if (rc) return rc;
     }
     batch_order(b);                                    // heaviest post-chain first, and on the highest-priority stream
     if (b->cores.size() > 1) {

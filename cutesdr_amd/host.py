@@ -592,6 +592,15 @@ class DemodBatch(_Obj):
     def set_pipelined(self, on=True):
         check(lib().csdr_demod_batch_set_pipelined(self.h, int(on)), "set_pipelined")
 
+    def set_input_rows(self, rows=None):
+        """receiver c reads input row rows[c] (several receivers cut from one stream); None: row c again"""
+        if rows is None:
+            check(lib().csdr_demod_batch_set_input_rows(self.h, None), "set_input_rows")
+            return
+        a = np.ascontiguousarray(rows, dtype=np.int32)
+        assert a.shape == (self.channels,)
+        check(lib().csdr_demod_batch_set_input_rows(self.h, _vp(a)), "set_input_rows")
+
     def flush(self, stream=None):
         check(lib().csdr_demod_batch_flush(self.h, C.c_void_p(stream) if stream else None), "flush")
 

@@ -254,6 +254,13 @@ int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate);
  * synchronises the device. */
 int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const csdr_demod_info *info);
 int csdr_demod_batch_commit(csdr_demod_batch *b);
+/* Receivers cut from shared streams (one radio, many receivers: SURVEY 8e "if channels are cut from one stream"):
+ * receiver c reads row input_row[c] of d_in (or datagram stream input_row[c]) instead of row c; several receivers
+ * may name the same row, each keeps its own CDownConvert / CFastFIR / AGC / demodulator state as in the reference,
+ * where every CDemodulator is handed the same buffer (interface/sdrinterface.cpp:903).  input_row: `channels` ints on
+ * the host, each in [0, channels); NULL restores row c for receiver c.  Before or after commit(); the call
+ * synchronises the device. */
+int csdr_demod_batch_set_input_rows(csdr_demod_batch *b, const int *input_row);
 int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq);
 double csdr_demod_batch_get_output_rate(csdr_demod_batch *b, int channel);
 double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel);

@@ -323,3 +323,57 @@ def test_live_mode_change_inside_a_batch(oracle, pipelined):
     for c in range(C):
         assert float(sm[c]) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02), c
         assert b.smeter_ave(c) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02), c
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["strict", "pipelined"])
+def test_receivers_cut_from_shared_streams(oracle, pipelined):
+    """One radio, many receivers (interface/sdrinterface.cpp:903 hands every demodulator the same buffer):
+    csdr_demod_batch_set_input_rows lets twelve receivers of four modes read TWO wide-band streams -- each stream the
+    sum of six stations 40 kHz apart -- every receiver tuned to its own station.  Each follows an oracle CDemodulator
+    fed the same shared stream; the mapping is changed after commit() too (the receivers swap streams mid-run)."""
+    import cutesdr_amd as ca
+    C, S, fs, lim = 12, 2, 2e6, 19968
+    n, calls = lim * 8, 4
+    names = ["FM", "AM", "USB", "SAM"]
+    t = np.arange(calls * n)
+    station = lambda c: 100e3 + 40e3 * (c // S)                # receiver c listens here, on stream c % S
+    x = np.zeros((S, calls * n), dtype=np.complex128)
+    for c in range(C):
+        x[c % S] += 0.3 * chain_input(names[c % 4], calls * n, fs) * np.exp(2j * np.pi * (station(c) - 100e3) * t / fs)
+    x = x.astype(np.complex64)
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    rows = np.array([c % S for c in range(C)], dtype=np.int32)
+    b.set_input_rows(rows)                                      # before commit()
+    refs = []
+    for c in range(C):
+        m, kw = MODES[names[c % 4]]
+        b.set_demod(c, m, info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-station(c))
+        refs.append(r)
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -station(c))
+    if pipelined:
+        b.set_pipelined(True)
+    since = [0] * C
+    for k in range(calls):
+        if k == 2:                                              # after commit(): every receiver moves to the other stream
+            b.flush(); ca.sync()
+            rows = (rows + 1) % S
+            b.set_input_rows(rows)
+        part = x[:, k * n:(k + 1) * n]
+        got = b.process(part)
+        if pipelined:
+            b.flush(); ca.sync()
+        for c in range(C):
+            want = refs[c].process_append(part[rows[c]].astype(np.complex128))
+            assert len(got[c]) == len(want), (c, k)
+            if len(want) and k != 2:                            # (call 2: the new stream's station fades in through the filters)
+                mode = names[c % 4]
+                # (SAM: the PLL pulls in on a carrier of arbitrary phase during its first bursts: 2e-3 there, then the rule)
+                check_chain_bursts(burst_errors(got[c], want), mode if mode == "FM" else "other", since[c], (c, k, mode),
+                                   from_zero=(2e-3 if mode == "SAM" else 5e-4) * FULL_SCALE)
+            since[c] = 0 if k == 2 else since[c] + len(want) // 1024
+    with pytest.raises(ca._capi.CsdrError):
+        b.set_input_rows(np.full(C, C, dtype=np.int32))        # a row the batch cannot have
+    b.set_input_rows(None)
