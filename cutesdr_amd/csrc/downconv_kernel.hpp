@@ -125,6 +125,22 @@ __device__ __forceinline__ v2f phasor_of(unsigned long long phase)
 // uniform reads), the layout words sit packed in two registers with stage s in lane s (v_readlane)
 enum { DP_KIND = 0, DP_HIST2, DP_ROFF, DP_OOFF, DP_CC, DP_C0 = 8, DP_WORDS = 24 };   // rows of 96 B, taps 16-B aligned
 
+// The arithmetic of one output, the same in every form of the stage (run-time plan, compiled plan, one or several
+// outputs per lane): first product rounded on its own, then acc + (a + b) * c as one fused multiply-add per tap pair.
+// Left to the compiler, "o * cc + (a + b) * c0" contracts into a fused multiply-add around EITHER product, depending on
+// the code around it -- one-ulp differences between the forms; dc_first() keeps the first product out of that choice.
+__device__ __forceinline__ v2f dc_first(v2f x, float c)
+{
+    v2f p = x * c;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ v2f dc_mac(v2f acc, v2f a, v2f b, float c) { return acc + (a + b) * c; }
+__device__ __forceinline__ v2f dc_cic(v2f e0, v2f o0, v2f e1, v2f o1, float c0, float c1)    // downconvert.cpp:453-454
+{
+    return dc_mac(dc_first(o0 + e1, c1), e0, o1, c0);
+}
+
 template <int L>
 __device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2f *yO, v2f *ylin, int nout,
                                          const int *prm, int t)
@@ -149,11 +165,11 @@ __device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2
             const int j = j0 + u * DC_T;
             if (j < nout) {
                 if (L == 3) {
-                    acc[u] = (E[j] + O[j + 1]) * c[0] + (O[j] + E[j + 1]) * c[1];
+                    acc[u] = dc_cic(E[j], O[j], E[j + 1], O[j + 1], c[0], c[1]);
                 } else {
-                    acc[u] = O[j + (H - 1) / 2] * cc;
+                    acc[u] = dc_first(O[j + (H - 1) / 2], cc);
 #pragma unroll
-                    for (int q = 0; q < NP; q++) acc[u] += (E[j + q] + E[j + H - q]) * c[q];
+                    for (int q = 0; q < NP; q++) acc[u] = dc_mac(acc[u], E[j + q], E[j + H - q], c[q]);
                 }
             }
         }
@@ -170,7 +186,21 @@ __device__ __forceinline__ void dc_stage(const v2f *E, const v2f *O, v2f *yE, v2
 }
 
 // The same stage for a complete tile of a compile-time plan: the output count is a constant, whole passes carry
-// no lane predicate, a lane's parity (hence its target half) is fixed and every LDS offset is an immediate.
+// no lane predicate and every LDS offset is an immediate.
+// A lane computes G ADJACENT outputs from one register window (round 3): outputs j .. j+G-1 read E[j .. j+H+G-1]
+// and G consecutive odd-half samples, as 16-byte LDS reads -- (H+G)/2 + G/2 wide reads instead of (H+2)*G narrow
+// ones.  The down-converter keeps the LDS pipe busy three quarters of its time (SQ_LDS_IDX_ACTIVE 74 %, DESIGN K2),
+// and the first two stages are two thirds of that traffic: 56 -> 40 B per output of an 11-tap stage at G = 2.  The
+// arithmetic per output -- centre product, then the pairs in tap order -- is what dc_stage does, so the words are too.
+#ifndef DC_STAGE_G4_MIN
+#define DC_STAGE_G4_MIN (1 << 30)         // four outputs per lane: measured no better than two (more registers), off
+#endif
+#ifndef DC_STAGE_G2_MIN
+#define DC_STAGE_G2_MIN 2
+#endif
+#ifndef DC_STAGE_G2_MAXL
+#define DC_STAGE_G2_MAXL 19
+#endif
 template <int L, int NOUT>
 __device__ __forceinline__ void dc_stage_full(const v2f *E, const v2f *O, v2f *yE, v2f *yO, bool last, int t)
 {
@@ -180,23 +210,78 @@ __device__ __forceinline__ void dc_stage_full(const v2f *E, const v2f *O, v2f *y
 #pragma unroll
     for (int q = 0; q < NP; q++) c[q] = dc_pair_coef(L, q);
     constexpr float cc = dc_centre_coef(L);
-    const v2f *e = E + t, *o = O + t;
-    auto fir = [&](int k) -> v2f {
-        const v2f *ek = e + k * DC_T, *ok = o + k * DC_T;
-        if (L == 3) return (ek[0] + ok[1]) * c[0] + (ok[0] + ek[1]) * c[1];
-        v2f acc = ok[(H - 1) / 2] * cc;
+    // (long half bands sit at the end of a cascade, a few outputs per tile: their window would cost more registers --
+    // spills at 128 -- than the LDS bytes it saves)
+    constexpr int G = NOUT >= DC_STAGE_G4_MIN ? 4 : ((NOUT >= DC_STAGE_G2_MIN && L <= DC_STAGE_G2_MAXL) ? 2 : 1);
+    if constexpr (G == 1) {
+        constexpr int PASSES = NOUT >= DC_T ? NOUT / DC_T : 1;
+        v2f r[PASSES];
+        if (NOUT >= DC_T || t < NOUT) {
 #pragma unroll
-        for (int q = 0; q < NP; q++) acc += (ek[q] + ek[H - q]) * c[q];
-        return acc;
-    };
-    v2f *y = last ? yE + t : ((t & 1) ? yO : yE) + (t >> 1);
-    constexpr int PASSES = NOUT >= DC_T ? NOUT / DC_T : 1;
-    v2f r[PASSES];
-    if (NOUT >= DC_T || t < NOUT) {
+            for (int k = 0; k < PASSES; k++) {
+                const v2f *e = E + t + k * DC_T, *o = O + t + k * DC_T;
+                if (L == 3) r[k] = dc_cic(e[0], o[0], e[1], o[1], c[0], c[1]);
+                else {
+                    v2f acc = dc_first(o[(H - 1) / 2], cc);
 #pragma unroll
-        for (int k = 0; k < PASSES; k++) r[k] = fir(k);
+                    for (int q = 0; q < NP; q++) acc = dc_mac(acc, e[q], e[H - q], c[q]);
+                    r[k] = acc;
+                }
+            }
+            v2f *y = last ? yE + t : ((t & 1) ? yO : yE) + (t >> 1);
 #pragma unroll
-        for (int k = 0; k < PASSES; k++) y[k * (last ? DC_T : DC_T / 2)] = r[k];
+            for (int k = 0; k < PASSES; k++) y[k * (last ? DC_T : DC_T / 2)] = r[k];
+        }
+    } else {
+        constexpr int PASSES = NOUT >= G * DC_T ? NOUT / (G * DC_T) : 1;
+        constexpr int NWIN = (L == 3 ? 1 : H) + G;                    // E[j .. j+NWIN-1]
+        constexpr int NB = (NWIN + 1) / 2;
+        constexpr int C0 = (L == 3) ? 0 : (H - 1) / 2;                // first odd-half sample: O[j + C0]
+        constexpr int OB0 = C0 & ~1, NOB = (C0 - OB0 + (L == 3 ? G + 1 : G) + 1) / 2;
+        v2f r[PASSES][G];
+        if (NOUT >= G * DC_T || G * t < NOUT) {
+#pragma unroll
+            for (int k = 0; k < PASSES; k++) {
+                const int j = G * t + G * DC_T * k;
+                v2f w[2 * NB], o[2 * NOB];
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const v4f v = *reinterpret_cast<const v4f *>(E + j + 2 * i);
+                    w[2 * i] = v2f{v.x, v.y}; w[2 * i + 1] = v2f{v.z, v.w};
+                }
+#pragma unroll
+                for (int i = 0; i < NOB; i++) {
+                    const v4f v = *reinterpret_cast<const v4f *>(O + j + OB0 + 2 * i);
+                    o[2 * i] = v2f{v.x, v.y}; o[2 * i + 1] = v2f{v.z, v.w};
+                }
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    if (L == 3) {
+                        r[k][u] = dc_cic(w[u], o[u], w[u + 1], o[u + 1], c[0], c[1]);
+                    } else {
+                        v2f acc = dc_first(o[C0 - OB0 + u], cc);
+#pragma unroll
+                        for (int q = 0; q < NP; q++) acc = dc_mac(acc, w[u + q], w[u + H - q], c[q]);
+                        r[k][u] = acc;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PASSES; k++) {
+                const int j = G * t + G * DC_T * k;
+                if (last) {
+#pragma unroll
+                    for (int u = 0; u < G; u += 2)
+                        *reinterpret_cast<v4f *>(yE + j + u) = v4f{r[k][u].x, r[k][u].y, r[k][u + 1].x, r[k][u + 1].y};
+                } else if constexpr (G == 4) {                        // (the halves start behind an odd history: 8-byte aligned)
+                    yE[(j >> 1)] = r[k][0]; yE[(j >> 1) + 1] = r[k][2];
+                    yO[(j >> 1)] = r[k][1]; yO[(j >> 1) + 1] = r[k][3];
+                } else {
+                    yE[j >> 1] = r[k][0];
+                    yO[j >> 1] = r[k][1];
+                }
+            }
+        }
     }
 }
 

