@@ -121,12 +121,14 @@ static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_strid
     a.channels = b->channels; a.n = n_per_channel;
     // segments: enough workgroups to fill the chip, each at least 32 tiles long (the longest blank
     // width is 4 tiles, the moving-sum reduction at a segment start another ~10-32 tiles' worth of reads)
-    long nseg = (1024 + b->channels - 1) / b->channels;
-    const long min_seg = 32 * 1024;
+    static const long want_wgs = getenv("CSDR_NB_WGS") ? atol(getenv("CSDR_NB_WGS")) : 2048;
+    long nseg = (want_wgs + b->channels - 1) / b->channels;
+    const long tile = noiseblank_tile();
+    const long min_seg = 32 * tile;
     if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
     if (nseg < 1) nseg = 1;
     long seg_len = (n_per_channel + nseg - 1) / nseg;
-    seg_len = (seg_len + 1023) / 1024 * 1024;
+    seg_len = (seg_len + tile - 1) / tile * tile;
     a.seg_len = (int)seg_len;
     a.nseg = (int)((n_per_channel + seg_len - 1) / seg_len);
     CSDR_HIP(noiseblank_launch(a, (hipStream_t)stream));

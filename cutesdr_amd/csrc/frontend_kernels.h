@@ -28,6 +28,7 @@ struct NbArgs {
                                         // multiple of 1024, >= 4 blank widths), one workgroup each
 };
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream);
+int noiseblank_tile();                 // samples per tile of the kernel: segment lengths are multiples of it
 
 // packets: [channels][npackets][pkt_len] bytes, pkt_len 1028 (16 bit, 256 samples) or 1444 (24 bit, 240);
 // out complex fp32 [channels][out_stride]; dc: optional [channels][2] doubles subtracted (I, Q)

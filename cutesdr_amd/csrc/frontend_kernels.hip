@@ -20,7 +20,17 @@
 namespace csdr {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int NB_T = 256, NB_PER = 4, NB_TILE = NB_T * NB_PER;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+// 512 threads and two rounds of workgroups: 2.60 ms against 2.79 with 256 threads and one round (256 receivers x 2^21;
+// 1024 threads 3.2 ms) -- fewer streams in flight per L2 at a time, for the sample leaving the moving-sum window
+#ifndef NB_THREADS
+#define NB_THREADS 512
+#endif
+#ifndef NB_PER_THREAD
+#define NB_PER_THREAD 4
+#endif
+constexpr int NB_T = NB_THREADS, NB_PER = NB_PER_THREAD, NB_TILE = NB_T * NB_PER;
+int noiseblank_tile() { return NB_TILE; }
 
 // Wave scans on the DPP network (row_shr 1, 2, 4, 8, then row_bcast 15 into rows 1, 3 and row_bcast 31 into rows
 // 2, 3; a step without a source lane reads the identity) instead of __shfl_up: a 64-bit shuffle is two
@@ -40,23 +50,24 @@ __device__ __forceinline__ double wave_incl_scan_add(double v, int)
 #undef NB_STEP
     return v;
 }
-constexpr long long NB_NEVER = -(1LL << 60);
-__device__ __forceinline__ long long wave_incl_scan_max(long long v, int)
+// trigger positions inside a tile are 32-bit offsets from the tile's first sample (NB_NEVER: none; an older trigger
+// is clamped to it -- the longest blank width is a few tiles)
+constexpr int NB_NEVER = -(1 << 30);
+__device__ __forceinline__ int wave_incl_scan_max(int v, int)
 {
-#define NB_STEP(C_, R_) { const long long o = (long long)nb_dpp64<C_, R_>((unsigned long long)v, (unsigned long long)NB_NEVER); v = o > v ? o : v; }
+#define NB_STEP(C_, R_) { const int o = __builtin_amdgcn_update_dpp(NB_NEVER, v, C_, R_, 0xf, false); v = o > v ? o : v; }
     NB_SCAN_STEPS(NB_STEP)
 #undef NB_STEP
     return v;
 }
 // the value of the lane in front (lane 0: NB_NEVER)
-__device__ __forceinline__ long long wave_prev_lane(long long v)
-{ return (long long)nb_dpp64<0x138, 0xf>((unsigned long long)v, (unsigned long long)NB_NEVER); }
+__device__ __forceinline__ int wave_prev_lane(int v) { return __builtin_amdgcn_update_dpp(NB_NEVER, v, 0x138, 0xf, 0xf, false); }
 
 __global__ __launch_bounds__(NB_T)
 void noiseblank_kernel(NbArgs a)
 {
     __shared__ double wsum[NB_T / 64];
-    __shared__ long long wmax[NB_T / 64];
+    __shared__ int wmax[NB_T / 64];
     const int ch = blockIdx.x / a.nseg, seg = blockIdx.x % a.nseg, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const NbChan C = a.chan[ch];                        // state at the start of the call (the last segment writes chan_next)
     const f2 *in = reinterpret_cast<const f2 *>(a.in) + (long)ch * a.in_stride;
@@ -103,9 +114,18 @@ void noiseblank_kernel(NbArgs a)
             // segment's last one): plain loads, no per-sample source selection or bounds.  (The same for datagram
             // input -- aligned pairs kept as raw words, decoded where consumed -- was measured: 201 VGPRs, slower.)
             if (!pk && b0 - M1 >= 0 && b0 - D1 >= 0 && b0 + NB_TILE <= seg_b) {
+                // a thread's four samples of each stream are 32 contiguous bytes: two 16-byte loads (the leaving and the
+                // delayed stream are only 8-byte aligned, which a global dwordx4 load accepts)
                 const f2 *p = in + b0 + (long)t * NB_PER;
+                static_assert(NB_PER % 2 == 0, "wide loads take sample pairs");
+                auto ld = [](const f2 *q, f2 *dst) {
 #pragma unroll
-                for (int k = 0; k < NB_PER; k++) { nx[k] = p[k]; nxo[k] = p[k - M1]; nxd[k] = p[k - D1]; }
+                    for (int k = 0; k < NB_PER; k += 2) {
+                        const f4u v = *reinterpret_cast<const f4u *>(q + k);
+                        dst[k] = f2{v.x, v.y}; dst[k + 1] = f2{v.z, v.w};
+                    }
+                };
+                ld(p, nx); ld(p - M1, nxo); ld(p - D1, nxd);
                 return;
             }
 #pragma unroll
@@ -121,9 +141,8 @@ void noiseblank_kernel(NbArgs a)
             double d[NB_PER], run = 0.0;
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                const long i = base + (long)t * NB_PER + k;
                 mag[k] = 0.f; d[k] = 0.0; xd[k] = f2{0.f, 0.f};
-                if (i < seg_b) {
+                if (base + (long)t * NB_PER + k < seg_b) {
                     const f2 x = nx[k], xo = nxo[k];
                     xd[k] = nxd[k];
                     mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
@@ -140,34 +159,38 @@ void noiseblank_kernel(NbArgs a)
             for (int q = 0; q < w; q++) off += wsum[q];
             double total = 0.0;
             for (int q = 0; q < NB_T / 64; q++) total += wsum[q];
-            // triggers and the position of the latest one at or before each sample
-            long long lt[NB_PER], runmax = -(1LL << 60);
+            // triggers and the position of the latest one at or before each sample, as offsets from `base`
+            const long left = seg_b - base, lead = seg_a - base;
+            const int nvalid = left < NB_TILE ? (int)left : NB_TILE, nskip = lead > 0 ? (int)lead : 0;
+            const long long ago = last - (long long)base;   // <= -1
+            const int last_rel = ago < (long long)NB_NEVER ? NB_NEVER : (int)ago;
+            int lt[NB_PER], runmax = NB_NEVER;
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                const long i = base + (long)t * NB_PER + k;
-                const bool trig = i < seg_b && (double)mag[k] * ratio > off + d[k];
-                if (trig) runmax = i;
+                const int r = t * NB_PER + k;
+                const bool trig = r < nvalid && (double)mag[k] * ratio > off + d[k];
+                if (trig) runmax = r;
                 lt[k] = runmax;
             }
-            const long long inclm = wave_incl_scan_max(runmax, lane);
+            const int inclm = wave_incl_scan_max(runmax, lane);
             if (lane == 63) wmax[w] = inclm;
             __syncthreads();
-            long long before = last;                       // latest trigger before this thread's samples
+            int before = last_rel;                          // latest trigger before this thread's samples
             for (int q = 0; q < w; q++) before = wmax[q] > before ? wmax[q] : before;
-            const long long upto = wave_prev_lane(inclm);
+            const int upto = wave_prev_lane(inclm);
             if (upto > before) before = upto;
-            long long tile_last = last;
+            int tile_last = NB_NEVER;
             for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                const long i = base + (long)t * NB_PER + k;
-                if (i < seg_b && i >= seg_a) {
-                    const long long l = lt[k] > before ? lt[k] : before;
-                    out[i] = (i - l < W) ? f2{0.f, 0.f} : xd[k];
+                const int r = t * NB_PER + k;
+                if (r < nvalid && r >= nskip) {
+                    const int l = lt[k] > before ? lt[k] : before;
+                    out[base + r] = (r - l < W) ? f2{0.f, 0.f} : xd[k];
                 }
             }
             S0 += total;
-            last = tile_last;
+            if (tile_last > NB_NEVER) last = (long long)base + tile_last;
             __syncthreads();                               // wsum / wmax reused by the next tile
         }
         if (t == 0 && last_seg) {
