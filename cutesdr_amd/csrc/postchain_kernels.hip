@@ -82,7 +82,7 @@ constexpr int PC_PLL_WARM_MAX = 192;     // longest warm-up of the overlapped PL
 constexpr float kNegBig = -1.0e30f;
 
 // what a workgroup's scans and broadcasts exchange through LDS (Wg<NW> holds a pointer to it)
-struct PcSync {
+struct alignas(16) PcSync {               // (16: the arrays behind it are read and written in 16-byte pieces)
     double xch[2][8][8];                 // per-wave totals of a workgroup scan; two banks used in turn, so that a scan
                                          // needs ONE workgroup barrier (the next scan's writes go to the other bank)
     double bc[4];                        // broadcast slot (thread 0 -> workgroup)
@@ -91,12 +91,12 @@ struct PcSync {
 
 struct PcLds {
     PcSync sy;
-    float2 dl[PH + PT];                  // [last dly_n inputs | tile]: delay line, then the AGC output in place
-    float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile]
-    float pk[PT + 16];                   // sliding peak, then the log gain argument
-    float w0[PT + PC_FIR_MAX + 17];      // [FIR history | tile] work array (audio / envelope / I)
-    float w1[PT + PC_FIR_MAX + 17];      // second work array (theta / Q)
-    float h0[PC_FIR_MAX + 17], h1[PC_FIR_MAX + 17]; // FIR taps of the active demodulator, reversed and zero padded:
+    alignas(16) float2 dl[PH + PT];                  // [last dly_n inputs | tile]: delay line, then the AGC output in place
+    alignas(16) float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile]
+    alignas(16) float pk[PT + 16];                   // sliding peak, then the log gain argument
+    alignas(16) float w0[PT + PC_FIR_MAX + 17];      // [FIR history | tile] work array (audio / envelope / I)
+    alignas(16) float w1[PT + PC_FIR_MAX + 17];      // second work array (theta / Q)
+    alignas(16) float h0[PC_FIR_MAX + 17], h1[PC_FIR_MAX + 17]; // FIR taps of the active demodulator, reversed and zero padded:
                                                     // h[4 + r] = tap ntaps-1-r (16-byte aligned rows of four)
     alignas(16) float w2[PT + 16];       // third work array (S-meter dB, attack average, PLL phase, |hp|)
     alignas(16) float rt[PC_RLEVELS][PC_NCHUNK];   // log table over the chunk maxima of the sliding peak
@@ -110,18 +110,18 @@ static_assert(sizeof(float) * PC_RLEVELS * PC_NCHUNK >= 8 * 512 && sizeof(float)
               "pll_overlap keeps one double per thread in PcLds::rt and in PcLds::w2");
 struct PreLds {
     PcSync sy;
-    float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile]
-    float pk[PT + 16];
-    float w2[PT + 16];
-    float rt[PC_RLEVELS][PC_NCHUNK];
+    alignas(16) float mg[PH + PT];                   // [last win_n-1 log-magnitudes | tile]
+    alignas(16) float pk[PT + 16];
+    alignas(16) float w2[PT + 16];
+    alignas(16) float rt[PC_RLEVELS][PC_NCHUNK];
 };
 
 // the squelch kernels' image (fm_squelch_*): a quarter of PcLds, so that eight of their workgroups share a CU
 struct SqLds {
     PcSync sy;
-    float w0[PT + PC_FIR_MAX + 17];      // [FIR history | tile] audio
-    float h0[PC_FIR_MAX + 17];           // high-pass taps, reversed and zero padded
-    float w2[PT + 16];                   // |hp| / audio being low-passed
+    alignas(16) float w0[PT + PC_FIR_MAX + 17];      // [FIR history | tile] audio
+    alignas(16) float h0[PC_FIR_MAX + 17];           // high-pass taps, reversed and zero padded
+    alignas(16) float w2[PT + 16];                   // |hp| / audio being low-passed
     double pw_sq[LCMAX + 1];
     double bq[BQ_TAB];
 };
