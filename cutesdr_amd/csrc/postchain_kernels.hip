@@ -1044,10 +1044,11 @@ void postchain_kernel(PcArgs a)
     // channel's workgroup usually has its CU to itself: nothing else would hide the HBM latency)
     constexpr bool kPrefetch = NW > 1;
     float2 nxt[LC];
+    float nxp[LC];                                        // PC_AGC_PRE: the tile's peaks travel with its samples
     const long total = (long)a.nbursts * a.burst;
     auto fetch = [&](long g0, int cnt) {
 #pragma unroll
-        for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < cnt) nxt[j] = in[g0 + i]; }
+        for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < cnt) { nxt[j] = in[g0 + i]; if (pre) nxp[j] = pkrow[g0 + i]; } }
     };
     if (kPrefetch && total > 0) fetch(0, a.burst < PT ? a.burst : PT);
 #ifdef PC_PROFILE
@@ -1067,7 +1068,7 @@ void postchain_kernel(PcArgs a)
             float2 *x = S.dl + ((do_agc && agc.on) ? D : 0);           // tile samples (AGC: behind the delay history)
             if (kPrefetch) {
 #pragma unroll
-                for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < n) x[i] = nxt[j]; }
+                for (int j = 0; j < LC; j++) { const int i = t + NT * j; if (i < n) { x[i] = nxt[j]; if (pre) S.pk[i] = nxp[j]; } }
                 const long gn = gi + n;                                // bursts are contiguous: the next tile follows
                 if (gn < total) {
                     const int left = a.burst - ((t0 + n) % a.burst);
@@ -1097,8 +1098,7 @@ void postchain_kernel(PcArgs a)
                     g.sync();
                 } else {
                   if (pre) {
-                    for (int i = t; i < n; i += NT) S.pk[i] = pkrow[gi + i];
-                    g.sync();
+                    if (!kPrefetch) { for (int i = t; i < n; i += NT) S.pk[i] = pkrow[gi + i]; g.sync(); }
                   } else {
                     float *mg = S.mg + W1;
                     for (int i = t; i < n; i += NT) {
