@@ -108,43 +108,90 @@ void noiseblank_kernel(NbArgs a)
         }
         // the three loads of a tile (new sample, the one leaving the window, the delayed one) are issued
         // one tile ahead, so that they are in flight while the current tile goes through its scans
-        f2 nx[NB_PER], nxo[NB_PER], nxd[NB_PER];
+        // pw: the prefetched tile -- three streams x NB_PER samples as fp32 pairs (slot s at 2*NB_PER*s), or, for a tile
+        // inside 24-bit datagrams, the raw words (new stream: 2 sample pairs = 6 words at 0; leaving and delayed stream:
+        // 3 pairs = 9 words at 6 and 15), decoded where they are consumed so that the fetch does not wait for itself
+        static_assert(NB_PER == 4, "the datagram fetch takes a thread's four samples as sample pairs");
+        unsigned pw[6 * NB_PER];
+        bool praw = false;                                  // uniform: what the last fetch left in pw
+        auto put = [&](int slot, int k, f2 v) { pw[2 * NB_PER * slot + 2 * k] = __float_as_uint(v.x); pw[2 * NB_PER * slot + 2 * k + 1] = __float_as_uint(v.y); };
         auto fetch = [&](long b0) {
+            const bool inside = b0 - M1 >= 0 && b0 - D1 >= 0 && b0 + NB_TILE <= seg_b;
+            praw = false;
+            if (pk && pkt_len == 1444 && inside) {
+                // 24-bit datagrams: a sample pair (even index) is 12 bytes at a 4-byte aligned offset and never straddles a
+                // datagram; a thread's four samples of a stream are two pairs (even start) or parts of three (odd start)
+                const unsigned i0 = (unsigned)(b0 + (long)t * NB_PER);
+                auto pair_words = [&](unsigned e, unsigned *dst) {   // e even
+                    const unsigned q = e / 240u, j = e - q * 240u;
+                    const unsigned *wp = reinterpret_cast<const unsigned *>(pk + (q * 1444u + 4u + 6u * j));
+                    dst[0] = wp[0]; dst[1] = wp[1]; dst[2] = wp[2];
+                };
+                pair_words(i0, pw); pair_words(i0 + 2u, pw + 3);
+                const unsigned eo = (i0 - (unsigned)M1) & ~1u, ed = (i0 - (unsigned)D1) & ~1u;
+                pair_words(eo, pw + 6); pair_words(eo + 2u, pw + 9); pair_words(eo + 4u, pw + 12);
+                pair_words(ed, pw + 15); pair_words(ed + 2u, pw + 18); pair_words(ed + 4u, pw + 21);
+                praw = true;
+                return;
+            }
             // a tile whose three streams lie inside this call's float rows (all but the first tiles of a call and a
-            // segment's last one): plain loads, no per-sample source selection or bounds.  (The same for datagram
-            // input -- aligned pairs kept as raw words, decoded where consumed -- was measured: 201 VGPRs, slower.)
-            if (!pk && b0 - M1 >= 0 && b0 - D1 >= 0 && b0 + NB_TILE <= seg_b) {
+            // segment's last one): plain loads, no per-sample source selection or bounds
+            if (!pk && inside) {
                 // a thread's four samples of each stream are 32 contiguous bytes: two 16-byte loads (the leaving and the
                 // delayed stream are only 8-byte aligned, which a global dwordx4 load accepts)
                 const f2 *p = in + b0 + (long)t * NB_PER;
                 static_assert(NB_PER % 2 == 0, "wide loads take sample pairs");
-                auto ld = [](const f2 *q, f2 *dst) {
+                auto ld = [&](const f2 *q, int slot) {
 #pragma unroll
                     for (int k = 0; k < NB_PER; k += 2) {
                         const f4u v = *reinterpret_cast<const f4u *>(q + k);
-                        dst[k] = f2{v.x, v.y}; dst[k + 1] = f2{v.z, v.w};
+                        put(slot, k, f2{v.x, v.y}); put(slot, k + 1, f2{v.z, v.w});
                     }
                 };
-                ld(p, nx); ld(p - M1, nxo); ld(p - D1, nxd);
+                ld(p, 0); ld(p - M1, 1); ld(p - D1, 2);
                 return;
             }
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 const long i = b0 + (long)t * NB_PER + k;
-                if (i < seg_b) { nx[k] = IN(i); nxo[k] = X(i - M1); nxd[k] = X(i - D1); }
+                if (i < seg_b) { put(0, k, IN(i)); put(1, k, X(i - M1)); put(2, k, X(i - D1)); }
+            }
+        };
+        // the prefetched tile as samples: new, leaving, delayed
+        auto take = [&](f2 *x, f2 *xo, f2 *xdl) {
+            if (praw) {
+                auto pair = [&](const unsigned *w, f2 &a, f2 &b) {
+                    const wf4 v = wire_pair_decode(wf4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), 0.f}, 1444);
+                    a = f2{v.x, v.y}; b = f2{v.z, v.w};
+                };
+                pair(pw, x[0], x[1]); pair(pw + 3, x[2], x[3]);
+                auto four = [&](const unsigned *w, bool odd, f2 *dst) {   // odd is uniform: each side decodes what it needs
+                    f2 skip;
+                    if (odd) { pair(w, skip, dst[0]); pair(w + 3, dst[1], dst[2]); pair(w + 6, dst[3], skip); }
+                    else { pair(w, dst[0], dst[1]); pair(w + 3, dst[2], dst[3]); }
+                };
+                four(pw + 6, M1 & 1, xo); four(pw + 15, D1 & 1, xdl);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) {
+                    x[k] = f2{__uint_as_float(pw[2 * k]), __uint_as_float(pw[2 * k + 1])};
+                    xo[k] = f2{__uint_as_float(pw[2 * NB_PER + 2 * k]), __uint_as_float(pw[2 * NB_PER + 2 * k + 1])};
+                    xdl[k] = f2{__uint_as_float(pw[4 * NB_PER + 2 * k]), __uint_as_float(pw[4 * NB_PER + 2 * k + 1])};
+                }
             }
         };
         fetch(first);
         for (long base = first; base < seg_b; base += NB_TILE) {
-            f2 xd[NB_PER];
+            f2 xd[NB_PER], xn[NB_PER], xl[NB_PER], xt[NB_PER];
             float mag[NB_PER];
             double d[NB_PER], run = 0.0;
+            take(xn, xl, xt);
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 mag[k] = 0.f; d[k] = 0.0; xd[k] = f2{0.f, 0.f};
                 if (base + (long)t * NB_PER + k < seg_b) {
-                    const f2 x = nx[k], xo = nxo[k];
-                    xd[k] = nxd[k];
+                    const f2 x = xn[k], xo = xl[k];
+                    xd[k] = xt[k];
                     mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
                     d[k] = (double)mag[k] - (double)fmaxf(fabsf(xo.x), fabsf(xo.y));
                 }

@@ -154,6 +154,16 @@ for name, nb in (("packets_chain_ms", None), ("packets_blanker_chain_ms", nbk)):
     for _ in range(30): chain_pk(nb)
     e1.record(); torch.cuda.synchronize()
     out[name] = round(e0.elapsed_time(e1) / 30, 3)
+# the same two with successive calls pipelined (csdr_demod_batch_set_pipelined): the blanker of call k+1 runs beside the
+# post-chain of call k
+b.set_pipelined(True)
+for name, nb in (("packets_chain_pipelined_ms", None), ("packets_blanker_chain_pipelined_ms", nbk)):
+    for _ in range(10): chain_pk(nb)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(30): chain_pk(nb)
+    e1.record(); b.flush(); torch.cuda.synchronize()
+    out[name] = round(e0.elapsed_time(e1) / 30, 3)
 out["packets_samples_per_channel"] = Tp
 out["channels"] = C
 out["hw_queues"] = os.environ["GPU_MAX_HW_QUEUES"]
