@@ -166,11 +166,14 @@ def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
             first[c] += len(want) // 1024
 
 
+@pytest.mark.parametrize("fs,width", [(2e6, 20.0), (2000200.0, 21.0)], ids=["odd-lags", "even-lags"])
 @pytest.mark.parametrize("pkt_len", [1028, 1444])
-def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len):
-    """The blanker kernel fed with datagrams (three decoded loads per sample: new, leaving the window, delayed)
-    against the oracle blanker on the oracle's unpacked samples: outputs are zeros or delayed copies of exactly
-    representable inputs, so every word must match, ragged calls included."""
+def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len, fs, width):
+    """The blanker kernel fed with datagrams (three streams per sample: new, leaving the window, delayed; a tile inside
+    24-bit datagrams takes them as sample pairs, so the parity of the two lags picks the decode -- 10 001 / 21 samples
+    at 2 MS/s, 10 002 / 22 at 2.0002 MS/s with a 21 us width) against the oracle blanker on the oracle's unpacked
+    samples: outputs are zeros or delayed copies of exactly representable inputs, so every word must match, ragged
+    calls included."""
     import ctypes as C_
     import cutesdr_amd as ca
     L = ca.lib()
@@ -178,7 +181,7 @@ def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len):
     L.csdr__noiseproc_batch_process_packets.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_int, C_.c_int, C_.c_void_p,
                                                         C_.c_longlong, C_.c_void_p]
     per = 240 if pkt_len == 1444 else 256
-    fs, Cn = 2e6, 3
+    Cn = 3
     rng = np.random.default_rng(11)
     counts = [3, 130, 1, 300, 77]                              # datagrams per call
     tot = sum(counts) * per
@@ -186,10 +189,10 @@ def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len):
     for xc in x:
         xc[rng.random(tot) < 2e-4] += 25000.0
     raw = np.stack([(_pack24 if pkt_len == 1444 else _pack16)(xc) for xc in x])
-    nb = ca.NoiseProcBatch(Cn); nb.setup(True, 25.0, 20.0, fs)
+    nb = ca.NoiseProcBatch(Cn); nb.setup(True, 25.0, width, fs)
     refs = []
     for c in range(Cn):
-        q = oracle.CNoiseProc(); q.SetupBlanker(True, 25.0, 20.0, fs); refs.append(q)
+        q = oracle.CNoiseProc(); q.SetupBlanker(True, 25.0, width, fs); refs.append(q)
     k0 = 0
     for npk in counts:
         part = np.ascontiguousarray(raw[:, k0:k0 + npk])
