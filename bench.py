@@ -227,6 +227,45 @@ def profiled_traffic():
     return None
 
 
+def live_traffic(timeout_s=150):
+    """HBM bytes per launch of the headline kernel MEASURED IN THIS RUN: two short child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in passes of their own, as the guide prescribes; never with a trace
+    domain), the kernel's per-launch means combined with the guide's gfx950 correction (FETCH_SIZE counts half of a
+    wide coalesced read).  Rank 0 at N = 1 only, after everything timed.  None when the profiler is not there or a
+    pass fails -- the caller then falls back to the committed profile (same-sources hash) or null."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="csdr_pmc_")
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu", "--no-check", "--no-secondary", "--steps", "5", "--warmup", "1"]
+            env = dict(os.environ, TMPDIR=out)
+            r = subprocess.run(cmd, cwd=out, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "fastfir_os2_kernel<14>" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if len(vals) < 3:
+                return None
+            means[counter] = sum(vals) / len(vals)
+        return {"bytes": (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0,
+                "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this script (KiB means per launch; "
+                          "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md)",
+                "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 # ---------------------------------------------------------------- CPU baseline
 def cpu_baseline(budget_s=18.0):
     """The fp64 CPU restatement (oracle, kind 'port') of the same filter on a bounded sample of the
@@ -805,7 +844,15 @@ def run_rank(args):
         extra["ranks"] = census
 
     if ctx.rank == 0:
-        traffic = profiled_traffic() if args.workload == "c3" else None
+        traffic = None
+        if args.workload == "c3":
+            live = live_traffic() if (ctx.world == 1 and not args.no_secondary and not os.environ.get("CSDR_BENCH_NO_PMC")) else None
+            if live:
+                traffic = live["bytes"]
+                extra["traffic_measured"] = {k: v for k, v in live.items() if k != "bytes"}
+            else:
+                traffic = profiled_traffic()
+                extra["traffic_measured"] = {"source": "profiles/traffic_latest.json (same kernel sources: hash checked)" if traffic else None}
         cpu = cpu_baseline() if (ctx.world == 1 and not args.no_cpu) else None
         print(json.dumps(result_line(ctx, chans, samples, args.steps, args.warmup, elapsed, kern_ms, traffic, cpu,
                                      args.workload, extra)), flush=True)
