@@ -156,8 +156,10 @@ for name, nb in (("packets_chain_ms", None), ("packets_blanker_chain_ms", nbk)):
     out[name] = round(e0.elapsed_time(e1) / 30, 3)
 # the same two with successive calls pipelined (csdr_demod_batch_set_pipelined): the blanker of call k+1 runs beside the
 # post-chain of call k
-b.set_pipelined(True)
-for name, nb in (("packets_chain_pipelined_ms", None), ("packets_blanker_chain_pipelined_ms", nbk)):
+# (only on request: the per-kernel averages of a profiled run should stay those of the strict chain)
+if os.environ.get("CSDR_BENCH_CHAIN_PIPE"):
+    b.set_pipelined(True)
+for name, nb in ((("packets_chain_pipelined_ms", None), ("packets_blanker_chain_pipelined_ms", nbk)) if os.environ.get("CSDR_BENCH_CHAIN_PIPE") else ()):
     for _ in range(10): chain_pk(nb)
     torch.cuda.synchronize()
     e0.record()
