@@ -765,7 +765,8 @@ class C4Workload:
                     "algorithmic_GBps_per_gpu": round((8.0 + 4.0 / 32.0) * n / ms / 1e6, 1),
                     "frac_of_hbm_peak": round((8.0 + 4.0 / 32.0) * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
         strict = one(False)
-        out = {"channels_per_gpu": self.C, "raw_samples_per_channel": self.T, "steps": steps}
+        out = {"channels_per_gpu": self.C, "raw_samples_per_channel": self.T, "steps": steps,
+               "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}    # (the pipelined mode needs more than HIP's default 4)
         out.update(one(True))
         out["strict"] = strict
         out["gather"] = self.gather()
