@@ -21,9 +21,18 @@ struct SpecCfg {
     static constexpr int N = 1 << LOG2N, T = N / 32, R0 = N / 1024, G = 32 / R0;
     static constexpr int LDS_DATA = N + 2 * (N / 32);
     static constexpr int LDS_BYTES = (LDS_DATA + 1024) * 8;
+    // the G columns (of the 1024 x R0 input matrix) a thread owns in pass A, in PAIRS that the workgroup's threads
+    // take side by side: column pair t + T k, k < G/2.  A wave's load of one element pair is then 64 x 16 contiguous
+    // bytes (with G consecutive columns per thread -- 64 bytes at N = 4096 -- every 128-byte line was consumed by four
+    // separate load instructions; measured: no difference in time, the line sat in L2 either way).
+#ifdef CSDR_SPEC_CONSECUTIVE_COLUMNS
+    static __device__ __forceinline__ int col(int t, int e) { return G * t + e; }
+#else
+    static __device__ __forceinline__ int col(int t, int e) { return 2 * (t + T * (e >> 1)) + (e & 1); }
+#endif
 };
 
-// forward (positive exponent) transform of the block held as x[e*R0+n1] <-> sample 1024*n1+G*t+e;
+// forward (positive exponent) transform of the block held as x[e*R0+n1] <-> sample 1024*n1+Cfg::col(t,e);
 // on return x[k2] is spectrum bin  (t>>5) + R0*((t&31) + 32*k2).
 // Three decimation-in-time passes with FMA-form butterflies (fft_core.hpp, as in the round-2 overlap-save kernel):
 // the bit-reversed input order a DIT network wants costs nothing -- pass A's samples sit in registers, passes B and C
@@ -51,9 +60,8 @@ __device__ __forceinline__ void fft_fwd_passes(v2f (&x)[32], v2f *lds, const v2f
     __syncthreads();                       // the previous transform's pass C has read its rows
     static_for<0, R0>([&](auto K0) {
         constexpr int k0 = K0.value;
-        const int base = lds_pad(1024 * k0 + G * t);
 #pragma unroll
-        for (int e = 0; e < G; e++) lds[base + e] = x[e * R0 + k0];      // 8-byte stores
+        for (int e = 0; e < G; e++) lds[lds_pad(1024 * k0 + Cfg::col(t, e))] = x[e * R0 + k0];   // (a column pair shares a 32-group: adjacent)
     });
     __syncthreads();
     // ---- pass B: radix-32 over the 32 points of column sn of sub-transform sb, twiddle W_1024^{sn k1}, in place.
@@ -148,7 +156,7 @@ void spectrum_kernel(SpectrumArgs a)
     for (int i = t; i < 1024; i += T) tw2[i] = reinterpret_cast<const v2f *>(a.tw2)[i];
     v2f w1[G];
 #pragma unroll
-    for (int e = 0; e < G; e++) w1[e] = reinterpret_cast<const v2f *>(a.tw1)[G * t + e];
+    for (int e = 0; e < G; e++) w1[e] = reinterpret_cast<const v2f *>(a.tw1)[Cfg::col(t, e)];
     const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
     float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
     int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
@@ -174,7 +182,7 @@ void spectrum_kernel(SpectrumArgs a)
 #pragma unroll
         for (int e = 0; e < G; e++)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; n1++) nxt[e * R0 + n1] = src[1024 * n1 + G * t + e];
+            for (int n1 = 0; n1 < R0; n1++) nxt[e * R0 + n1] = src[1024 * n1 + Cfg::col(t, e)];
     };
     if (f0 < f1) fetch(f0);
     for (int f = f0; f < f1; f++) {
@@ -183,7 +191,7 @@ void spectrum_kernel(SpectrumArgs a)
         for (int e = 0; e < G; e++)
 #pragma unroll
             for (int n1 = 0; n1 < R0; n1++) {
-                const int i = 1024 * n1 + G * t + e;
+                const int i = 1024 * n1 + Cfg::col(t, e);
                 const v2f s = nxt[e * R0 + n1];
                 const float w = a.win[i];
                 if (s.x > 32000.0f) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
@@ -221,6 +229,121 @@ void spectrum_kernel(SpectrumArgs a)
     if (over) a.overload[ch] = 1;
 }
 
+// ---- the 4096-point display spectrum (BASELINE config C1) as 256 threads x 16 points -----------------------------
+// spectrum_kernel<12> holds 32 points, the prefetched next frame and 32 running sums per thread: 300 registers, ONE
+// wave per SIMD, its vector unit 42 % busy with nothing to overlap a wave's own LDS and memory waits.  Sixteen points
+// per thread fit two waves per SIMD.  N = 16 x 16 x 16, three radix-16 DIT passes in registers:
+//   A  thread t: samples 256 a + t (one coalesced 8-byte load per point), DFT over a, twiddle W_N^{t ka}   -> (ka, t)
+//   B  thread (ka, c): points (ka, 16 b + c), DFT over b, twiddle W_256^{c kb}, back to the same 16 places
+//   C  thread (ka, kb): its 16 consecutive points, DFT over c                    -> bin ka + 16 kb + 256 kc
+// B -> C stays inside the quarter-wave that owns ka: no workgroup barrier.  Rows of 16 points are 18 apart in LDS
+// (pass C reads them as 16-byte pieces without bank conflicts).
+__device__ __forceinline__ int pad16(int pos) { return pos + ((pos >> 4) << 1); }
+constexpr int SPEC16_LDS = (4096 + 2 * 256) * 8;
+#ifndef CSDR_SPEC16_WAVES
+#define CSDR_SPEC16_WAVES 1
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CSDR_SPEC16_WAVES)))
+void spectrum16_kernel(SpectrumArgs a)
+{
+    constexpr int N = 4096, T = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+    const int t = threadIdx.x, ch = blockIdx.x / a.nparts, part = blockIdx.x % a.nparts;
+    const int f0 = (int)((long)a.nframes * part / a.nparts), f1 = (int)((long)a.nframes * (part + 1) / a.nparts);
+    const v2f *tw1 = reinterpret_cast<const v2f *>(a.tw1);           // W_N^n, n < 1024
+    const v2f wA = tw1[t], wB = tw1[16 * (t & 15)];                  // W_N^t and W_256^c
+    const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
+    float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
+    int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    total += f0;                                              // counters at this group's first frame
+    ave_count = ave_count + f0 < a.ave_size ? ave_count + f0 : (ave_count > a.ave_size ? ave_count : a.ave_size);
+    int over = 0;
+    int tt = t;
+    asm volatile("" : "+v"(tt));              // keep the scattered addresses out of LICM's hands
+    const int kbin = (tt >> 4) + 16 * (tt & 15);              // this thread's bins: kbin + 256 kc
+    float sm[16], wn[16];
+    static_for<0, 16>([&](auto Rr) {
+        constexpr int r = Rr.value;
+        sm[r] = a.nparts == 1 ? sum[((kbin + 256 * r) + N / 2) & (N - 1)] : 0.f;   // display order, fft.cpp:564-589
+        wn[r] = a.win[256 * r + t];
+    });
+    v2f nxt[16];
+    auto fetch = [&](int f) {
+        const v2f *src = in + (long)f * N + t;
+#pragma unroll
+        for (int q = 0; q < 16; q++) nxt[q] = src[256 * q];
+    };
+    if (f0 < f1) fetch(f0);
+    for (int f = f0; f < f1; f++) {
+        v2f x[16];
+        static_for<0, 16>([&](auto Q) {
+            constexpr int q = Q.value;
+            const v2f s_ = nxt[q];
+            if (s_.x > 32000.0f) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
+            x[bitrev<16>(q)] = v2f{wn[q] * s_.y, wn[q] * s_.x};    // I/Q swapped, fft.cpp:280-281
+        });
+        if (f + 1 < f1) fetch(f + 1);
+        const float prev_count = (float)ave_count;
+        total++;                                                  // CpxFFT counters, fft.cpp:515-517
+        if (ave_count < a.ave_size) ave_count++;
+        // ---- pass A
+        dft_dit<16, +1>(x);
+        {
+            v2f pw[16];
+            twiddle_powers<16>(opaque(wA), pw);
+            static_for<1, 16>([&](auto K) { x[K.value] = cmul(x[K.value], pw[K.value]); });
+        }
+        __syncthreads();                       // the previous frame's pass C has read its rows
+        static_for<0, 16>([&](auto K) { lds[pad16(256 * K.value + t)] = x[K.value]; });
+        __syncthreads();
+        // ---- pass B: (ka, c) = (t >> 4, t & 15)
+        {
+            v2f *col = lds + pad16(256 * (t >> 4)) + (t & 15);                   // point b at col[18 b]
+            static_for<0, 16>([&](auto B) { x[bitrev<16>(B.value)] = lds_ld8(col + 18 * B.value); });
+            dft_dit<16, +1>(x);
+            v2f pw[16];
+            twiddle_powers<16>(opaque(wB), pw);
+            static_for<1, 16>([&](auto K) { x[K.value] = cmul(x[K.value], pw[K.value]); });
+            static_for<0, 16>([&](auto K) { lds_st8(col + 18 * K.value, x[K.value]); });
+        }
+        // B -> C stays inside the sixteen threads that own ka
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- pass C: the 16 consecutive points of row t
+        {
+            const v2f *row = lds + 18 * t;
+            static_for<0, 8>([&](auto J) {
+                const v4f v = *reinterpret_cast<const v4f *>(row + 2 * J.value);
+                x[bitrev<16>(2 * J.value)] = v2f{v.x, v.y};
+                x[bitrev<16>(2 * J.value + 1)] = v2f{v.z, v.w};
+            });
+            dft_dit<16, +1>(x);
+        }
+        static_for<0, 16>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const float p = x[r].x * x[r].x + x[r].y * x[r].y;
+            if (total <= a.ave_size) sm[r] = sm[r] + p;
+            else sm[r] = sm[r] - sm[r] / prev_count + p;          // minus the previous mean (fft.cpp:570-574)
+        });
+    }
+    if (a.nparts > 1) {
+        float *dst = a.part + ((long)ch * a.nparts + part) * N;
+        static_for<0, 16>([&](auto Rr) { dst[((kbin + 256 * Rr.value) + N / 2) & (N - 1)] = sm[Rr.value]; });
+    } else if (a.nframes > 0) {
+        static_for<0, 16>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const int j = ((kbin + 256 * r) + N / 2) & (N - 1);
+            const float m = sm[r] / (float)ave_count;
+            sum[j] = sm[r]; pwr[j] = m;
+            ave[j] = (float)((double)log10f(m + a.kc) + a.kb);
+        });
+    }
+    if (t == 0 && a.nparts == 1) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }
+    if (over) a.overload[ch] = 1;
+}
+
 // plain transform: out[k] = sum_n in[n] e^{sign j 2 pi n k / N}; sign=-1 via conjugation
 template <int LOG2N>
 __global__ __launch_bounds__(SpecCfg<LOG2N>::T)
@@ -235,14 +358,14 @@ void fft_plain_kernel(const v2f *in, v2f *out, const v2f *tw1g, const v2f *tw2g,
     for (int i = t; i < 1024; i += T) tw2[i] = tw2g[i];
     v2f w1[G];
 #pragma unroll
-    for (int e = 0; e < G; e++) w1[e] = tw1g[G * t + e];
+    for (int e = 0; e < G; e++) w1[e] = tw1g[Cfg::col(t, e)];
     const float cj = sign > 0 ? 1.0f : -1.0f;
     v2f x[32];
 #pragma unroll
     for (int e = 0; e < G; e++)
 #pragma unroll
         for (int n1 = 0; n1 < R0; n1++) {
-            const v2f s = in[1024 * n1 + G * t + e];
+            const v2f s = in[1024 * n1 + Cfg::col(t, e)];
             x[e * R0 + n1] = v2f{s.x, cj * s.y};
         }
     __syncthreads();
@@ -305,7 +428,11 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spectrum_kernel<LOG2N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
+    static const bool wide = !(getenv("CSDR_SPEC16") && atoi(getenv("CSDR_SPEC16")) == 0);
+    if (LOG2N == 12 && wide)
+        hipLaunchKernelGGL(spectrum16_kernel, dim3(a.channels * a.nparts), dim3(256), SPEC16_LDS, s, a);
+    else
+        hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
     if (a.nparts > 1) {
         hipLaunchKernelGGL(spectrum_alpha_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
         hipLaunchKernelGGL(spectrum_combine_kernel, dim3(Cfg::N / 256, a.channels), dim3(256), 0, s, a, (int)Cfg::N);
