@@ -268,6 +268,8 @@ void spectrum16_kernel(SpectrumArgs a)
         sm[r] = a.nparts == 1 ? sum[((kbin + 256 * r) + N / 2) & (N - 1)] : 0.f;   // display order, fft.cpp:564-589
         wn[r] = a.win[256 * r + t];
     });
+    v2f pwA[16];                              // W_N^{t ka}: resident (30 registers; pass B's are recomputed per frame)
+    twiddle_powers<16>(wA, pwA);
     v2f nxt[16];
     auto fetch = [&](int f) {
         const v2f *src = in + (long)f * N + t;
@@ -289,11 +291,7 @@ void spectrum16_kernel(SpectrumArgs a)
         if (ave_count < a.ave_size) ave_count++;
         // ---- pass A
         dft_dit<16, +1>(x);
-        {
-            v2f pw[16];
-            twiddle_powers<16>(opaque(wA), pw);
-            static_for<1, 16>([&](auto K) { x[K.value] = cmul(x[K.value], pw[K.value]); });
-        }
+        static_for<1, 16>([&](auto K) { x[K.value] = cmul(x[K.value], pwA[K.value]); });
         __syncthreads();                       // the previous frame's pass C has read its rows
         static_for<0, 16>([&](auto K) { lds[pad16(256 * K.value + t)] = x[K.value]; });
         __syncthreads();
