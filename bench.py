@@ -391,7 +391,7 @@ def spectrum_c1(torch, ca, ctx, x, with_cpu):
     bins = C * frames * N
     moved = bins * 8.0 + C * N * 4.0
     out = {"config": "C1: 4096-pt CFft display spectrum (Hann, ave 1) @2 MSPS, %d channels x %d frames per launch" % (C, frames),
-           "kernel": "csdr::spectrum_kernel<12> (+ its frame-group combine)", "ms_per_launch": round(ms, 4),
+           "kernel": "csdr::spectrum16_kernel (4096 points as 256 threads x 16; + its frame-group combine)", "ms_per_launch": round(ms, 4),
            "MSamples_per_s": round(bins / ms / 1e3, 1),
            "algorithmic_GBps_at_12B_per_bin": round(bins * 12.0 / ms / 1e6, 1),
            "frac_at_12B_per_bin": round(bins * 12.0 / ms / 1e6 / HBM_PEAK_GBS, 4),

@@ -35,7 +35,7 @@ for l in open(os.path.join(out, "chain.log")):
 npk = (T // 240) // 8 * 8
 known = {   # kernel substring -> (what, algorithmic bytes per launch of the stand-alone measurement, grid predicate)
     "downconv_kernel": ("K2 alone: 256 ch x 2^21 in, /32 out", C * T * (8 + 8 / 32.0)),
-    "spectrum_kernel<12>": ("K3: 256 ch x 512 frames x 4096, 8 B in + 4 B out per bin (SURVEY 8d); the kernel keeps the running sums in "
+    "spectrum16_kernel": ("K3: 256 ch x 512 frames x 4096, 8 B in + 4 B out per bin (SURVEY 8d); the kernel keeps the running sums in "
                             "registers and writes only the last frame's bels, so its traffic is the 8 B in", C * 512 * 4096 * 12),
     "noiseblank_kernel": ("K6 blanker: 256 ch x 2^21, 8 B in + 8 B out", C * T * 16),
     "unpack_kernel": ("K6 unpack 24 bit: 6 B in + 8 B out per sample", C * (T // 240) * 240 * 14),
