@@ -67,6 +67,9 @@ for sub, (what, alg) in known.items():
     if "hbm_bytes_fetch_doubled" in e:
         e["traffic_over_algorithmic_fetch_doubled"] = round(e["hbm_bytes_fetch_doubled"] / alg, 3)
         e["traffic_over_algorithmic_as_counted"] = round(e["hbm_bytes_as_counted"] / alg, 3)
+        if e["avg_us"]:     # the fraction on the bytes the counters saw move (K3 writes a third of what SURVEY 8d prices)
+            e["GBps_on_counted_traffic"] = round(e["hbm_bytes_fetch_doubled"] / (e["avg_us"] * 1e-6) / 1e9, 1)
+            e["frac_of_8TBps_on_counted_traffic"] = round(e["hbm_bytes_fetch_doubled"] / (e["avg_us"] * 1e-6) / 8e12, 4)
 json.dump({"tag": tag, "command": "tools/collect_chain_profile.sh: rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in their own passes, each around python3 tools/bench_chain.py",
            "bench_chain_line_under_profiler": line, "kernels": kern,
            "notes": "FETCH_SIZE / WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE counts half the bytes of a wide (16 B per lane) coalesced streaming "
@@ -74,4 +77,4 @@ json.dump({"tag": tag, "command": "tools/collect_chain_profile.sh: rocprofv3 --k
                     "exactly known byte count of each stand-alone measurement."},
           open("profiles/%s_chain_summary.json" % tag, "w"), indent=1)
 for k, e in kern.items():
-    if "standalone" in e: print(k, {x: e[x] for x in e if x in ("avg_us", "achieved_GBps", "frac_of_8TBps", "traffic_over_algorithmic_fetch_doubled", "traffic_over_algorithmic_as_counted")})
+    if "standalone" in e: print(k, {x: e[x] for x in e if x in ("avg_us", "achieved_GBps", "frac_of_8TBps", "frac_of_8TBps_on_counted_traffic", "traffic_over_algorithmic_fetch_doubled", "traffic_over_algorithmic_as_counted")})
