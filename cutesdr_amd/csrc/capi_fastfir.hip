@@ -28,7 +28,8 @@ struct csdr_fastfir_batch {
     float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
     int hist_cur;                     // which half holds the previous call's tail
     int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
-    int variant;                      // 0: generic kernel (every size); 2: pipelined build (N = 16384, fastfir2_kernels.hip)
+    int variant;                      // 0: generic kernel (every size); 2: pipelined build (N = 16384, fastfir2_kernels.hip);
+                                      // 3: 128 threads x 16 points (N = 2048, fastfir16_kernels.hip)
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
@@ -50,6 +51,10 @@ static void build_perm(csdr_fastfir_batch *b)
         for (int j = 0; j < 16; j++)
             for (int t = 0; t < T; t++)
                 for (int e = 0; e < 2; e++) b->perm2[(j * T + t) * 2 + e] = fastfir2_bin_of(t, j, e);
+    }
+    if (b->n == 2048) {
+        b->perm2.resize(b->n);
+        for (int i = 0; i < b->n; i++) b->perm2[i] = fastfir16_bin_of(i);
     }
 }
 
@@ -93,7 +98,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
         // N = 16384 runs the software-pipelined build; CSDR_FASTFIR_VARIANT=0
         // forces the generic kernel (diagnostics; launches it cannot take fall back to the generic one anyway)
         const char *v = getenv("CSDR_FASTFIR_VARIANT");
-        b->variant = (fft_size == 16384 && !(v && atoi(v) == 0)) ? 2 : 0;
+        b->variant = (v && atoi(v) == 0) ? 0 : (fft_size == 16384 ? 2 : (fft_size == 2048 ? 3 : 0));
     }
     b->d_h = b->d_h2 = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
@@ -110,7 +115,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
             tw2[2 * (k * 32 + i)] = (float)std::cos(a); tw2[2 * (k * 32 + i) + 1] = (float)std::sin(a);
         }
     bool ok = hipMalloc((void **)&b->d_h, hbytes) == hipSuccess &&
-              (fft_size != 16384 || (hipMalloc((void **)&b->d_h2, hbytes) == hipSuccess && hipMemset(b->d_h2, 0, hbytes) == hipSuccess)) &&
+              ((fft_size != 16384 && fft_size != 2048) || (hipMalloc((void **)&b->d_h2, hbytes) == hipSuccess && hipMemset(b->d_h2, 0, hbytes) == hipSuccess)) &&
               hipMalloc((void **)&b->d_hist, histbytes) == hipSuccess &&
               hipMalloc((void **)&b->d_tw1, 8192) == hipSuccess &&
               hipMalloc((void **)&b->d_tw2, 8192) == hipSuccess &&
@@ -239,7 +244,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
         // whose workgroups fill whole rounds of the resident slots best (CUs of the device x workgroups per CU
         // at this size: the LDS block is N*8.5 bytes), fewest runs on a tie -- longer runs re-read
         // less overlap.  C3 (256 channels, N=16384): one run of 64 blocks per channel.
-        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : 8));
+        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : (b->variant == 3 ? 6 : 8)));
         const long slots = (long)b->cus * per_cu;
         long best_runs = 1; double best_eff = -1.0;
         const long max_runs = std::min<long>(a.nblocks, std::max<long>(1, 4 * ((slots + b->channels - 1) / b->channels)));
@@ -254,7 +259,10 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.blocks_per_run = blocks_per_wg;
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
     a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
-    if (b->variant >= 2) {
+    if (b->variant == 3) {
+        a.h = (const v4f_h *)b->d_h2;         // its own H order
+        CSDR_HIP(fastfir16_launch(a, s));
+    } else if (b->variant >= 2) {
         a.h = (const v4f_h *)b->d_h2;         // its own H order
         CSDR_HIP(fastfir2_launch(a, s));     // any block count (pairs, then a single trailing block)
     }

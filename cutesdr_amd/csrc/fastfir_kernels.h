@@ -34,4 +34,8 @@ hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream);
 // natural-order spectrum bin of H slot (float4 index j*512 + t, half e) of that kernel
 int fastfir2_bin_of(int t, int j, int e);
 
+// N = 2048 as 128 threads x 16 points (fastfir16_kernels.hip): H in its own order, slot i <-> bin fastfir16_bin_of(i)
+hipError_t fastfir16_launch(const FastFirArgs &a, hipStream_t stream);
+int fastfir16_bin_of(int slot);
+
 }  // namespace csdr
