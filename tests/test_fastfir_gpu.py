@@ -33,10 +33,12 @@ def test_batch_matches_oracle_shared_filter(oracle, n):
         assert err <= TOL * np.abs(x[c]).max(), (c, err)
 
 
-def test_batch_distinct_filters_and_response(oracle):
+@pytest.mark.parametrize("n", [2048, 16384])
+def test_batch_distinct_filters_and_response(oracle, n):
+    """(both sizes that have a kernel of their own: 16384 the pipelined one, 2048 the 128-thread one)"""
     import cutesdr_amd as ca
-    n, C, fs = 16384, 4, 62500.0
-    T = 3 * (n // 2)
+    C, fs = 4, 62500.0
+    T = 3 * (n // 2) if n == 16384 else 19 * (n // 2)
     x = np.stack([tones_plus_noise(c, T, fs, [500.0 * (c + 1), -12000.0]) for c in range(C)])
     b = ca.FastFirBatch(C, n)
     b.setup(-5000, 5000, 0, fs)
@@ -52,9 +54,10 @@ def test_batch_distinct_filters_and_response(oracle):
         assert np.abs(y[c] - ref).max() <= TOL * np.abs(x[c]).max()
 
 
-def test_batch_streaming_state_and_run_lengths(oracle):
+@pytest.mark.parametrize("n", [2048, 16384])
+def test_batch_streaming_state_and_run_lengths(oracle, n):
     import cutesdr_amd as ca
-    n, C, fs = 16384, 2, 62500.0
+    C, fs = 2, 62500.0
     L = n // 2
     T = 7 * L
     x = np.stack([tones_plus_noise(10 + c, T, fs, [2000.0, 9000.0]) for c in range(C)])
