@@ -1097,31 +1097,31 @@ void postchain_kernel(PcArgs a)
                     for (int i = t; i < n; i += NT) { x[i].x *= gm; x[i].y *= gm; }
                     g.sync();
                 } else {
-                  if (pre) {
-                    if (!kPrefetch) { for (int i = t; i < n; i += NT) S.pk[i] = pkrow[gi + i]; g.sync(); }
-                  } else {
-                    float *mg = S.mg + W1;
-                    for (int i = t; i < n; i += NT) {
-                        float m = fabsf(x[i].x);
-                        if (!agc_real) { const float mi = fabsf(x[i].y); if (mi > m) m = mi; }
-                        mg[i] = log10f(m + 3.2767e-4f) - 4.51543987f;
-                    }
-                    g.sync();
-                    // sliding maximum: pk[i] = max E[i .. i+W1], E = [W1 history | tile] = S.mg
-                    PC_TICK(2);
-                    sliding_max(g, S, W1, n);
-                    PC_TICK(3);
-                    // the last W1 magnitudes are the next tile's history: read all, one barrier, write all
-                    {
-                        float keepm[PH / NT];
-#pragma unroll
-                        for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) keepm[j] = S.mg[n + i]; }
+                    if (pre) {
+                        if (!kPrefetch) { for (int i = t; i < n; i += NT) S.pk[i] = pkrow[gi + i]; g.sync(); }
+                    } else {
+                        float *mg = S.mg + W1;
+                        for (int i = t; i < n; i += NT) {
+                            float m = fabsf(x[i].x);
+                            if (!agc_real) { const float mi = fabsf(x[i].y); if (mi > m) m = mi; }
+                            mg[i] = log10f(m + 3.2767e-4f) - 4.51543987f;
+                        }
                         g.sync();
+                        // sliding maximum: pk[i] = max E[i .. i+W1], E = [W1 history | tile] = S.mg
+                        PC_TICK(2);
+                        sliding_max(g, S, W1, n);
+                        PC_TICK(3);
+                        // the last W1 magnitudes are the next tile's history: read all, one barrier, write all
+                        {
+                            float keepm[PH / NT];
 #pragma unroll
-                        for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) S.mg[i] = keepm[j]; }
-                        g.sync();
+                            for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) keepm[j] = S.mg[n + i]; }
+                            g.sync();
+#pragma unroll
+                            for (int j = 0; j < PH / NT; j++) { const int i = t + NT * j; if (i < W1) S.mg[i] = keepm[j]; }
+                            g.sync();
+                        }
                     }
-                  }
                     PC_TICK(4);
                     // attack / decay averagers -> log gain argument max(att, dec) per sample in S.pk
                     {
