@@ -33,6 +33,25 @@ def test_batch_matches_oracle_shared_filter(oracle, n):
         assert err <= TOL * np.abs(x[c]).max(), (c, err)
 
 
+@pytest.mark.parametrize("n,C,hops", [(2048, 16, 37), (2048, 24, 5), (16384, 8, 5)])
+def test_batch_channel_counts_that_are_multiples_of_eight(oracle, n, C, hops):
+    """With eight channels or a multiple, the runs of a channel are laid over the workgroup index so that they share
+    an XCD (the other branch of the kernels' index mapping); a prime hop count gives ragged runs."""
+    import cutesdr_amd as ca
+    fs = 62500.0
+    T = hops * (n // 2)
+    x = np.stack([tones_plus_noise(40 + c, T, fs, [700.0 * (c % 5 + 1), -4100.0, 15000.0]) for c in range(C)])
+    b = ca.FastFirBatch(C, n)
+    b.setup(-5000, 5000, 0, fs)
+    for c in range(0, C, 3):
+        b.setup(200 + 10 * c, 3000 + 10 * c, 0, fs, channel=c)          # some channels with a filter of their own
+    y = b.process(x)
+    for c in range(C):
+        cut = (200 + 10 * c, 3000 + 10 * c, 0, fs) if c % 3 == 0 else (-5000, 5000, 0, fs)
+        ref = oracle_filter(oracle, n, x[c], cut)
+        assert np.abs(y[c] - ref).max() <= TOL * np.abs(x[c]).max(), c
+
+
 @pytest.mark.parametrize("n", [2048, 16384])
 def test_batch_distinct_filters_and_response(oracle, n):
     """(both sizes that have a kernel of their own: 16384 the pipelined one, 2048 the 128-thread one)"""
