@@ -230,13 +230,15 @@ def test_waterfall_line_on_device_for_all_channels(oracle, invert):
         assert not ov.any()
 
 
+@pytest.mark.parametrize("n", [2048, 4096])
 @pytest.mark.parametrize("ave", [1, 3, 10])
-def test_fft_batch_many_frames_are_split_into_groups(oracle, ave):
+def test_fft_batch_many_frames_are_split_into_groups(oracle, ave, n):
     """Calls with many frames on few channels cut each channel's frames into groups (one workgroup
     each, running sum folded afterwards as a linear map): same spectrum as the frame-by-frame oracle,
-    across two calls (warm-up of the average inside the first, steady state in the second)."""
+    across two calls (warm-up of the average inside the first, steady state in the second).  (2048: the 64-thread
+    kernel; 4096: the 256-thread one.)"""
     import cutesdr_amd as ca
-    n, C, frames, fs = 2048, 2, 72, 2e6
+    C, frames, fs = 2, 72, 2e6
     b = ca.FftBatch(C)
     b.set_params(n, False, 0.0, fs); b.set_ave(ave)
     refs = []
