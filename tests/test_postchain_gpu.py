@@ -544,11 +544,11 @@ def test_agc_peaks_ahead_of_the_walk_give_the_same_words(tmp_path, fastfir_n):
     assert a.shape == w.shape and np.array_equal(a.view(np.uint32), w.view(np.uint32))
 
 
-def _fm_unlocked_words(path, fastfir_n):
+def _fm_unlocked_words(path, fastfir_n, fs=2e6):
     """FM receivers that hear noise only, a carrier at the edge of lock, and a clean carrier; squelch open -> path"""
     import cutesdr_amd as ca
-    fs, C = 2e6, 6
-    n = 19968 * (16 if fastfir_n == 2048 else 72)
+    C = 6
+    n = 19968 * (16 if fastfir_n == 2048 else 72) * (4 if fs > 5e6 else 1)
     b = ca.DemodBatch(C, fastfir_n); b.set_input_rate(fs)
     for c in range(C):
         b.set_demod(c, 2, info(ca, SquelchValue=-160))            # threshold far up: the squelch stays open
@@ -565,18 +565,19 @@ def _fm_unlocked_words(path, fastfir_n):
     return per
 
 
-@pytest.mark.parametrize("fastfir_n", [2048, 16384])
-def test_fm_unlocked_pll_overlapped_walks_equal_the_sequential_walk(tmp_path, fastfir_n):
+@pytest.mark.parametrize("fastfir_n,fs", [(2048, 2e6), (16384, 2e6), (2048, 10e6)], ids=["2048-62k5", "16384-62k5", "2048-78k125"])
+def test_fm_unlocked_pll_overlapped_walks_equal_the_sequential_walk(tmp_path, fastfir_n, fs):
     """A tile of CFmDemod's PLL (fmdemod.cpp:166-177) that is not locked -- an idle channel, a carrier in the noise --
     cannot be solved as one linear system; it used to fall to one thread walking 1024 samples.  pll_overlap runs the
     exact recurrence on every thread over its own samples, started early from a zero state, and checks that neighbours
     meet to 1e-9 turns.  Its audio must be the sequential walk's (CSDR_PLL_OVERLAP=0, child process) to 1e-6 of full
-    scale on every sample: noise only, weak and strong carriers, two calls."""
+    scale on every sample: noise only, weak and strong carriers, two calls; at the two output rates of the BASELINE
+    configs (62.5 kS/s: spectral radius 0.47, 48 samples of warm-up; 78.125 kS/s from a 10 MSPS radio: 0.56, 62)."""
     import subprocess, sys, os
-    got = _fm_unlocked_words(str(tmp_path / "overlap.npy"), fastfir_n)
+    got = _fm_unlocked_words(str(tmp_path / "overlap.npy"), fastfir_n, fs)
     assert all(np.abs(g).max() > 100.0 for g in got)                 # squelch open everywhere: there is audio to compare
-    code = ("import sys; sys.path.insert(0, %r); import test_postchain_gpu as T; T._fm_unlocked_words(%r, %d)"
-            % (os.path.dirname(__file__), str(tmp_path / "seq.npy"), fastfir_n))
+    code = ("import sys; sys.path.insert(0, %r); import test_postchain_gpu as T; T._fm_unlocked_words(%r, %d, %r)"
+            % (os.path.dirname(__file__), str(tmp_path / "seq.npy"), fastfir_n, fs))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSDR_PLL_OVERLAP="0"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     a, w = np.load(tmp_path / "overlap.npy"), np.load(tmp_path / "seq.npy")
