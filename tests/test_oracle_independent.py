@@ -1,0 +1,453 @@
+"""The oracle against a SECOND, independent statement of the reference's algorithms (tests/indep_ref.py: scipy / numpy
+library routines and closed forms, written from the reference's source a second time in another shape).
+
+The reference ships no vectors and cannot be built here, so the C oracle's transcription is pinned by seven survey
+anchors only (test_oracle_anchors.py).  These tests shrink what remains unpinned: for every stage below, two
+transcriptions made independently must agree to rounding.  Stage by stage first, then composed into the whole
+CDemodulator chain.  CPU only."""
+import math
+import os
+import re
+import numpy as np
+import pytest
+from scipy import signal
+
+import indep_ref as ind
+
+HDR = open(os.path.join(os.path.dirname(__file__), "..", "include", "csdr_hb_taps.h")).read()
+
+
+def _hb_tables():
+    lens = [int(v) for v in re.search(r"csdr_hb_len\[[^\]]*\]\s*=\s*\{([^}]*)\}", HDR).group(1).split(",") if v.strip()]
+    even = {}
+    for L in lens:
+        m = re.search(r"/\* HB%d \*/ \{([^}]*)\}" % L, HDR)
+        even[L] = [float(v) for v in m.group(1).split(",") if v.strip()]
+    diff = lambda s: (lambda a: float(a[0]) - float(a[1]))(re.fullmatch(r"\(?\s*([0-9.]+)\s*-\s*([0-9.]+)\s*\)?", s.strip()).groups())
+    maxbw = [diff(v) for v in re.search(r"csdr_hb_maxbw\[[^\]]*\]\s*=\s*\{([^}]*)\}", HDR).group(1).split(",") if v.strip()]
+    cic3 = diff(re.search(r"#define CSDR_CIC3_MAXBW\s+(\S+)", HDR).group(1))
+    return lens, even, maxbw, cic3
+
+
+def cnoise(rng, n, amp=1.0):
+    return amp * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+
+
+# ------------------------------------------------------------------------------------------------ CIir
+@pytest.mark.parametrize("kind,f0,q,fs", [("LP", 3000.0, 1.0, 62500.0), ("HP", 300.0, 0.707, 31250.0),
+                                          ("BP", 1000.0, 5.0, 15625.0), ("BR", 1200.0, 10.0, 48000.0)])
+def test_ciir_equals_cookbook_biquad_through_lfilter(oracle, kind, f0, q, fs):
+    f = oracle.CIir(); f.Init(kind, f0, q, fs)
+    b, a = ind.rbj_biquad(kind, f0, q, fs)
+    np.testing.assert_allclose(f.coefs(), [b[0], b[1], b[2], a[1], a[2]], rtol=0, atol=1e-15)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(5000)
+    mine = ind.Biquad(kind, f0, q, fs)
+    got = np.concatenate([f.ProcessFilter(x[:1234]), f.ProcessFilter(x[1234:])])       # state carried across calls
+    want = np.concatenate([mine.run(x[:1234]), mine.run(x[1234:])])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * np.abs(want).max())
+    z = cnoise(rng, 3000)
+    f2 = oracle.CIir(); f2.Init(kind, f0, q, fs)
+    np.testing.assert_allclose(f2.ProcessFilter(z), ind.Biquad(kind, f0, q, fs).run(z), rtol=0, atol=1e-10 * np.abs(z).max())
+    # and the response is the analogue prototype's: unity (LP at DC, HP at Nyquist), zero at f0 (BR), peak 1 at f0 (BP)
+    w, h = signal.freqz(b, a, worN=[0.0, math.pi, 2 * math.pi * f0 / fs])
+    want_gain = {"LP": (1, 0, None), "HP": (0, 1, None), "BP": (0, 0, 1), "BR": (1, 1, 0)}[kind]
+    for hv, g in zip(np.abs(h), want_gain):
+        if g is not None:
+            assert hv == pytest.approx(g, abs=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ CFir
+def test_cfir_is_a_plain_convolution(oracle):
+    rng = np.random.default_rng(2)
+    for nt in (3, 11, 40, 75):
+        h = rng.standard_normal(nt)
+        f = oracle.CFir(); f.InitConstFir(h)
+        x = rng.standard_normal(4000)
+        got = np.concatenate([f.ProcessFilter(x[:333]), f.ProcessFilter(x[333:])])
+        np.testing.assert_allclose(got, np.convolve(x, h)[:len(x)], rtol=0, atol=1e-12 * nt)
+    # complex overload: I taps on .re, Q taps on .im, no cross terms (fir.cpp:104-127).  (InitConstFir fills only the
+    # real tap set, fir.cpp:133-153; the complex sets come from the designers.)
+    f2 = oracle.CFir(); f2.InitLPFilter(1.0, 40.0, 4500.0, 5500.0, 31250.0); f2.GenerateHBFilter(5000.0)
+    _, hi_, hq_ = f2.taps()
+    z = cnoise(rng, 2000)
+    got = np.concatenate([f2.ProcessFilter(z[:700]), f2.ProcessFilter(z[700:])])
+    want = np.convolve(z.real, hi_)[:2000] + 1j * np.convolve(z.imag, hq_)[:2000]
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * len(hi_))
+
+
+@pytest.mark.parametrize("astop,fpass,fstop,fs", [(50.0, 5000.0, 9000.0, 31250.0), (50.0, 2800.0, 5040.0, 62500.0),
+                                                 (40.0, 4500.0, 5500.0, 31250.0), (30.0, 1000.0, 3000.0, 15625.0),
+                                                 (15.0, 1000.0, 6000.0, 48000.0), (50.0, 100.0, 180.0, 62500.0)])
+def test_kaiser_lowpass_equals_scipy_window_times_ideal_response(oracle, astop, fpass, fstop, fs):
+    f = oracle.CFir()
+    n = f.InitLPFilter(1.0, astop, fpass, fstop, fs)
+    want = ind.kaiser_lowpass(1.0, astop, fpass, fstop, fs)
+    assert n == len(want)
+    c, i, q = f.taps()
+    np.testing.assert_allclose(c, want, rtol=0, atol=2e-9)        # the reference sums the I0 series to 1e-9
+    np.testing.assert_allclose(i, c, atol=0); np.testing.assert_allclose(q, c, atol=0)
+    # the design does what it says: the -6 dB point sits at the mean of the edges; the stop band is down by about Astop
+    w, h = signal.freqz(want, worN=8192, fs=fs)
+    if 8 < n < 75 and astop >= 30:      # (Kaiser's length estimate meets Astop within a few dB; clamped designs do not)
+        assert abs(h[np.argmin(np.abs(w - (fpass + fstop) / 2))]) == pytest.approx(0.5, abs=0.06)
+        assert 20 * np.log10(np.abs(h[w >= fstop]).max() + 1e-300) < -(astop - 10.0)
+
+
+@pytest.mark.parametrize("astop,fpass,fstop,fs", [(50.0, 5000.0, 3000.0, 62500.0), (50.0, 3000.0, 1800.0, 62500.0),
+                                                 (50.0, 15000.0, 9000.0, 78125.0), (40.0, 300.0, 100.0, 15625.0)])
+def test_kaiser_highpass_equals_scipy_window_times_ideal_response(oracle, astop, fpass, fstop, fs):
+    f = oracle.CFir()
+    n = f.InitHPFilter(1.0, astop, fpass, fstop, fs)
+    want = ind.kaiser_highpass(1.0, astop, fpass, fstop, fs)
+    assert n == len(want) and n % 2 == 1
+    np.testing.assert_allclose(f.taps()[0], want, rtol=0, atol=2e-9)
+    w, h = signal.freqz(want, worN=8192, fs=fs)
+    if n < 75:
+        assert np.abs(h[w >= fpass * 1.2]).min() > 0.9 and np.abs(h[w <= fstop * 0.8]).max() < 10 ** (-(astop - 8) / 20)
+
+
+def test_hilbert_pair_of_the_sam_demodulator(oracle):
+    fs = 31250.0
+    f = oracle.CFir()
+    f.InitLPFilter(1.0, 40.0, 4500.0, 5500.0, fs)
+    f.GenerateHBFilter(5000.0)
+    c, i, q = f.taps()
+    wi, wq = ind.hilbert_pair(ind.kaiser_lowpass(1.0, 40.0, 4500.0, 5500.0, fs), 5000.0, fs)
+    np.testing.assert_allclose(i, wi, atol=4e-9); np.testing.assert_allclose(q, wq, atol=4e-9)
+    # I + jQ is an analytic band-pass 0 .. 10 kHz: it passes +5 kHz and rejects -5 kHz
+    w, h = signal.freqz(wi + 1j * wq, worN=[2 * math.pi * 5000 / fs, -2 * math.pi * 5000 / fs])
+    assert abs(h[0]) == pytest.approx(2.0, abs=0.05) and abs(h[1]) < 0.03
+
+
+# ------------------------------------------------------------------------------------- CDownConvert stages
+def test_every_half_band_and_the_cic_equal_upfirdn(oracle):
+    """each decimate-by-2 class alone, driven through the oracle's CDownConvert with the NCO at 0 Hz (a pure real
+    gain sequence, undone here), against the polyphase statement with the table's taps"""
+    lens, even, maxbw, cic3 = _hb_tables()
+    rng = np.random.default_rng(3)
+    for kind in [3] + lens:
+        # a rate / bandwidth pair that selects exactly this one stage
+        if kind == 3:
+            rate, bw = 31600.0, 31600.0 * cic3 * 0.99 / 1.0
+        else:
+            k = lens.index(kind)
+            lo = maxbw[k - 1] if k > 0 else cic3
+            rate, bw = 31600.0, 31600.0 * (lo + maxbw[k]) / 2.0
+        dc = oracle.CDownConvert()
+        dc.SetDataRate(rate, bw)
+        assert dc.stages() == [kind], (kind, dc.stages())
+        dc.SetFrequency(0.0)
+        x = cnoise(rng, 4 * 512)
+        got = np.concatenate([dc.ProcessData(x[i:i + 512]) for i in range(0, len(x), 512)])
+        mixed = ind.nco_mix(x, 0.0, rate)
+        h = np.array([1.0, 3.0, 3.0, 1.0]) / 8.0 if kind == 3 else ind.halfband_taps(even[kind], kind)
+        st = ind.DecimateBy2(h)
+        want = np.concatenate([st.run(mixed[i:i + 512]) for i in range(0, len(x), 512)])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-13 * np.abs(x).max(), err_msg="stage %d" % kind)
+        # and the taps are a half band: unity at DC, -6 dB at a quarter of the rate
+        if kind != 3:
+            w, hh = signal.freqz(h, worN=[0.0, math.pi / 2])
+            assert abs(hh[0]) == pytest.approx(1.0, abs=2e-4) and abs(hh[1]) == pytest.approx(0.5, abs=1e-12)
+
+
+@pytest.mark.parametrize("rate,bw,fc", [(2e6, 15000.0, -100e3), (2e6, 10000.0, 250e3), (2e6, 1000.0, 12345.0), (10e6, 15000.0, 1.2e6)])
+def test_whole_downconverter_equals_mixer_then_cascade(oracle, rate, bw, fc):
+    lens, even, maxbw, cic3 = _hb_tables()
+    kinds, out_rate = ind.decimator_chain(rate, bw, even, lens, maxbw, cic3)
+    dc = oracle.CDownConvert()
+    assert dc.SetDataRate(rate, bw) == out_rate and dc.stages() == kinds
+    dc.SetFrequency(fc)
+    rng = np.random.default_rng(4)
+    n = 3 * (1 << 14)
+    x = cnoise(rng, n, 1000.0)
+    got = np.concatenate([dc.ProcessData(x[i:i + (1 << 14)]) for i in range(0, n, 1 << 14)])
+    y = ind.nco_mix(x, fc, rate)
+    for k in kinds:
+        y = ind.DecimateBy2(np.array([1.0, 3.0, 3.0, 1.0]) / 8.0 if k == 3 else ind.halfband_taps(even[k], k)).run(y)
+    np.testing.assert_allclose(got, y, rtol=0, atol=1e-9 * 1000.0)
+
+
+# ------------------------------------------------------------------------------------------------ CFastFIR
+@pytest.mark.parametrize("nfft,flo,fhi,off,fs", [(2048, -5000, 5000, 0, 62500.0), (2048, 100, 2800, 0, 62500.0),
+                                                 (2048, -500, 500, 700, 15625.0), (16384, -5000, 5000, 0, 62500.0),
+                                                 (4096, -2800, -100, 0, 31250.0)])
+def test_overlap_save_equals_direct_convolution_with_independently_designed_taps(oracle, nfft, flo, fhi, off, fs):
+    ff = oracle.CFastFIR(nfft)
+    assert ff.SetupParameters(flo, fhi, off, fs) == 1
+    taps = ind.fastfir_taps(flo, fhi, off, fs, nfft)
+    # the oracle's H is the forward (positive-exponent, unscaled) transform of taps / N
+    H = np.fft.ifft(np.concatenate([taps, np.zeros(nfft - len(taps))]))          # = sum h e^{+j...} / N
+    np.testing.assert_allclose(ff.coef(), H, rtol=0, atol=1e-12)
+    rng = np.random.default_rng(5)
+    hop = nfft // 2
+    x = cnoise(rng, 5 * hop + 123, 3000.0)
+    got = np.concatenate([ff.ProcessData(x[:777]), ff.ProcessData(x[777:])])
+    want = ind.fastfir_stream(x, taps, nfft)
+    assert len(got) == len(want) == 5 * hop
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * 3000.0)
+
+
+# ------------------------------------------------------------------------------------------------ CFft display
+@pytest.mark.parametrize("n,ave", [(4096, 1), (2048, 4), (8192, 3)])
+def test_display_spectrum_equals_numpy_fft_of_the_windowed_frame(oracle, n, ave):
+    fs = 2e6
+    f = oracle.CFft(); f.SetFFTParams(n, False, -3.0, fs); f.SetFFTAve(ave)
+    mine = ind.DisplayFft(n, -3.0, fs, ave)
+    rng = np.random.default_rng(6)
+    t = np.arange(n)
+    for k in range(ave + 3):                                       # past the point where the average turns exponential
+        x = 3000.0 * np.exp(2j * np.pi * (250e3 + 1e3 * k) * t / fs) + cnoise(rng, n, 30.0)
+        assert f.PutInDisplayFFT(x) == mine.put(x)
+        np.testing.assert_allclose(f.ave_buf(), mine.bels, rtol=0, atol=1e-9)
+    # (never more pixels than bins: the reference's translate table has N entries, fft.cpp:165, 355-356)
+    for (h, w, mx, mn, lo, hi) in ((400, 800, 0.0, -160.0, -1000000, 1000000), (255, min(3000, n - 1), -20.0, -120.0, 200000, 300000),
+                                   (1 << 20, n - 1, 0.0, -220.0, -1000000, 1000000), (300, 17, 0.0, -100.0, -30000, 900000)):
+        ov, pix = f.GetScreenIntegerFFTData(h, w, mx, mn, lo, hi)
+        want = mine.screen(h, w, mx, mn, lo, hi)
+        touched = want >= 0                                        # many-bins case: the reference leaves other pixels alone
+        assert np.array_equal(pix[touched[:len(pix)]], want[:len(pix)][touched[:len(pix)]]), (h, w)
+        assert ov == mine.overload
+
+
+# ------------------------------------------------------------------------------------------------ CSMeter
+def test_smeter_loop_and_closed_forms(oracle):
+    fs = 62500.0
+    rng = np.random.default_rng(7)
+    x = np.concatenate([cnoise(rng, 20000, 50.0), 8000.0 * np.exp(2j * np.pi * 0.01 * np.arange(30000)), cnoise(rng, 20000, 50.0)])
+    m = oracle.CSMeter()
+    st = None
+    for i in range(0, len(x), 7000):
+        m.ProcessData(x[i:i + 7000], fs)
+        ave, peak, st = ind.smeter(x[i:i + 7000], fs, st)
+        assert m.GetAve() == pytest.approx(ave, abs=1e-9)
+    # a constant carrier of amplitude A settles at 20 log10(A / 32767) + 5 (smeter.cpp:76, 109-112)
+    c = oracle.CSMeter()
+    c.ProcessData(np.full(200000, 1000.0 + 0j), fs)
+    assert c.GetAve() == pytest.approx(20 * math.log10(1000.0 / 32767.0) + 5.0, abs=1e-6)
+    # the peak only reports values above 0 dBFS (it starts at 0 and is reset to 0 on read)
+    assert c.GetPeak() == pytest.approx(5.0) and c.GetPeak() == pytest.approx(5.0)
+    # attack: after one time constant (10 ms) a step from silence has closed 1 - 1/e of the gap (in dB)
+    s = oracle.CSMeter()
+    s.ProcessData(np.full(int(20 * fs), 1e-3 + 0j), fs)          # 40 decay time constants: both averages have settled
+    lo = s.GetAve()
+    s.ProcessData(np.full(int(fs * 0.01), 10000.0 + 0j), fs)
+    hi = 20 * math.log10(10000.0 / 32767.0) + 5.0
+    assert (s.GetAve() - lo) / (hi - lo) == pytest.approx(1 - math.exp(-1), abs=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------ CAgc
+@pytest.mark.parametrize("hang,thresh,slope,decay,fs", [(False, -100, 0, 200, 62500.0), (False, -60, 5, 500, 31250.0),
+                                                        (True, -80, 2, 300, 62500.0), (False, -100, 0, 20, 15625.0)])
+def test_agc_equals_the_independent_statement(oracle, hang, thresh, slope, decay, fs):
+    rng = np.random.default_rng(8)
+    n = 3 * 2048
+    env = np.concatenate([np.full(n // 3, 30.0), np.full(n // 3, 9000.0), np.full(n - 2 * (n // 3), 200.0)])
+    x = env * np.exp(2j * np.pi * 0.03 * np.arange(n)) + cnoise(rng, n, 3.0)
+    a = oracle.CAgc(); a.SetParameters(True, hang, thresh, 30, slope, decay, fs)
+    mine = ind.Agc(True, hang, thresh, 30, slope, decay, fs)
+    got = np.concatenate([a.ProcessData(x[i:i + 1024]) for i in range(0, n, 1024)])
+    want = np.concatenate([mine.run(x[i:i + 1024]) for i in range(0, n, 1024)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(want).max())
+
+
+def test_agc_steady_state_gain_law_and_manual_gain(oracle):
+    """agc.cpp:273-281: above the knee the output amplitude of a constant envelope A is A * 0.7 * 10^(mag (slope - 1)),
+    mag = log10(A' + 3.2767e-4) - log10(32767), A' = the larger of |re|, |im|; below it FixedGain; off: ManualGain"""
+    fs = 62500.0
+    for A, thresh, slope in ((3000.0, -100, 0), (3000.0, -100, 5), (20.0, -40, 0), (10000.0, -20, 10)):
+        a = oracle.CAgc(); a.SetParameters(True, False, thresh, 30, slope, 200, fs)
+        y = a.ProcessData(np.full(8 * 62500, A + 0j))
+        mag = math.log10(A + 3.2767e-4) - math.log10(32767.0)
+        knee, gs = thresh / 20.0, slope / 100.0
+        g = 0.7 * 10 ** (knee * (gs - 1.0)) if mag <= knee else 0.7 * 10 ** (mag * (gs - 1.0))
+        assert abs(y[-1]) == pytest.approx(A * g, rel=1e-6)
+        if slope == 0 and mag > knee:
+            assert abs(y[-1]) == pytest.approx(0.7 * 32767.0, rel=1e-4)      # slope 0: constant output 3 dB under full scale
+    m = oracle.CAgc(); m.SetParameters(False, False, -100, 40, 0, 200, fs)
+    z = np.array([1.0 + 2.0j, -3.0 + 0.5j])
+    np.testing.assert_allclose(m.ProcessData(z), 32767.0 * 10 ** (-(100 - 40) / 20.0) * z, rtol=1e-14)
+    # the delay line: the output is the input 15 ms earlier (agc.cpp:50, 162, 184-190)
+    d = oracle.CAgc(); d.SetParameters(True, False, -100, 30, 0, 200, fs)
+    imp = np.zeros(3000, dtype=complex); imp[0] = 1000.0
+    assert np.argmax(np.abs(d.ProcessData(imp))) == int(fs * 0.015)
+
+
+# ------------------------------------------------------------------------------------------------ demodulators
+def test_am_demodulator_equals_envelope_dcblock_lowpass(oracle):
+    fs = 31250.0
+    rng = np.random.default_rng(9)
+    n = 12000
+    x = 5000.0 * (1.0 + 0.5 * np.sin(2 * np.pi * 1000.0 * np.arange(n) / fs)) * np.exp(2j * np.pi * 0.013 * np.arange(n)) + cnoise(rng, n, 5.0)
+    d = oracle.CAmDemod(fs); d.SetBandwidth(5000.0)
+    mine = ind.AmDemod(fs); mine.set_bandwidth(5000.0)
+    got = np.concatenate([d.ProcessData(x[i:i + 1024]) for i in range(0, n, 1024)])
+    want = np.concatenate([mine.run(x[i:i + 1024]) for i in range(0, n, 1024)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * 5000.0)
+    # H(z) = (1 - z^-1) / (1 - 0.99 z^-1) as a library filter gives the same DC-blocked envelope
+    env = np.abs(x)
+    y, _ = ind.dc_block(env)
+    np.testing.assert_allclose(want, ind.Fir(ind.kaiser_lowpass(1.0, 50.0, 5000.0, 9000.0, fs)).run(y), rtol=0, atol=1e-8 * 5000.0)
+    # the 1 kHz tone comes out with the modulation's amplitude 0.5 * 5000
+    tone = got[6000:]
+    assert np.abs(tone).max() == pytest.approx(2500.0, rel=0.02)
+    s = oracle.CAmDemod(fs); s.SetBandwidth(5000.0)
+    st = s.ProcessData(x[:2048], stereo=True)
+    np.testing.assert_allclose(st.real, got[:2048], atol=1e-9); np.testing.assert_allclose(st.imag, got[:2048], atol=1e-9)
+
+
+def test_fm_demodulator_equals_the_independent_statement_and_its_gain_constant(oracle):
+    fs = 62500.0
+    n = 10 * 1024
+    t = np.arange(n) / fs
+    dev, fm = 3000.0, 1000.0
+    ph = 2 * np.pi * 200.0 * t + (dev / fm) * np.sin(2 * np.pi * fm * t)
+    rng = np.random.default_rng(10)
+    x = 8000.0 * np.exp(1j * ph) + cnoise(rng, n, 2.0)
+    for sq in (0, 50):
+        d = oracle.CFmDemod(fs); d.SetSquelch(sq)
+        mine = ind.FmDemod(fs); mine.set_squelch(sq)
+        for i in range(0, n, 1024):
+            got = d.ProcessData(x[i:i + 1024], 5000.0)
+            want = mine.run(x[i:i + 1024], 5000.0)
+            assert d.squelched() == mine.squelched
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-7 * 25000.0)
+    # squelch open (value 0 -> threshold 5000): a deviation of `dev` Hz reads dev * 2pi/fs * 25000 / NcoHLimit
+    # = dev * 25000 / 6000 at the peak of the tone, less the 3 kHz low-pass's gain at 1 kHz (Q = 1 biquad)
+    d = oracle.CFmDemod(fs); d.SetSquelch(0)
+    y = np.concatenate([d.ProcessData(x[i:i + 1024], 5000.0) for i in range(0, n, 1024)])
+    assert not d.squelched()
+    b, a = ind.rbj_biquad("LP", 3000.0, 1.0, fs)
+    g = abs(signal.freqz(b, a, worN=[2 * np.pi * fm / fs])[1][0])
+    # (to 3 %: with alpha = 0.85 and beta = 0.36 per sample the loop is far from its continuous-time prototype, whose
+    # frequency-to-NcoFreq response at 1 kHz would be 0.9996)
+    assert np.abs(y[-3000:]).max() == pytest.approx(dev * 25000.0 / 6000.0 * g, rel=0.03)
+    # noise only: the squelch shuts and the output is exactly zero
+    q = oracle.CFmDemod(fs); q.SetSquelch(0)
+    z = np.concatenate([q.ProcessData(cnoise(rng, 1024, 300.0), 5000.0) for _ in range(6)])
+    assert q.squelched() and not z[-1024:].any()
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_sam_demodulator_equals_the_independent_statement(oracle, stereo):
+    fs = 31250.0
+    n = 8 * 1024
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(11)
+    x = 6000.0 * (1.0 + 0.4 * np.sin(2 * np.pi * 700.0 * t)) * np.exp(1j * (2 * np.pi * 120.0 * t + 0.7)) + cnoise(rng, n, 3.0)
+    d = oracle.CSamDemod(fs)
+    mine = ind.SamDemod(fs)
+    got = np.concatenate([d.ProcessData(x[i:i + 1024], stereo=stereo) for i in range(0, n, 1024)])
+    want = np.concatenate([mine.run(x[i:i + 1024], stereo=stereo) for i in range(0, n, 1024)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-7 * 6000.0)
+    if not stereo:       # locked on the 120 Hz offset carrier: the audio is the 700 Hz tone of amplitude 0.4 * 6000
+        assert np.abs(got[-2000:]).max() == pytest.approx(2400.0, rel=0.03)
+
+
+def test_ssb_is_the_real_part(oracle):
+    rng = np.random.default_rng(12)
+    z = cnoise(rng, 100)
+    np.testing.assert_array_equal(oracle.ssb_demod(z), z.real)
+    np.testing.assert_array_equal(oracle.ssb_demod(z, stereo=True), z)
+
+
+# ------------------------------------------------------------------------------------------------ CFractResampler
+@pytest.mark.parametrize("rate", [1.0, 78125.0 / 48000.0, 62500.0 / 48000.0, 0.7311, 1.302083333])
+def test_resampler_equals_direct_windowed_sinc_evaluation(oracle, rate):
+    rng = np.random.default_rng(13)
+    x = cnoise(rng, 5000, 1000.0)
+    r = oracle.CFractResampler(); r.Init(8192)
+    mine = ind.Resampler()
+    for i in range(0, 5000, 1024):
+        got = r.Resample(x[i:i + 1024], rate)
+        want = mine.run(x[i:i + 1024], rate)
+        assert len(got) == len(want)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * 1000.0)
+    # a band-limited tone comes out as the same tone at the new rate, delayed by 14 input samples
+    n = 6000
+    f0 = 0.05
+    tone = np.exp(2j * np.pi * f0 * np.arange(n))
+    r2 = oracle.CFractResampler(); r2.Init(8192)
+    y = r2.Resample(tone, rate)
+    k = np.arange(len(y))
+    want = np.exp(2j * np.pi * f0 * (k * rate - 14.0))
+    np.testing.assert_allclose(y[200:-50], want[200:-50], rtol=0, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ the whole chain
+def _info(orc, **kw):
+    base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100, AgcManualGain=30,
+                AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+    base.update(kw)
+    return orc.DemodInfo(**base)
+
+
+@pytest.mark.parametrize("mode", ["USB", "AM", "FM"])
+def test_whole_cdemodulator_chain_composed_from_the_independent_stages(oracle, mode):
+    """CDemodulator::ProcessData (demodulator.cpp:163-215) = m_InBufLimit windows through down-converter, band-pass,
+    S-meter, AGC, demodulator: the independent stages composed the same way must give the oracle's audio"""
+    lens, even, maxbw, cic3 = _hb_tables()
+    fs, fc = 2e6, 100e3
+    if mode == "USB":
+        info = _info(oracle, HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200, LowCutmin=0, Symetric=0)
+        m, max_bw = oracle.DEMOD_USB, 20000.0
+    elif mode == "AM":
+        info = _info(oracle, HiCutmin=500, HiCutmax=10000, LowCutmax=-500, LowCutmin=-10000)
+        m, max_bw = oracle.DEMOD_AM, 10000.0
+    else:
+        info = _info(oracle)
+        m, max_bw = oracle.DEMOD_FM, 15000.0
+    d = oracle.CDemodulator(2048)
+    d.SetInputSampleRate(fs); d.SetDemod(m, info); d.SetDemodFreq(-fc)
+    lim = d.buf_limit()
+    nwin = 16 if mode == "FM" else 10
+    n = nwin * lim
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(14)
+    if mode == "USB":
+        x = 1500.0 * (np.exp(2j * np.pi * (fc + 1200.0) * t) + np.exp(2j * np.pi * (fc + 2340.0) * t))
+    elif mode == "AM":
+        x = 3000.0 * (1 + 0.5 * np.sin(2 * np.pi * 1000.0 * t)) * np.exp(2j * np.pi * fc * t)
+    else:
+        x = 3000.0 * np.exp(1j * (2 * np.pi * fc * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)))
+    x = x + cnoise(rng, n, 10.0)
+    got = d.process_append(x)
+
+    kinds, out_rate = ind.decimator_chain(fs, max_bw, even, lens, maxbw, cic3)
+    assert out_rate == d.GetOutputRate()
+    assert lim == (int(out_rate / 100.0 * fs / out_rate) & 0xFFFFFF00)
+    stages = [ind.DecimateBy2(np.array([1.0, 3.0, 3.0, 1.0]) / 8.0 if k == 3 else ind.halfband_taps(even[k], k)) for k in kinds]
+    taps = ind.fastfir_taps(info.LowCut, info.HiCut, 0.0, out_rate, 2048)
+    agc = ind.Agc(True, False, -100, 30, 0, 200, out_rate)
+    am = ind.AmDemod(out_rate); am.set_bandwidth((info.HiCut - info.LowCut) / 2.0)
+    fmd = ind.FmDemod(out_rate); fmd.set_squelch(0)
+    audio, filt_in, done, sm_state, sm_ave = [], np.zeros(0, dtype=complex), 0, None, None
+    for w in range(nwin):
+        y = ind.nco_mix(x[w * lim:(w + 1) * lim], -fc, fs, first_sample=w * lim)
+        for s in stages:
+            y = s.run(y)
+        filt_in = np.concatenate([filt_in, y])
+        ready = (len(filt_in) // 1024) * 1024                       # whole hops the filter has delivered so far
+        if ready > done:
+            f = ind.fastfir_stream(filt_in, taps, 2048)[done:ready]
+            done = ready
+            sm_ave, _, sm_state = ind.smeter(f, out_rate, sm_state)
+            g = agc.run(f)
+            audio.append(g.real if mode == "USB" else am.run(g) if mode == "AM" else fmd.run(g, float(info.HiCut)))
+    want = np.concatenate(audio)
+    assert len(got) == len(want)
+    tol = {"USB": 1e-7, "AM": 1e-7, "FM": 1e-6}[mode]               # (FM: two loops of transcendentals drifting apart by rounding)
+    # FM demodulates the PHASE of whatever it is given: in the first bursts that is the filter's start-up, samples of
+    # 1e-13 of full scale in which the two transcriptions' rounding IS the signal; from the fourth
+    # burst on the carrier is there.  The other modes are compared from sample 0.
+    # burst on the carrier is there, and the 10 ms average of the loop frequency forgets the kick by a factor of five
+    # per burst -- the rule the GPU chain tests apply to the fp32 path, with tighter numbers.
+    if mode == "FM":
+        np.testing.assert_allclose(got[3 * 1024:6 * 1024], want[3 * 1024:6 * 1024], rtol=0, atol=1e-3 * 32767.0)
+        np.testing.assert_allclose(got[6 * 1024:], want[6 * 1024:], rtol=0, atol=tol * 32767.0)
+    else:
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol * 32767.0)
+    # (the meter's first samples are the same start-up garbage in dB, -250 against -270, and its 0.5 s decay average
+    # has not forgotten them after these 0.1 s)
+    assert d.GetSMeterAve() == pytest.approx(sm_ave, abs=1e-3)
