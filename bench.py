@@ -130,8 +130,8 @@ def spawn_ranks(n, argv):
     Runs before anything in this process has imported torch or touched HIP: the children are fresh
     interpreters, nothing is re-executed in place."""
     if "--stub" not in argv and not os.environ.get("CSDR_BENCH_ONE_GPU"):
-        import torch                                  # counting devices does not initialise the GPU (no HIP call yet)
-        ndev = torch.cuda.device_count()
+        import torch                                  # (device_count() may initialise HSA in this parent when amdsmi is not
+        ndev = torch.cuda.device_count()              # there; harmless: the ranks are fresh children, nothing is re-exec'd)
         if ndev < n:
             print("bench.py: --gpus %d but this node shows %d device(s); nothing started" % (n, ndev), file=sys.stderr)
             return 2
@@ -140,10 +140,9 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        # RCCL between processes needs dmabuf IPC on this driver (HSA_ENABLE_IPC_MODE_LEGACY=0); the image exports it
-        # and the children inherit the environment as it is -- forcing it is opt-in
-        if os.environ.get("CSDR_BENCH_SET_IPC_MODE"):
-            env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        # RCCL between processes needs dmabuf IPC on this driver (HSA_ENABLE_IPC_MODE_LEGACY=0): the image exports it;
+        # setdefault never overrides what the environment says, and covers a host that does not export it
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the one JSON line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
     rc = 0

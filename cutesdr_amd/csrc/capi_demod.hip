@@ -4,6 +4,7 @@
 // CDemodulator::ProcessData call for call, and the batched multi-channel form.
 #include "capi_common.hpp"
 #include "pc_unit.hpp"
+#include "dc_host.hpp"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -210,6 +211,15 @@ struct ChainCore {
     int step(const float *d_in, long in_stride, const int *d_in_rows, int n, float *d_out, long out_stride,
              const int *d_out_rows, bool stereo, hipStream_t s, hipEvent_t dc_after = nullptr, hipEvent_t dc_done = nullptr)
     {
+        int rc = step_dc(d_in, in_stride, d_in_rows, n, s, dc_after, dc_done);
+        if (rc < 0) return rc;
+        return step_post(d_out, out_stride, d_out_rows, stereo, s);
+    }
+    // the two halves of step(): the down-converter of this call into the staging rows ...
+    int m_call = 0;                     // decimated samples the down-converter of this call appended
+    int step_dc(const float *d_in, long in_stride, const int *d_in_rows, int n, hipStream_t s, hipEvent_t dc_after,
+                hipEvent_t dc_done)
+    {
         if (s_post) return fail(CSDR_ESTATE, "pipelined objects take step_pipelined()");
         const int m = csdr_downconvert_batch_out_count(dc, 0, n);
         if (m < 0) return m;
@@ -222,16 +232,21 @@ struct ChainCore {
                                                   cap, s, pk, pk_len);
         if (rc) return rc;
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
-        const int total = pending + m, nb = total / L;
+        m_call = m;
+        return CSDR_OK;
+    }
+    // ... and everything behind it: filter, S-meter, AGC, demodulator, the staging shift
+    int step_post(float *d_out, long out_stride, const int *d_out_rows, bool stereo, hipStream_t s)
+    {
+        const int total = pending + m_call, nb = total / L;
+        m_call = 0;
         last_out = 0;
         last_post = -1;
         if (nb > 0) {
-            rc = csdr_fastfir_batch_process(ff, d_stage, cap, nb * L, d_filt, cap, s, 0);
+            int rc = csdr_fastfir_batch_process(ff, d_stage, cap, nb * L, d_filt, cap, s, 0);
             if (rc) return rc;
             rc = post(d_filt, d_out, out_stride, d_out_rows, stereo, nb, s);
             if (rc) return rc;
-        }
-        if (nb > 0) {
             const int rest = total - nb * L;
             if (rest > 0) {
                 hipLaunchKernelGGL(shift_rows_kernel, dim3(rows), dim3(256), 0, s, d_stage, d_stage, cap, nb * L, rest);
@@ -383,7 +398,7 @@ struct csdr_demod_batch {
     std::vector<int *> d_rows;                        // core -> device array of channel ids (input rows)
     std::vector<int *> d_out_rows;                    // core -> the same for the outputs, -1 = muted row (its receiver has
                                                       // moved to another plan group: csdr_demod_batch_set_demod)
-    std::map<long long, int> core_by_bw;
+    std::vector<std::vector<int>> row_in_last;        // core -> input row of each of its rows as last uploaded
     // the groups are independent: each runs on its own stream, forked from and joined to the caller's
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> joins;
@@ -452,48 +467,126 @@ static int batch_plumbing(csdr_demod_batch *b)
     return CSDR_OK;
 }
 
-/* CDemodulator::SetDemod with a mode whose maximum bandwidth -- hence decimator chain and output rate -- differs from
- * the receiver's present one, on a committed batch (dsp/demodulator.cpp:107-157).  The receiver leaves its plan group
- * (whose rows share one decimation, hop count and staging fill) and continues in a group of its own, with everything
- * the reference keeps across SetDemod: the down-converter's oscillator, the filter's overlap AND its partly filled
- * input (samples at the OLD rate: fastfir.cpp:278-285 never resets m_InBufInPos), AGC and S-meter objects; the new
- * demodulator starts fresh and the rebuilt decimator from zero histories, as there.  Its old row stays in the old
- * group, muted (no output, no S-meter; the group still filters it).  A receiver already alone in its group changes
- * in place, exactly like the single-channel object. */
-static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const DemodInfo &di)
+// a plan group's stream and events for group number `have` .. `want`-1 (the new groups get the lowest priority until
+// batch_order / the next plumbing pass ranks them); nothing is published on failure
+static int batch_plumbing_reserve(csdr_demod_batch *b, size_t want)
+{
+    if (!b->fork) CSDR_HIP(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+    int pr_lo = 0, pr_hi = 0;
+    CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+    while (b->streams.size() < want) {
+        hipStream_t st;
+        CSDR_HIP(stream_pool().get(b->device, pr_lo, &st));
+        b->streams.push_back(st);
+    }
+    while (b->joins.size() < want) { hipEvent_t ev; CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->joins.push_back(ev); }
+    while (b->dc_done.size() < want) { hipEvent_t ev; CSDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); b->dc_done.push_back(ev); }
+    if (b->prev_post.size() < want) b->prev_post.resize(want, -1);
+    if (b->prev_join.size() < want) b->prev_join.resize(want, 0);
+    return CSDR_OK;
+}
+
+// a plan group none of whose rows has a receiver any more (all moved away) leaves the batch: no more launches for it
+static void batch_drop_core(csdr_demod_batch *b, int ki)
+{
+    delete b->cores[ki];
+    b->cores.erase(b->cores.begin() + ki);
+    b->members.erase(b->members.begin() + ki);
+    if ((size_t)ki < b->row_in_last.size()) b->row_in_last.erase(b->row_in_last.begin() + ki);
+    if (b->d_rows[ki]) (void)hipFree(b->d_rows[ki]);
+    if (b->d_out_rows[ki]) (void)hipFree(b->d_out_rows[ki]);
+    b->d_rows.erase(b->d_rows.begin() + ki);
+    b->d_out_rows.erase(b->d_out_rows.begin() + ki);
+    if ((size_t)ki < b->streams.size()) { stream_pool().put(b->device, b->streams[ki]); b->streams.erase(b->streams.begin() + ki); }
+    if ((size_t)ki < b->joins.size()) { (void)hipEventDestroy(b->joins[ki]); b->joins.erase(b->joins.begin() + ki); }
+    if ((size_t)ki < b->dc_done.size()) { (void)hipEventDestroy(b->dc_done[ki]); b->dc_done.erase(b->dc_done.begin() + ki); }
+    if ((size_t)ki < b->prev_post.size()) b->prev_post.erase(b->prev_post.begin() + ki);
+    if ((size_t)ki < b->prev_join.size()) b->prev_join.erase(b->prev_join.begin() + ki);
+    for (int &c : b->core_of) if (c > ki) c--;
+}
+
+/* CDemodulator::SetDemod with a NEW MODE whose decimator chain has another number of stages -- hence another output
+ * rate, hop count and staging fill -- on a committed batch (dsp/demodulator.cpp:107-157).  The receiver leaves its plan
+ * group (whose rows share one decimation) with everything the reference keeps across SetDemod: the down-converter's
+ * oscillator, the filter's overlap AND its partly filled input (samples at the OLD rate: fastfir.cpp:278-285 never
+ * resets m_InBufInPos), AGC and S-meter objects; the new demodulator starts fresh and the rebuilt decimator from zero
+ * histories, as there.  It continues in a muted row of a group that already has the new decimation and the same
+ * staging fill (a receiver that left earlier: retuning back and forth does not grow the batch), else in a group of
+ * its own.  Its old row stays behind muted (no output, no S-meter; the group still filters it) and a group left with
+ * muted rows only is dropped.  Transactional: the new row is complete before anything of the batch changes, and any
+ * failure leaves the batch as it was.  A receiver already alone in its group changes in place, exactly like the
+ * single-channel object. */
+static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const DemodInfo &di, int new_stages)
 {
     CSDR_HIP(hipDeviceSynchronize());                  // control plane: nothing of this batch in flight from here on
     const int ka = b->core_of[channel], r = b->row_of[channel];
     ChainCore &A = *b->cores[ka];
     if (A.rows == 1) return apply_set_demod(A, 0, b->cfg[channel], b->in_rate, mode, di);
-    ChainCore *S = new ChainCore();
-    int rc = S->init(b->device, 1, b->fft_n);
-    if (rc == CSDR_OK && b->pipelined) rc = S->pipelined_init();
-    if (rc == CSDR_OK) rc = csdr__downconvert_batch_copy_channel(S->dc, 0, A.dc, r);
-    if (rc == CSDR_OK) rc = csdr__fastfir_batch_copy_row(S->ff, 0, A.ff, r);
-    if (rc == CSDR_OK) rc = S->pc.import_channel(0, A.pc, r);
-    if (rc == CSDR_OK) rc = S->ensure((long)A.pending + 1);
-    if (rc != CSDR_OK) { delete S; return rc; }
-    if (A.pending > 0) {
-        const float *cur = (A.stage_cur ? A.d_stage2 : A.d_stage) + (size_t)r * A.cap * 2;
-        CSDR_HIP(hipMemcpy(S->d_stage, cur, (size_t)A.pending * 8, hipMemcpyDeviceToDevice));
+    // ---- where to: a muted row of a group with the new decimation and the same staging fill, else a new group
+    int kb = -1, rb = -1;
+    for (size_t ki = 0; ki < b->cores.size() && kb < 0; ki++) {
+        ChainCore &B = *b->cores[ki];
+        if ((int)ki == ka || B.pending != A.pending || B.rows < 2) continue;
+        if (csdr_downconvert_batch_out_count(B.dc, 0, 1 << 12) != (1 << 12) >> new_stages) continue;
+        for (size_t q = 0; q < b->members[ki].size(); q++) if (b->members[ki][q] < 0) { kb = (int)ki; rb = (int)q; break; }
     }
-    S->pending = A.pending;
+    ChainCore *S = nullptr;
     int *dr = nullptr, *dor = nullptr;
-    CSDR_HIP(hipMalloc((void **)&dr, sizeof(int)));
-    CSDR_HIP(hipMalloc((void **)&dor, sizeof(int)));
-    CSDR_HIP(hipMemcpy(dr, &b->in_row[channel], sizeof(int), hipMemcpyHostToDevice));
-    CSDR_HIP(hipMemcpy(dor, &channel, sizeof(int), hipMemcpyHostToDevice));
-    const int muted = -1;                              // the old row: keeps reading its input, writes nothing
-    CSDR_HIP(hipMemcpy(b->d_out_rows[ka] + r, &muted, sizeof(int), hipMemcpyHostToDevice));
-    b->cores.push_back(S);
-    b->members.push_back(std::vector<int>(1, channel));
-    b->d_rows.push_back(dr); b->d_out_rows.push_back(dor);
-    b->core_of[channel] = (int)b->cores.size() - 1; b->row_of[channel] = 0;
-    rc = apply_set_demod(*S, 0, b->cfg[channel], b->in_rate, mode, di);
-    if (rc) return rc;
+    int rc = CSDR_OK;
+    auto hip = [&](hipError_t e) { if (e != hipSuccess && rc == CSDR_OK) rc = fail(CSDR_EHIP, "%s", hipGetErrorString(e)); return e == hipSuccess; };
+    if (kb < 0) {
+        S = new ChainCore();
+        rc = S->init(b->device, 1, b->fft_n);
+        if (rc == CSDR_OK && b->pipelined) rc = S->pipelined_init();
+        if (rc == CSDR_OK) rc = S->ensure((long)A.pending + 1);
+        if (rc == CSDR_OK) { hip(hipMalloc((void **)&dr, sizeof(int))) && hip(hipMalloc((void **)&dor, sizeof(int))); }
+        if (rc == CSDR_OK) rc = batch_plumbing_reserve(b, b->cores.size() + 1);
+    }
+    ChainCore &T = kb < 0 ? *S : *b->cores[kb];
+    const int tr = kb < 0 ? 0 : rb;
+    ChanCfg cfg = b->cfg[channel];                     // committed only when everything has worked
+    if (rc == CSDR_OK) rc = csdr__downconvert_batch_copy_channel(T.dc, tr, A.dc, r);
+    if (rc == CSDR_OK) rc = csdr__fastfir_batch_copy_row(T.ff, tr, A.ff, r);
+    if (rc == CSDR_OK) rc = T.pc.import_channel(tr, A.pc, r);
+    if (rc == CSDR_OK && A.pending > 0) {
+        const float *cur = (A.stage_cur ? A.d_stage2 : A.d_stage) + (size_t)r * A.cap * 2;
+        float *dst = (T.stage_cur ? T.d_stage2 : T.d_stage) + (size_t)tr * T.cap * 2;
+        hip(hipMemcpy(dst, cur, (size_t)A.pending * 8, hipMemcpyDeviceToDevice));
+    }
+    if (rc == CSDR_OK) rc = apply_set_demod(T, tr, cfg, b->in_rate, mode, di);
+    const int muted = -1;
+    int *t_in = kb < 0 ? dr : b->d_rows[kb] + rb, *t_out = kb < 0 ? dor : b->d_out_rows[kb] + rb;
+    if (rc == CSDR_OK) hip(hipMemcpy(t_in, &b->in_row[channel], sizeof(int), hipMemcpyHostToDevice));
+    if (rc == CSDR_OK) hip(hipMemcpy(t_out, &channel, sizeof(int), hipMemcpyHostToDevice));
+    if (rc == CSDR_OK) hip(hipMemcpy(b->d_out_rows[ka] + r, &muted, sizeof(int), hipMemcpyHostToDevice));
+    if (rc != CSDR_OK) {                               // nothing published: the batch is as it was (a reused muted row
+        delete S;                                      // holds copied state nobody reads)
+        if (dr) (void)hipFree(dr);
+        if (dor) (void)hipFree(dor);
+        if (kb >= 0) (void)hipMemcpy(b->d_out_rows[kb] + rb, &muted, sizeof(int), hipMemcpyHostToDevice);
+        return rc;
+    }
+    // ---- publish (host bookkeeping only from here on: cannot fail)
+    b->cfg[channel] = cfg;
+    b->members[ka][r] = -1;
+    if (kb < 0) {
+        S->pending = A.pending;
+        b->cores.push_back(S);
+        b->members.push_back(std::vector<int>(1, channel));
+        b->d_rows.push_back(dr); b->d_out_rows.push_back(dor);
+        b->row_in_last.resize(b->cores.size());
+        b->row_in_last.back().assign(1, b->in_row[channel]);
+        b->core_of[channel] = (int)b->cores.size() - 1; b->row_of[channel] = 0;
+    } else {
+        b->members[kb][rb] = channel;
+        if ((size_t)kb < b->row_in_last.size() && (size_t)rb < b->row_in_last[kb].size()) b->row_in_last[kb][rb] = b->in_row[channel];
+        b->core_of[channel] = kb; b->row_of[channel] = rb;
+    }
+    bool empty = true;
+    for (int m : b->members[ka]) empty = empty && m < 0;
+    if (empty) batch_drop_core(b, ka);
     batch_order(b);
-    return batch_plumbing(b);
+    return CSDR_OK;
 }
 
 extern "C" {
@@ -627,13 +720,20 @@ int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const
         return fail(CSDR_EINVAL, "bad argument");
     ChanCfg &c = b->cfg[channel];
     if (b->core_of[channel] >= 0) {
-        // already committed: a change that keeps the decimator chain stays in its row; one that alters it moves the
-        // receiver to a plan group of its own (batch_move_channel)
+        // already committed.  The reference rebuilds the down-converter only when the MODE changes
+        // (demodulator.cpp:111-121); a new mode whose chain has as many stages as the old one stays in its row (the
+        // down-converter object holds a plan per row), one with another decimation moves (batch_move_channel)
         DemodInfo di; memcpy(&di, info, sizeof(di));
         if (!device_ok(b->device)) return CSDR_EHIP;
-        const double bw = (mode == PC_MODE_LSB || mode == PC_MODE_CWL) ? -di.LowCutmin : di.HiCutmax;
-        if (bw != c.want_bw) return batch_move_channel(b, channel, mode, di);
-        return apply_set_demod(*b->cores[b->core_of[channel]], b->row_of[channel], c, b->in_rate, mode, di);
+        ChainCore &k = *b->cores[b->core_of[channel]];
+        if (c.mode != mode) {
+            const double bw = (mode == PC_MODE_LSB || mode == PC_MODE_CWL) ? -di.LowCutmin : di.HiCutmax;
+            const int new_stages = dc_make_plan(b->in_rate, bw).nstages;
+            int codes[DC_MAX_STAGES];
+            const int old_stages = csdr_downconvert_batch_get_stages(k.dc, b->row_of[channel], codes, DC_MAX_STAGES);
+            if (new_stages != old_stages) return batch_move_channel(b, channel, mode, di, new_stages);
+        }
+        return apply_set_demod(k, b->row_of[channel], c, b->in_rate, mode, di);
     }
     memcpy(&c.info, info, sizeof(DemodInfo));
     c.pending = mode;                    // applied at commit
@@ -644,9 +744,15 @@ int csdr_demod_batch_set_demod(csdr_demod_batch *b, int channel, int mode, const
 static int batch_upload_input_rows(csdr_demod_batch *b)
 {
     std::vector<int> rows;
+    b->row_in_last.resize(b->cores.size());
     for (size_t ki = 0; ki < b->cores.size(); ki++) {
+        b->row_in_last[ki].resize(b->members[ki].size(), 0);
         rows.clear();
-        for (int c : b->members[ki]) rows.push_back(b->in_row[c]);
+        for (size_t q = 0; q < b->members[ki].size(); q++) {   // (a muted row keeps reading the row it last had)
+            const int c = b->members[ki][q];
+            rows.push_back(c >= 0 ? b->in_row[c] : b->row_in_last[ki][q]);
+        }
+        b->row_in_last[ki] = rows;
         CSDR_HIP(hipMemcpy(b->d_rows[ki], rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
     }
     return CSDR_OK;
@@ -789,6 +895,44 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
     const bool forked = b->cores.size() > 1 || b->pipelined;
     if (forked) CSDR_HIP(hipEventRecord(b->fork, caller));
     int err = 0;
+    // CSDR_CHAIN_PHASED=1 (measured in round 4, not the default): strict mode in two phases -- every group's
+    // down-converter first, concurrently, so that together they fill the chip like ONE launch with nothing else
+    // resident (1.05 ms for the C4 share), then every group's filter and post-chain (0.9 ms: the walks are the long
+    // pole whatever runs beside them).  2.05 ms against 1.82 interleaved, where group g's post-chain runs beside group
+    // g+1's down-converter: the walks' latency has to be overlapped with something, not queued behind everything.
+    // 2 = phased with the down-converters chained one after the other (2.11 ms).
+    static const int phased = getenv("CSDR_CHAIN_PHASED") ? atoi(getenv("CSDR_CHAIN_PHASED")) : 0;
+    bool plain = true;                                   // (an object that was ever pipelined keeps its three-stream cores)
+    for (auto *k : b->cores) plain = plain && !k->s_post;
+    if (forked && !b->pipelined && phased && plain && b->cores.size() > 1) {
+        std::vector<char> ok(b->cores.size(), 0);
+        for (size_t oi = 0; oi < b->cores.size(); oi++) {
+            const size_t ki = (size_t)b->order[oi];
+            ChainCore &k = *b->cores[ki];
+            k.pk = d_packets; k.pk_len = pkt_len;
+            CSDR_HIP(hipStreamWaitEvent(b->streams[ki], b->fork, 0));
+            const int rc = k.step_dc(d_in, in_stride, b->d_rows[ki], n_per_channel, b->streams[ki],
+                                     phased == 2 && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, b->dc_done[ki]);
+            if (rc < 0) { if (!err) err = rc; CSDR_HIP(hipEventRecord(b->dc_done[ki], b->streams[ki])); }
+            else ok[ki] = 1;
+        }
+        for (size_t oi = 0; oi < b->cores.size(); oi++) {
+            const size_t ki = (size_t)b->order[oi];
+            ChainCore &k = *b->cores[ki];
+            hipStream_t st = b->streams[ki];
+            for (size_t kj = 0; kj < b->cores.size(); kj++)
+                if (kj != ki) CSDR_HIP(hipStreamWaitEvent(st, b->dc_done[kj], 0));
+            if (ok[ki]) {
+                const int rc = k.step_post(d_out, out_stride, b->d_out_rows[ki], stereo, st);
+                if (rc < 0 && !err) err = rc;
+            }
+            CSDR_HIP(hipEventRecord(b->joins[ki], st));
+            CSDR_HIP(hipStreamWaitEvent(caller, b->joins[ki], 0));
+        }
+        return err ? err : CSDR_OK;
+    }
+    // strict mode: CSDR_CHAIN_DC_CHAINED=0 starts every group's down-converter at once (A/B)
+    static const bool dc_chained = !(getenv("CSDR_CHAIN_DC_CHAINED") && atoi(getenv("CSDR_CHAIN_DC_CHAINED")) == 0);
     for (size_t oi = 0; oi < b->cores.size(); oi++) {
         const size_t ki = (size_t)b->order[oi];
         ChainCore &k = *b->cores[ki];
@@ -811,7 +955,7 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
                                   st, !b->pipelined && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, b->dc_done[ki]);
         else
             rc = k.step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_out_rows[ki], stereo, st,
-                        forked && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, forked ? b->dc_done[ki] : nullptr);
+                        forked && oi > 0 && dc_chained ? b->dc_done[b->order[oi - 1]] : nullptr, forked ? b->dc_done[ki] : nullptr);
         if (rc < 0 && !err) err = rc;
         if (forked) {                                   // join even after an error: the caller's stream stays ordered
             CSDR_HIP(hipEventRecord(b->joins[ki], st));  // the input has been consumed (+ filter and shift, strict mode)
@@ -864,6 +1008,12 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     int rc = csdr__noiseproc_batch_process_packets(nb, d_packets, npackets, pkt_len, b->d_blank, b->raw_cap, stream);
     if (rc < 0) return rc;
     return demod_batch_run(b, b->d_blank, b->raw_cap, (int)n, d_out, out_stride, stream, false);
+}
+int csdr_demod_batch_group_count(csdr_demod_batch *b, int *rows)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (rows) { *rows = 0; for (auto *k : b->cores) *rows += k->rows; }
+    return (int)b->cores.size();
 }
 /* audio samples channel `channel` received in the last process call */
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel)

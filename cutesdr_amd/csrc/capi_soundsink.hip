@@ -31,7 +31,8 @@ struct csdr_soundsink {
     double user_rate = kRate, out_ratio = 1.0, rate_corr = 0.0, gain = 1.0, ave_level = 0.0;
     int head = 0, tail = 0, level = 0, rate_count = 0, ppm = 0;
     bool blocking = false;                // m_BlockingMode
-    std::mutex mu;                        // m_Mutex
+    std::mutex mu;                        // m_Mutex: queue, fill average, rate controller, the parameters put() reads
+    std::mutex mu_put;                    // one producer at a time owns the resampler and its output buffer
     std::condition_variable cv;           // wakes a put that waits for room (the reference sleeps 10 ms and looks again)
     std::vector<short> q, r;              // the ring (2 shorts per entry when stereo), resampler output
 };
@@ -84,6 +85,7 @@ int csdr_soundsink_change_user_data_rate(csdr_soundsink *s, double rate)
 int csdr_soundsink_set_volume(csdr_soundsink *s, int vol)
 {
     if (!s) return csdr::fail(CSDR_EINVAL, "bad handle");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (vol == 0) s->gain = 0.0;
     else if (vol <= 99) s->gain = std::pow(10.0, ((double)vol - 99.0) / 39.2);
     return CSDR_OK;
@@ -95,27 +97,34 @@ int csdr_soundsink_put(csdr_soundsink *s, int n, const double *in)
 {
     if (!s || n < 0 || (n > 0 && !in)) return csdr::fail(CSDR_EINVAL, "bad argument");
     if (n == 0) return 0;
-    const double rate = 1.0 * s->out_ratio * (1.0 + s->rate_corr);            // TEST_ERROR * m_OutRatio * (1 + m_RateCorrection)
+    std::lock_guard<std::mutex> producer(s->mu_put);
+    double rate, gain;
+    {   // the rate and the gain as they are now: get() and the setters change them under the same mutex
+        std::lock_guard<std::mutex> lock(s->mu);
+        rate = 1.0 * s->out_ratio * (1.0 + s->rate_corr);          // TEST_ERROR * m_OutRatio * (1 + m_RateCorrection)
+        gain = s->gain;
+    }
     if ((double)n / rate + 8.0 > (double)kQ) return csdr::fail(CSDR_EINVAL, "call too long for the %d-entry queue", kQ);
-    const int k = s->stereo ? csdr_resampler_resample_cpx_i16(s->rs, n, rate, in, s->r.data(), s->gain)
-                            : csdr_resampler_resample_real_i16(s->rs, n, rate, in, s->r.data(), s->gain);
+    const int k = s->stereo ? csdr_resampler_resample_cpx_i16(s->rs, n, rate, in, s->r.data(), gain)
+                            : csdr_resampler_resample_real_i16(s->rs, n, rate, in, s->r.data(), gain);
     if (k < 0) return k;
     std::unique_lock<std::mutex> lock(s->mu);
+    int i = 0;
     if (s->blocking) {                                  // :209-220 / :267-278: wait while the queue is full, drop nothing
-        for (int i = 0; i < k; i++) {
-            while (((s->head + 1) & (kQ - 1)) == s->tail) {
-                if (!s->blocking) break;                // the mode was switched off while waiting
+        for (; i < k; i++) {
+            while (s->blocking && ((s->head + 1) & (kQ - 1)) == s->tail)
                 s->cv.wait_for(lock, std::chrono::milliseconds(10));
-            }
+            if (!s->blocking) break;                    // the mode was switched off while waiting: the rest of the call
+                                                        // takes the non-blocking branch below, queue-full rule included
             if (s->stereo) { s->q[2 * s->head] = s->r[2 * i]; s->q[2 * s->head + 1] = s->r[2 * i + 1]; }
             else s->q[s->head] = s->r[i];
             s->head = (s->head + 1) & (kQ - 1);
             s->level++;
         }
-        return k;
+        if (i == k) return k;
     }
     bool overflow = false;
-    for (int i = 0; i < k; i++) {
+    for (; i < k; i++) {
         if (s->stereo) { s->q[2 * s->head] = s->r[2 * i]; s->q[2 * s->head + 1] = s->r[2 * i + 1]; }
         else s->q[s->head] = s->r[i];
         s->head = (s->head + 1) & (kQ - 1);
@@ -173,14 +182,29 @@ int csdr_soundsink_get(csdr_soundsink *s, int n, short *out)
     }
     return n;
 }
-double csdr_soundsink_get_rate_correction(csdr_soundsink *s) { return s ? s->rate_corr : 0.0; }
-double csdr_soundsink_get_ave_level(csdr_soundsink *s) { return s ? s->ave_level : 0.0; }
+double csdr_soundsink_get_rate_correction(csdr_soundsink *s)
+{
+    if (!s) return 0.0;
+    std::lock_guard<std::mutex> lock(s->mu);
+    return s->rate_corr;
+}
+double csdr_soundsink_get_ave_level(csdr_soundsink *s)
+{
+    if (!s) return 0.0;
+    std::lock_guard<std::mutex> lock(s->mu);
+    return s->ave_level;
+}
 int csdr_soundsink_get_level(csdr_soundsink *s)
 {
     if (!s) return csdr::fail(CSDR_EINVAL, "bad handle");
     std::lock_guard<std::mutex> lock(s->mu);
     return s->level;
 }
-int csdr_soundsink_get_ppm_error(csdr_soundsink *s) { return s ? s->ppm : 0; }
+int csdr_soundsink_get_ppm_error(csdr_soundsink *s)
+{
+    if (!s) return 0;
+    std::lock_guard<std::mutex> lock(s->mu);
+    return s->ppm;
+}
 
 }  // extern "C"

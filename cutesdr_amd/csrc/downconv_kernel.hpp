@@ -238,6 +238,14 @@ __device__ __forceinline__ void dc_stage_full(const v2f *E, const v2f *O, v2f *y
         constexpr int NB = (NWIN + 1) / 2;
         constexpr int C0 = (L == 3) ? 0 : (H - 1) / 2;                // first odd-half sample: O[j + C0]
         constexpr int OB0 = C0 & ~1, NOB = (C0 - OB0 + (L == 3 ? G + 1 : G) + 1) / 2;
+        // Alignment and extent of the 16-byte window reads.  A region starts at an even slot (dc_layout_of rounds every
+        // half to an even length), j is a multiple of G and OB0 is even: E + j + 2i and O + j + OB0 + 2i are 16-byte
+        // aligned whatever the history's parity (only the OUTPUT halves, which start behind hist/2 slots, are 8-byte
+        // aligned: they are stored as v2f unless `last`).  An odd window is read one sample long; that sample and the
+        // whole last window lie inside the half, whose length is (hist/2 + NOUT + 2) & ~1:
+        constexpr int HALF = (dc_hist_of(L) / 2 + NOUT + 2) & ~1;
+        static_assert((NOUT >= G ? NOUT - G : 0) + 2 * NB <= HALF, "even-half window reads stay inside the stage's LDS half");
+        static_assert((NOUT >= G ? NOUT - G : 0) + OB0 + 2 * NOB <= HALF, "odd-half window reads stay inside the stage's LDS half");
         v2f r[PASSES][G];
         if (NOUT >= G * DC_T || G * t < NOUT) {
 #pragma unroll

@@ -24,6 +24,13 @@ inline bool agc_prepass()
     return on;
 }
 
+// CSDR_SM_CALL=0 keeps the S-meter inside the walk (A/B runs, diagnostics)
+inline bool smeter_whole_call()
+{
+    static const bool on = !(getenv("CSDR_SM_CALL") && atoi(getenv("CSDR_SM_CALL")) == 0);
+    return on;
+}
+
 // CSDR_PLL_OVERLAP=0: an FM tile whose PLL is not locked is walked by one thread, as before pll_overlap (A/B, tests)
 inline bool pll_overlap_on()
 {
@@ -39,6 +46,8 @@ struct PcUnit {
     double *d_sqbuf = nullptr; long sqbuf_cap = 0;       // per-burst records of the deferred FM squelch (fm_squelch_launch)
     float *d_pkbuf = nullptr, *d_magtail = nullptr; long pkbuf_cap = 0;   // AGC peaks of a call (agc_peaks_launch)
     bool no_output = false;
+    hipStream_t s_side = nullptr;                        // the whole-call S-meter runs here, beside the walk
+    hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     std::vector<PcChannel> h;            // host mirror (authoritative for parameters)
     std::vector<HostAgc> hagc;
     std::vector<HostFir> fir_am, fir_sam, fir_fm;
@@ -53,6 +62,9 @@ struct PcUnit {
         if (d_pkbuf) (void)hipFree(d_pkbuf);
         if (d_magtail) (void)hipFree(d_magtail);
         if (d_sm) (void)hipFree(d_sm);
+        if (s_side) { (void)hipStreamSynchronize(s_side); (void)hipStreamDestroy(s_side); }
+        if (ev_side_fork) (void)hipEventDestroy(ev_side_fork);
+        if (ev_side_join) (void)hipEventDestroy(ev_side_join);
     }
     int init(int dev, int nch)
     {
@@ -186,6 +198,31 @@ struct PcUnit {
             a.flags |= PC_FM_DEFER; a.sqbuf = d_sqbuf;
         }
         if (!pll_overlap_on()) a.flags |= PC_PLL_SEQ;
+        // the S-meter of a call of several bursts: one scan per receiver instead of two per walked tile, in front of
+        // the peaks kernel and the walk
+        bool sm_forked = false;
+        if ((a.flags & PC_DO_SMETER) && (long)nbursts * burst >= 4096 && smeter_whole_call()) {
+            // (a stream of its own: measured 2.31 against 1.80 ms strict and 4.7-6.1 against 1.74 pipelined -- with one more
+            // stream per plan group the process goes past the hardware queues it is given; opt-in for diagnostics only)
+            static const bool side = getenv("CSDR_SM_SIDE") && atoi(getenv("CSDR_SM_SIDE")) != 0;
+            const bool alone = !(a.flags & (PC_DO_AGC | PC_DO_DEMOD));
+            if (side && !alone) {
+                if (!s_side) {
+                    CSDR_HIP(hipStreamCreateWithFlags(&s_side, hipStreamNonBlocking));
+                    CSDR_HIP(hipEventCreateWithFlags(&ev_side_fork, hipEventDisableTiming));
+                    CSDR_HIP(hipEventCreateWithFlags(&ev_side_join, hipEventDisableTiming));
+                }
+                CSDR_HIP(hipEventRecord(ev_side_fork, stream));
+                CSDR_HIP(hipStreamWaitEvent(s_side, ev_side_fork, 0));
+                CSDR_HIP(smeter_call_launch(a, s_side));
+                CSDR_HIP(hipEventRecord(ev_side_join, s_side));
+                sm_forked = true;
+            } else {
+                CSDR_HIP(smeter_call_launch(a, stream));
+            }
+            a.flags &= ~PC_DO_SMETER;
+            if (alone) return CSDR_OK;
+        }
         // the AGC's log magnitudes and sliding maximum of the whole call: burst-parallel, in front of the walk
         a.pkbuf = nullptr; a.magtail = nullptr;
         bool pre = (flags & PC_DO_AGC) && !(flags & PC_AGC_REAL) && nbursts >= 4 && agc_prepass();
@@ -206,8 +243,16 @@ struct PcUnit {
             a.flags |= PC_AGC_PRE; a.pkbuf = d_pkbuf; a.magtail = d_magtail;
             CSDR_HIP(agc_peaks_launch(a, stream));
         }
+        {   // may the walk take its lean instantiation?  (the conditions its compiled-out code would have served)
+            bool any_fm = false, any_agc = false;
+            for (int c = 0; c < channels; c++) { any_fm = any_fm || h[c].mode == PC_MODE_FM; any_agc = any_agc || h[c].agc.on; }
+            const bool agc_ok = !(a.flags & PC_DO_AGC) || (!(a.flags & PC_AGC_REAL) && (pre || !any_agc));
+            const bool fm_ok = !(a.flags & PC_DO_DEMOD) || defer || !any_fm;
+            if (!(a.flags & PC_DO_SMETER) && agc_ok && fm_ok) a.flags |= PC_LEAN;
+        }
         CSDR_HIP(postchain_launch(a, stream));
         if (defer) CSDR_HIP(fm_squelch_launch(a, stream));
+        if (sm_forked) CSDR_HIP(hipStreamWaitEvent(stream, ev_side_join, 0));
         return CSDR_OK;
     }
 };

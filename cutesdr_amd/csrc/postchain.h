@@ -69,7 +69,9 @@ enum { PC_DO_SMETER = 1, PC_DO_AGC = 2, PC_DO_DEMOD = 4, PC_STEREO = 8, PC_AGC_R
                                         // and audio low-pass follow as their own burst-parallel launches (fm_squelch_launch)
        PC_AGC_PRE = 64,               // AGC: the log magnitudes and their sliding maximum (agc.cpp:196-231) come from a
                                         // burst-parallel launch in front of the walk (agc_peaks_launch), in pkbuf
-       PC_PLL_SEQ = 128 };              // FM: an unlocked tile is walked by one thread (no overlapped walks; A/B, tests)
+       PC_PLL_SEQ = 128,                // FM: an unlocked tile is walked by one thread (no overlapped walks; A/B, tests)
+       PC_LEAN = 256 };                 // set by PcUnit::run: no S-meter in this launch, every AGC row has its peaks in pkbuf,
+                                        // every FM row's squelch is deferred -- the walk may take its lean instantiation
 
 struct PcArgs {
     PcChannel *chan;                    // [channels]
@@ -94,6 +96,8 @@ hipError_t postchain_launch(const PcArgs &a, hipStream_t stream);
 hipError_t fm_squelch_launch(const PcArgs &a, hipStream_t stream);
 // CAgc's log magnitudes and sliding maximum of every sample of the call, for the walk that follows (PC_AGC_PRE)
 hipError_t agc_peaks_launch(const PcArgs &a, hipStream_t stream);
+// CSMeter over the whole call as one scan per receiver (the walk then runs without PC_DO_SMETER)
+hipError_t smeter_call_launch(const PcArgs &a, hipStream_t stream);
 hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, float *ave, float *peak, hipStream_t stream);
 hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows, double *ave, double *peak, hipStream_t stream);
 hipError_t filter_leaf_launch(PcFir *fir, PcIir *iir, const float *in, float *out, int n, int op, hipStream_t stream);

@@ -847,8 +847,9 @@ __device__ __forceinline__ bool pll_scan(const Wg<NW> &g, const float *th, int n
 // rho every sample (CFmDemod at 62.5 kHz: 0.47), a wrap moves the phase by whole turns only and a clamped frequency
 // is exact at once -- so by its first own sample a thread's state has met the sequential one.  That is checked, not
 // assumed: a thread's start state must equal its predecessor's end state to 1e-9 turns (the first threads start
-// from the true state at sample 0), and then by induction every state is the sequential one to that bound.  Any
-// mismatch -> false, and the caller walks the tile.  warm = pll_warm_len() samples: rho^(warm-8) < 1e-13; the eight
+// from the true state at sample 0), and then by induction every state is the sequential one TO THAT BOUND -- not bit
+// for bit: the audio of an accepted tile may differ from the one-thread walk's by rounding (tests: 1e-6 of full scale;
+// include/cutesdr_mi.h states the contract).  Any mismatch -> false, and the caller walks the tile.  warm = pll_warm_len() samples: rho^(warm-8) < 1e-13; the eight
 // on top are for a wrap decision that differs late in the warm-up (measured on noise: 32 samples at rho = 0.47 sent
 // a quarter of the tiles to the one-thread walk, 48 none: 1.92 -> 0.45 ms for 85 idle receivers x 2^20 samples, against
 // 0.34 ms with carriers).
@@ -968,8 +969,16 @@ __device__ __forceinline__ void sliding_max(const Wg<NW> &g, L &S, int W1, int n
 #ifndef CSDR_PC_WAVES_PER_EU
 #define CSDR_PC_WAVES_PER_EU 1
 #endif
-template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? CSDR_PC_WAVES_PER_EU : 1)))
+// LEAN: the walk of a chain call of several bursts, where everything without feedback has left it -- no S-meter
+// (smeter_call_kernel), the AGC's peaks from agc_peaks_kernel (PC_AGC_PRE), FM's squelch half deferred (PC_FM_DEFER).
+// The code those stages needed is compiled out: it never ran in such a launch, but its live ranges set the kernel's
+// register allocation (256 + 118 for the full kernel: one workgroup per CU and nothing but one down-converter wave
+// beside it on a SIMD).
+#ifndef CSDR_PC_LEAN_WAVES_PER_EU
+#define CSDR_PC_LEAN_WAVES_PER_EU 2
+#endif
+template <int NW, bool LEAN>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? (LEAN ? CSDR_PC_LEAN_WAVES_PER_EU : CSDR_PC_WAVES_PER_EU) : 1)))
 void postchain_kernel(PcArgs a)
 {
     using G = Wg<NW>;
@@ -993,12 +1002,12 @@ void postchain_kernel(PcArgs a)
     float *outm = a.out ? a.out + orow : nullptr;                               // mono
     float2 *outs = a.out ? reinterpret_cast<float2 *>(a.out) + orow : nullptr;  // stereo / complex
     const int mode = (a.flags & PC_DO_DEMOD) ? C.mode : PC_MODE_NONE;
-    const bool do_sm = a.flags & PC_DO_SMETER, do_agc = a.flags & PC_DO_AGC, agc_real = a.flags & PC_AGC_REAL;
+    const bool do_sm = !LEAN && (a.flags & PC_DO_SMETER), do_agc = a.flags & PC_DO_AGC, agc_real = !LEAN && (a.flags & PC_AGC_REAL);
     const bool cpx_out = stereo || mode == PC_MODE_NONE;
     // FM with the squelch deferred: this walk ends at the raw audio (fm_squelch_launch does the rest, burst-parallel)
-    const bool defer = (a.flags & PC_FM_DEFER) && mode == PC_MODE_FM && a.burst <= 16384;
+    const bool defer = LEAN ? mode == PC_MODE_FM : ((a.flags & PC_FM_DEFER) && mode == PC_MODE_FM && a.burst <= 16384);
     // AGC peaks from agc_peaks_kernel: the walk neither computes nor keeps the window's log magnitudes
-    const bool pre = (a.flags & PC_AGC_PRE) && do_agc && C.agc.on && !agc_real;
+    const bool pre = LEAN ? (do_agc && C.agc.on) : ((a.flags & PC_AGC_PRE) && do_agc && C.agc.on && !agc_real);
     const float *pkrow = pre ? a.pkbuf + (long)ch * a.nbursts * a.burst : nullptr;
 
     // scalar state, identical on every thread
@@ -1015,7 +1024,7 @@ void postchain_kernel(PcArgs a)
     // histories -> LDS
     if (do_agc && agc.on) {
         for (int i = t; i < D; i += NT) S.dl[i] = make_float2(g_dly[2 * i], g_dly[2 * i + 1]);
-        if (!pre) for (int i = t; i < W1; i += NT) S.mg[i] = g_mag[i];
+        if constexpr (!LEAN) if (!pre) for (int i = t; i < W1; i += NT) S.mg[i] = g_mag[i];
     }
     const PcFir *fir = mode == PC_MODE_AM ? &C.am.fir : mode == PC_MODE_SAM ? &C.sam.fir : mode == PC_MODE_FM ? &C.fm.hp : nullptr;
     const int nt = fir ? fir->ntaps : 1;
@@ -1080,7 +1089,7 @@ void postchain_kernel(PcArgs a)
             g.sync();
             PC_TICK(0);
             // ---------------- S-meter (smeter.cpp:62-93) ----------------
-            if (do_sm) {
+            if constexpr (!LEAN) if (do_sm) {
                 for (int i = t; i < n; i += NT) {
                     const float pw = (x[i].x * x[i].x + x[i].y * x[i].y) * (1.0f / (32767.0f * 32767.0f));
                     S.w2[i] = pw > 0.f ? 10.0f * log10f(pw) : -500.0f;
@@ -1099,7 +1108,7 @@ void postchain_kernel(PcArgs a)
                 } else {
                     if (pre) {
                         if (!kPrefetch) { for (int i = t; i < n; i += NT) S.pk[i] = pkrow[gi + i]; g.sync(); }
-                    } else {
+                    } else if constexpr (!LEAN) {
                         float *mg = S.mg + W1;
                         for (int i = t; i < n; i += NT) {
                             float m = fabsf(x[i].x);
@@ -1271,7 +1280,7 @@ void postchain_kernel(PcArgs a)
                     // keeps it in LDS instead: the low-pass at the end of the burst reads it from there)
                     if (a.burst > PT || defer)
                         for (int i = t; i < n; i += NT) { if (stereo) outs[gi + i] = make_float2(au[i], au[i]); else outm[gi + i] = au[i]; }
-                    if (a.burst <= 16384 && !defer) {                     // MAX_SQBUF_SIZE
+                    if constexpr (!LEAN) if (a.burst <= 16384 && !defer) {                     // MAX_SQBUF_SIZE
                         float acc[LC];
                         fir_blk<NW>(S.h0, nt, S.w0, t, acc);
 #pragma unroll
@@ -1356,7 +1365,7 @@ void postchain_kernel(PcArgs a)
             }
         }
         // ---------------- end of burst: FM squelch decision (fmdemod.cpp:128-151) ----------------
-        if (mode == PC_MODE_FM && a.burst <= 16384 && !defer) {
+        if constexpr (!LEAN) if (mode == PC_MODE_FM && a.burst <= 16384 && !defer) {
             const PcFm &F = C.fm;
             if (0 == F.sq_thresh) fm_squelched = 1;
             else if (fm_squelched) { if (fm_sq < (F.sq_thresh - 100.0)) fm_squelched = 0; }
@@ -1398,7 +1407,7 @@ void postchain_kernel(PcArgs a)
     if (do_agc && agc.on) {
         for (int i = t; i < D; i += NT) { g_dly[2 * i] = S.dl[i].x; g_dly[2 * i + 1] = S.dl[i].y; }
         if (pre) { const float *tail = a.magtail + (long)ch * PC_AGC_RING; for (int i = t; i < W1; i += NT) g_mag[i] = tail[i]; }
-        else for (int i = t; i < W1; i += NT) g_mag[i] = S.mg[i];
+        else if constexpr (!LEAN) for (int i = t; i < W1; i += NT) g_mag[i] = S.mg[i];
     }
     if (fir && !defer) {
         PcFir *fw = const_cast<PcFir *>(fir);
@@ -1494,6 +1503,72 @@ hipError_t agc_peaks_launch(const PcArgs &a, hipStream_t stream)
     if (b.pre_bpw < 1) b.pre_bpw = 1;
     const int ngrp = (a.nbursts + b.pre_bpw - 1) / b.pre_bpw;
     hipLaunchKernelGGL(agc_peaks_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(PreLds), stream, b);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// CSMeter (smeter.cpp:62-93) over a WHOLE call, out of the walk (round 4).  The meter feeds nothing -- its averages
+// go to the GUI -- and both of them are compositions of associative maps (the attack average an affine one, the decay
+// average x -> max(A x + B, C)), so nothing about them is sequential: one workgroup per receiver takes the call in
+// super-tiles of 8192 samples, a thread owning 32 CONSECUTIVE samples of a super-tile (power -> dB once, staged in
+// LDS with a pad word every 32 so that both the coalesced fill and the per-thread runs are conflict-free), and pays
+// two workgroup scans per 8192 samples where the walk paid two per 1024 -- a quarter to a half of a walked tile's
+// time (S-meter alone as a walk: 4.5 us per 1024 samples, 290 us per call; here ~20 us).  The same fp64 maps as
+// smeter_tile, chunked differently: states agree to rounding (1e-15 relative).
+// =====================================================================================================
+constexpr int SM_ST = 8192, SM_LC = SM_ST / 256;
+struct SmLds {
+    PcSync sy;
+    alignas(16) float db[SM_ST + SM_ST / 32];
+    double pw[SM_LC + 1];                                // (1 - att_a)^k
+};
+__global__ __launch_bounds__(256)
+void smeter_call_kernel(PcArgs a)
+{
+    using G = Wg<4>;
+    __shared__ SmLds S;
+    const int t = threadIdx.x, ch = blockIdx.x;
+    if (a.out_rows && a.out_rows[ch] < 0) return;
+    const G g{t, t & 63, t >> 6, &S.sy};
+    PcChannel &C = a.chan[ch];
+    PcSMeter sm = C.sm;
+    const double aa = sm.att_a, ia = 1.0 - sm.att_a, da = sm.dec_a, id = 1.0 - sm.dec_a;
+    if (t <= SM_LC) { double p = 1.0; for (int k = 0; k < t; k++) p *= ia; S.pw[t] = p; }
+    const float2 *in = reinterpret_cast<const float2 *>(a.in) + (long)ch * a.in_stride;
+    const long total = (long)a.nbursts * a.burst;
+    for (long p0 = 0; p0 < total; p0 += SM_ST) {
+        const int n = (int)((total - p0) < SM_ST ? (total - p0) : SM_ST);
+        g.sync();                                        // the previous super-tile's runs have been read (and S.pw written)
+        for (int i = t; i < n; i += 256) {
+            const float2 v = in[p0 + i];
+            const float pw = (v.x * v.x + v.y * v.y) * (1.0f / (32767.0f * 32767.0f));
+            S.db[i + (i >> 5)] = pw > 0.f ? 10.0f * log10f(pw) : -500.0f;
+        }
+        g.sync();
+        const int base = SM_LC * t;
+        int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > SM_LC ? SM_LC : cnt);
+        const float *run = S.db + base + t;              // = index(base + j) for j < 32
+        double p = 0.0, pk = -1.0e300;
+        for (int j = 0; j < cnt; j++) { const double x = (double)run[j]; p = ia * p + aa * x; pk = fmax(pk, x); }
+        double A = S.pw[cnt], B = p, At, Bt;
+        g.scan1_max(A, B, At, Bt, pk);
+        double att = A * sm.att_ave + B;                 // attack average entering this thread's run
+        const double att_end = At * sm.att_ave + Bt;
+        double MA = 1.0, MB = 0.0, MC = -1.0e300, TA, TB, TC;
+        for (int j = 0; j < cnt; j++) {
+            const double x = (double)run[j];
+            att = ia * att + aa * x;
+            MA = id * MA; MB = id * MB + da * x; MC = fmax(id * MC + da * x, att);
+        }
+        g.scan_max(MA, MB, MC, TA, TB, TC);
+        const double dec_end = fmax(TA * sm.dec_ave + TB, TC);
+        sm.att_ave = att_end; sm.dec_ave = dec_end; sm.ave_mag = dec_end; sm.peak_mag = fmax(sm.peak_mag, pk);
+    }
+    if (t == 0) C.sm = sm;
+}
+hipError_t smeter_call_launch(const PcArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smeter_call_kernel, dim3(a.channels), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1786,16 +1861,16 @@ hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows,
     return hipGetLastError();
 }
 
-template <int NW>
+template <int NW, bool LEAN>
 static hipError_t pc_launch_nw(const PcArgs &a, hipStream_t stream)
 {
     // per launch: the attribute belongs to the current device, and a process may drive several
     if (sizeof(PcLds) > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&postchain_kernel<NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&postchain_kernel<NW, LEAN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PcLds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(postchain_kernel<NW>, dim3(a.channels), dim3(64 * NW), sizeof(PcLds), stream, a);
+    hipLaunchKernelGGL((postchain_kernel<NW, LEAN>), dim3(a.channels), dim3(64 * NW), sizeof(PcLds), stream, a);
     return hipGetLastError();
 }
 hipError_t postchain_launch(const PcArgs &a, hipStream_t stream)
@@ -1804,10 +1879,14 @@ hipError_t postchain_launch(const PcArgs &a, hipStream_t stream)
     if (forced < 0) { const char *env = getenv("CSDR_POSTCHAIN_WAVES"); forced = env ? atoi(env) : 0; }
     int nw = a.channels <= 1024 ? 4 : 1;
     if (forced == 1 || forced == 4 || forced == 8) nw = forced;
+    // the lean walk (four waves): no S-meter in the launch, AGC peaks precomputed for every receiver that has the AGC
+    // on, the squelch of every FM receiver deferred -- the caller (PcUnit::run) says so with PC_LEAN
+    static const bool lean_ok = !(getenv("CSDR_PC_LEAN") && atoi(getenv("CSDR_PC_LEAN")) == 0);
+    if (nw == 4 && (a.flags & PC_LEAN) && lean_ok) return pc_launch_nw<4, true>(a, stream);
     switch (nw) {
-    case 8:  return pc_launch_nw<8>(a, stream);
-    case 4:  return pc_launch_nw<4>(a, stream);
-    default: return pc_launch_nw<1>(a, stream);
+    case 8:  return pc_launch_nw<8, false>(a, stream);
+    case 4:  return pc_launch_nw<4, false>(a, stream);
+    default: return pc_launch_nw<1, false>(a, stream);
     }
 }
 

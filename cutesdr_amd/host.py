@@ -589,6 +589,12 @@ class DemodBatch(_Obj):
     def out_count(self, channel):
         return check(lib().csdr_demod_batch_out_count(self.h, channel))
 
+    def group_count(self):
+        """(plan groups, rows of all groups incl. muted ones)"""
+        rows = C.c_int(0)
+        g = check(lib().csdr_demod_batch_group_count(self.h, C.byref(rows)))
+        return g, rows.value
+
     def set_pipelined(self, on=True):
         check(lib().csdr_demod_batch_set_pipelined(self.h, int(on)), "set_pipelined")
 

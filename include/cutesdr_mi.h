@@ -268,7 +268,13 @@ double csdr_demod_batch_get_smeter_ave(csdr_demod_batch *b, int channel);
  * (either may be NULL); reading the peaks resets them, as GetPeak does.  Asynchronous on `stream`: ordered
  * behind the process calls issued on it.  What a multi-GPU host gathers from its ranks. */
 int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_peak, void *stream);
-/* d_in [channels][in_stride] complex fp32 -> d_out [channels][out_stride] fp32 mono audio */
+/* d_in [channels][in_stride] complex fp32 -> d_out [channels][out_stride] fp32 mono audio.
+ * Numerical contract of the recurrent stages: the scans that replace the reference's per-sample loops (averagers,
+ * AGC, locked PLL tiles) differ from the sequential fp64 loop by rounding only, and an FM tile whose loop is NOT
+ * locked is walked by all threads at once, each from a warmed-up state that is CHECKED to meet its predecessor's to
+ * 1e-9 turns -- a bound, not bit equality: the audio of such tiles (noise, acquisition) can differ from a one-thread
+ * walk, and between builds with another tiling, by up to ~1e-6 of full scale (tests: 1e-6; CSDR_PLL_OVERLAP=0 selects
+ * the one-thread walk).  Strict and pipelined mode run the same kernels with the same tiling: identical words. */
 int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
                              int n_per_channel, float *d_out, long long out_stride, void *stream);
 /* Pipelined mode for streaming hosts (off by default).  on != 0: the three stages of a call (down-converter |
@@ -287,6 +293,11 @@ int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream);
 int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long long in_stride,
                                     int n_per_channel, float *d_out_iq, long long out_stride, void *stream);
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
+/* Diagnostics: the number of plan groups the batch runs per call (rows that share one decimation; every group is one
+ * set of launches), and with rows != NULL the number of rows -- live and muted -- of all groups.  A mode change to a
+ * chain of the same decimation stays in its row; one to another decimation moves the receiver into a muted row of a
+ * matching group when there is one, else into a group of its own; a group whose rows are all muted is dropped. */
+int csdr_demod_batch_group_count(csdr_demod_batch *b, int *rows);
 /* The same pass fed with the datagrams as they arrived (interface/netiobase.cpp:479-527):
  * d_packets [channels][npackets][pkt_len] bytes on the device, 4-byte aligned, pkt_len 1028 (16 bit) or 1444
  * (24 bit).  No unpack pass: the first kernel at input rate decodes the datagrams in its own loads -- the

@@ -381,3 +381,73 @@ def test_receivers_cut_from_shared_streams(oracle, pipelined):
     with pytest.raises(ca._capi.CsdrError):
         b.set_input_rows(np.full(C, C, dtype=np.int32))        # a row the batch cannot have
     b.set_input_rows(None)
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["strict", "pipelined"])
+def test_mode_changes_do_not_grow_the_batch(oracle, pipelined):
+    """What a committed batch does with SetDemod (dsp/demodulator.cpp:107-157), group by group: a change of the SAME
+    mode's bandwidth limits stays in its row (the reference rebuilds the down-converter only when the mode changes,
+    :111-121); a new mode whose chain has the same decimation stays in its row too (FM <-> USB at 2 MSPS: both /32);
+    one with another decimation moves the receiver -- into the muted row an earlier mover left when the staging fill
+    matches (retuning back and forth does not add groups), and a group left with muted rows only is dropped.  The
+    audio follows oracle chains that get the same SetDemod calls throughout."""
+    import cutesdr_amd as ca
+    C, fs, lim = 6, 2e6, 19968
+    n = 64 * lim                                               # whole CDemodulator windows AND whole hops for every
+                                                               # decimation: every group's staging fill is equal (empty)
+    names = ["FM", "FM", "FM", "AM", "AM", "USB"]
+    calls = 6
+    x = np.stack([chain_input("FM" if c < 3 else names[c], calls * n, fs) * np.exp(2j * np.pi * 900.0 * c * np.arange(calls * n) / fs)
+                  for c in range(C)]).astype(np.complex64)
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    refs, modes = [], list(names)
+    for c in range(C):
+        m, kw = MODES[names[c]]
+        b.set_demod(c, m, info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-100e3 - 900.0 * c)
+        refs.append(r)
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -100e3 - 900.0 * c)
+    if pipelined:
+        b.set_pipelined(True)
+    g0 = b.group_count()
+    assert g0 == (3, 6)                                        # FM (3 rows), AM (2), USB (1)
+    since = [0] * C
+
+    def change(c, name, **more):
+        m, kw = MODES[name]
+        kw = dict(kw, **more)
+        b.set_demod(c, m, info(ca, **kw)); refs[c].SetDemod(m, info(oracle, **kw))
+        assert b.output_rate(c) == refs[c].GetOutputRate()
+        if modes[c] != name:
+            since[c] = 0
+        modes[c] = name
+    steps = {
+        1: lambda: change(1, "FM", HiCutmax=12000, HiCut=4000, LowCut=-4000),   # same mode, other limits: in place
+        2: lambda: change(0, "USB"),                           # FM -> USB: same decimation, in place (row keeps its group)
+        3: lambda: change(2, "AM"),                            # FM -> AM: another decimation, nobody left a row there: new group
+        4: lambda: change(3, "FM"),                            # AM -> FM: into the row receiver 2 left in the FM group
+        5: lambda: (change(2, "FM"), change(4, "FM")),         # 2 is alone in its group: in place; 4 leaves the AM group, whose
+                                                               # rows are now all muted: the group is dropped
+    }
+    want_groups = {1: (3, 6), 2: (3, 6), 3: (4, 7), 4: (4, 7)}
+    for k in range(calls):
+        if k in steps:
+            steps[k]()
+            if k in want_groups:
+                assert b.group_count() == want_groups[k], (k, b.group_count())
+        part = x[:, k * n:(k + 1) * n]
+        got = b.process(part)
+        for c in range(C):
+            want = refs[c].process_append(part[c].astype(np.complex128))
+            assert len(got[c]) == len(want), (c, k, modes[c])
+            if len(want):
+                check_chain_bursts(burst_errors(got[c], want), modes[c] if modes[c] == "FM" else "other", since[c], (c, k, modes[c]),
+                                   from_zero=5e-4 * FULL_SCALE)
+                since[c] += len(want) // 1024
+    groups, rows = b.group_count()
+    assert groups <= 4 and rows <= 8, (groups, rows)          # six receivers never needed more than one spare row each way
+    sm = b.smeter_all()
+    for c in range(C):
+        assert float(sm[c]) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02), c
