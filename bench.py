@@ -226,43 +226,117 @@ def profiled_traffic():
     return None
 
 
-def live_traffic(timeout_s=150):
-    """HBM bytes per launch of the headline kernel MEASURED IN THIS RUN: two short child runs of this script under
-    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in passes of their own, as the guide prescribes; never with a trace
-    domain), the kernel's per-launch means combined with the guide's gfx950 correction (FETCH_SIZE counts half of a
-    wide coalesced read).  Rank 0 at N = 1 only, after everything timed.  None when the profiler is not there or a
-    pass fails -- the caller then falls back to the committed profile (same-sources hash) or null."""
+K2_ALONE_GRID = 8192 * 64          # 256 receivers x 32 segments, one wave each (capi_downconv.hip's segment rule)
+
+
+def live_traffic(timeout_s=240):
+    """HBM bytes per launch MEASURED IN THIS RUN for the headline kernel and for the secondary objects: two child runs
+    of this script (`--pmc-child`: a few launches of every workload) under `rocprofv3 --pmc`, FETCH_SIZE and
+    WRITE_SIZE in passes of their own as the guide prescribes (never with a trace domain), per-dispatch values grouped
+    by kernel and combined with the guide's gfx950 correction (FETCH_SIZE counts half of a coalesced read; calibrated
+    for 4-, 8- and 16-byte loads in profiles/r03_fetch_calib.json): (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Rank 0 at
+    N = 1 only, after everything timed.  None when the profiler is not there or a pass fails -- the caller then falls
+    back to the committed profile (same-sources hash) or null."""
     import csv, glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
     out = tempfile.mkdtemp(prefix="csdr_pmc_")
-    means = {}
+    per = {}                                              # counter -> object -> KiB per launch / step
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--no-cpu", "--no-check", "--no-secondary", "--steps", "5", "--warmup", "1"]
+                   "--pmc-child"]
             env = dict(os.environ, TMPDIR=out)
             r = subprocess.run(cmd, cwd=out, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
             if r.returncode != 0:
                 return None
-            vals = []
+            counts = None
+            for line in r.stdout.decode(errors="replace").splitlines():
+                if line.startswith('{"pmc_child"'):
+                    counts = json.loads(line)["pmc_child"]
+            if not counts:
+                return None
+            acc = {"k1": [], "k2": [], "k3": 0.0, "k6": [], "chain": 0.0}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "fastfir_os2_kernel<14>" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if len(vals) < 3:
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] != counter or "csdr" not in name:
+                        continue
+                    v = float(row["Counter_Value"])
+                    if "fastfir_os2_kernel<14>" in name:
+                        acc["k1"].append(v)
+                    elif "downconv_kernel" in name and int(row.get("Grid_Size", 0)) == K2_ALONE_GRID:
+                        acc["k2"].append(v)
+                    elif "spectrum" in name:
+                        acc["k3"] += v
+                    elif "noiseblank_kernel" in name:
+                        acc["k6"].append(v)
+                    else:
+                        acc["chain"] += v
+            if len(acc["k1"]) < 3:
                 return None
-            means[counter] = sum(vals) / len(vals)
-        return {"bytes": (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0,
-                "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this script (KiB means per launch; "
-                          "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md)",
-                "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1)}
+            mean = lambda v: sum(v) / len(v) if v else None
+            per[counter] = {"k1": mean(acc["k1"]), "k2": mean(acc["k2"]), "k6": mean(acc["k6"]),
+                            "k3": acc["k3"] / counts["k3"] if counts.get("k3") else None,
+                            "chain": acc["chain"] / counts["chain"] if counts.get("chain") else None}
+        res = {}
+        for key in ("k1", "k2", "k3", "k6", "chain"):
+            f, w = per["FETCH_SIZE"].get(key), per["WRITE_SIZE"].get(key)
+            res[key] = None if f is None or w is None else {"bytes": (2.0 * f + w) * 1024.0, "FETCH_SIZE_KiB": round(f, 1),
+                                                            "WRITE_SIZE_KiB": round(w, 1)}
+        res["source"] = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this script (KiB means per launch; "
+                         "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md)")
+        return res
     except Exception:
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def run_pmc_child():
+    """A few launches of every workload for the counter passes of live_traffic(): C3 (K1), then on the C4 buffer K2
+    alone, K3, K6 and whole strict chain steps.  Prints how many launches / steps of each ran."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    import torch
+    import cutesdr_amd as ca
+    ctx = dist_init()
+    torch.cuda.set_device(ctx.local)
+    w = C3Workload(torch, ca, ctx, CHANNELS)
+    for _ in range(6):
+        w.step()
+    torch.cuda.synchronize()
+    del w
+    torch.cuda.empty_cache()
+    c4 = C4Workload(torch, ca, ctx, CHANNELS)
+    st = torch.cuda.current_stream().cuda_stream
+    C, T = c4.x.shape[0], c4.x.shape[1]
+    dc = ca.DownConvertBatch(C, device=ctx.local)
+    dc.set_data_rate(C4_FS, 15000.0)
+    y = torch.empty((C, T // 16, 2), device=c4.x.device, dtype=torch.float32)
+    for _ in range(3):
+        dc.process_ptr(c4.x.data_ptr(), T, T, y.data_ptr(), T // 16, st)
+    torch.cuda.synchronize()
+    del dc, y
+    fb = ca.FftBatch(C, device=ctx.local)
+    fb.set_params(4096, False, 0.0, C4_FS); fb.set_ave(1)
+    for _ in range(3):
+        fb.put_display_ptr(c4.x.data_ptr(), T, 512, st)
+    torch.cuda.synchronize()
+    del fb
+    nb = ca.NoiseProcBatch(C, device=ctx.local)
+    nb.setup(True, 50.0, 2.0, C4_FS)
+    xb = torch.empty_like(c4.x)
+    for _ in range(3):
+        nb.process_ptr(c4.x.data_ptr(), T, T, xb.data_ptr(), T, st)
+    torch.cuda.synchronize()
+    del nb, xb
+    c4.set_mode(False)
+    for _ in range(4):
+        c4.step()
+    torch.cuda.synchronize()
+    print(json.dumps({"pmc_child": {"k1": 6, "k2": 3, "k3": 3, "k6": 3, "chain": 4}}), flush=True)
 
 
 # ---------------------------------------------------------------- CPU baseline
@@ -355,6 +429,30 @@ def gpu_ms(torch, fn, warm, reps):
     return e0.elapsed_time(e1) / reps
 
 
+FULL_SCALE = 32767.0
+
+
+def chain_burst_check(got, want, mode, hop=1024):
+    """The chain rule the parity tests apply burst by burst (tests/test_postchain_gpu.py: check_chain_bursts; a burst =
+    one FastFIR hop of audio: 1024 samples behind the 2048-point filter, 8192 behind the 16384-point one), on the common prefix of the product's audio and the oracle's.  FM: 1e-3 of
+    full scale from the 4th burst, 3e-5 from the 7th (its first bursts demodulate the filter's start-up, DESIGN
+    section 5); the other modes: 5e-4 from sample 0, 2e-5 from the 3rd burst."""
+    import numpy as np
+    n = (min(len(got), len(want)) // hop) * hop
+    if n == 0:
+        return {"bursts": 0, "ok": False}
+    e = np.abs(np.asarray(got[:n], dtype=np.float64) - np.asarray(want[:n], dtype=np.float64)).reshape(-1, hop).max(axis=1) / FULL_SCALE
+    idx = np.arange(len(e))
+    if mode == "FM":
+        early, steady, t_early, t_steady = e[(idx >= 3) & (idx < 6)], e[idx >= 6], 1e-3, 3e-5
+    else:
+        early, steady, t_early, t_steady = e[idx < 2], e[idx >= 2], 5e-4, 2e-5
+    ok = bool((early <= t_early).all() and (steady <= t_steady).all())
+    return {"bursts": int(len(e)), "max_err_early_over_full_scale": float(early.max()) if len(early) else None,
+            "max_err_steady_over_full_scale": float(steady.max()) if len(steady) else None,
+            "tolerance_early": t_early, "tolerance_steady": t_steady, "ok": ok}
+
+
 def fm_defaults(mod):
     return mod.DemodInfo(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
                          FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
@@ -389,13 +487,17 @@ def spectrum_c1(torch, ca, ctx, x, with_cpu):
     ms = gpu_ms(torch, lambda: fb.put_display_ptr(x.data_ptr(), T, frames, st), 10, 20)
     bins = C * frames * N
     moved = bins * 8.0 + C * N * 4.0
+    # headline of this object: the bytes the kernel MOVES (8 B per bin read + the last frame's bels written); the
+    # survey's 12 B per bin (every frame's 4-byte result counted, two thirds of which the kernel never writes) is kept
+    # beside it under its own name
     out = {"config": "C1: 4096-pt CFft display spectrum (Hann, ave 1) @2 MSPS, %d channels x %d frames per launch" % (C, frames),
            "kernel": "csdr::spectrum16_kernel (4096 points as 256 threads x 16; + its frame-group combine)", "ms_per_launch": round(ms, 4),
            "MSamples_per_s": round(bins / ms / 1e3, 1),
-           "algorithmic_GBps_at_12B_per_bin": round(bins * 12.0 / ms / 1e6, 1),
-           "frac_at_12B_per_bin": round(bins * 12.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
-           "bytes_moved_per_launch": moved, "GBps_on_bytes_moved": round(moved / ms / 1e6, 1),
-           "frac_on_bytes_moved": round(moved / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
+           "roofline": roofline_obj(moved / ms / 1e6, ms, "csdr::spectrum16_kernel + spectrum_alpha / combine / count kernels", moved, None),
+           "frac_of_hbm_peak": round(moved / ms / 1e6 / HBM_PEAK_GBS, 4),
+           "at_survey_12B_per_bin": {"algorithmic_GBps": round(bins * 12.0 / ms / 1e6, 1),
+                                     "frac": round(bins * 12.0 / ms / 1e6 / HBM_PEAK_GBS, 4)},
+           "cpu_baseline": None}
     if with_cpu:
         from oracle import oracle as orc
         f = orc.CFft()
@@ -428,7 +530,8 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
     alg = C * T * (8.0 + 8.0 / 32.0)
     out["downconv_k2"] = {"config": "K2 alone: %d receivers x 2^%d samples @2 MSPS, chain 11,11,15,19,31 -> 62.5 kS/s" % (C, T.bit_length() - 1),
                           "kernel": "csdr::downconv_kernel<DcPlanT<11,11,15,19,31>>", "ms_per_launch": round(ms, 4),
-                          "raw_input_MSamples_per_s": round(C * T / ms / 1e3, 1), "algorithmic_GBps": round(alg / ms / 1e6, 1),
+                          "raw_input_MSamples_per_s": round(C * T / ms / 1e3, 1),
+                          "roofline": roofline_obj(alg / ms / 1e6, ms, "csdr::downconv_kernel<DcPlanT<11,11,15,19,31>>", alg, None),
                           "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
     del y, dc
     nb = ca.NoiseProcBatch(C, device=ctx.local)
@@ -437,7 +540,8 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
     ms = gpu_ms(torch, lambda: nb.process_ptr(x.data_ptr(), T, T, xb.data_ptr(), T, st), 5, 10)
     out["blanker_k6"] = {"config": "K6 alone: CNoiseProc::ProcessBlanker (threshold 50, width 2 us) on %d receivers x 2^%d samples" % (C, T.bit_length() - 1),
                          "kernel": "csdr::noiseblank_kernel", "ms_per_launch": round(ms, 4),
-                         "MSamples_per_s": round(C * T / ms / 1e3, 1), "algorithmic_GBps": round(C * T * 16.0 / ms / 1e6, 1),
+                         "MSamples_per_s": round(C * T / ms / 1e3, 1),
+                         "roofline": roofline_obj(C * T * 16.0 / ms / 1e6, ms, "csdr::noiseblank_kernel", C * T * 16.0, None),
                          "frac_of_hbm_peak": round(C * T * 16.0 / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
     del xb, nb
     if with_cpu:
@@ -454,7 +558,7 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
     return out
 
 
-def chain_one_receiver(torch, ca, ctx, with_cpu, name):
+def chain_one_receiver(torch, ca, ctx, with_cpu, name, check=True):
     """BASELINE configs C2 (2 MSPS -> CDownConvert -> 16384-pt CFastFIR -> AGC -> FM) and C5 (10 MSPS -> ... 2048-pt
     filter -> FM -> CFractResampler to 48 kHz): ONE receiver resident in HBM.  A single receiver cannot fill the
     chip: these are latency-bound rates, reported as such (no roofline fraction is claimed for them)."""
@@ -487,6 +591,32 @@ def chain_one_receiver(torch, ca, ctx, with_cpu, name):
     out = {"config": label, "ms_per_call": round(ms, 3), "raw_input_MSamples_per_s": round(T / ms / 1e3, 1),
            "x_real_time": round(T / ms / 1e3 / (fs / 1e6), 1), "output_rate": out_rate,
            "bound": "latency of one receiver's sequential stages (one workgroup walks its bursts)", "cpu_baseline": None}
+    if check:
+        # the buffer that was just timed, through a FRESH object (the timed one has seen it a dozen times), against the
+        # oracle's CDemodulator on the same samples -- the call length (2^23 / 2^24) is not a multiple of m_InBufLimit:
+        # the oracle holds back its last partial window, the common prefix is compared
+        from oracle import oracle as orc
+        fb = ca.DemodBatch(1, nfft, device=ctx.local)
+        fb.set_input_rate(fs); fb.set_demod(0, ca.DEMOD_FM, fm_defaults(ca)); fb.commit(); fb.set_freq(0, -fc)
+        aud.zero_()
+        fb.process_ptr(x.data_ptr(), T, T, aud.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        got = aud[0, :fb.out_count(0)].cpu().numpy()
+        ro = orc.CDemodulator(nfft)
+        ro.SetInputSampleRate(fs); ro.SetDemod(orc.DEMOD_FM, fm_defaults(orc)); ro.SetDemodFreq(-fc)
+        want = ro.process_append(to_c128(x[0]))
+        out["parity_checked"] = dict(chain_burst_check(got, want, "FM", hop=nfft // 2), receiver="the timed buffer, one call of 2^%d samples "
+                                     "through a fresh object vs oracle CDemodulator::ProcessData" % (T.bit_length() - 1))
+        if rs:
+            rs2 = ca.ResamplerBatch(1, device=ctx.local)
+            k = len(want) // 1024 * 1024
+            rs2.resample_ptr(aud.data_ptr(), cap, k, rate, pcm.data_ptr(), pcm.shape[1], None, st)
+            torch.cuda.synchronize()
+            q = orc.CFractResampler(); q.Init(k + 64)           # one call, like the timed step: the same output times
+            ref = q.Resample(want[:k], rate)
+            pg = pcm[0, :len(ref)].cpu().numpy()
+            out["parity_checked"]["resampled"] = chain_burst_check(pg, ref, "FM")
+        del fb
     if with_cpu:
         from oracle import oracle as orc
         r = orc.CDemodulator(nfft)
@@ -727,6 +857,38 @@ class C4Workload:
         self.b = self.make_batch(pipelined)
         self.mode = want
 
+    def parity_check(self, receivers=(0, 1, 2)):
+        """The buffer that was just timed through a FRESH batch object of all the receivers, one call of 2^21 samples
+        (not a multiple of m_InBufLimit = 19968), receivers 0-2 (AM, FM, USB) against the oracle's CDemodulator on the
+        same samples -- the chain rule of the parity tests, burst by burst, on the common prefix (the oracle holds back
+        its last partial window)."""
+        from oracle import oracle as orc
+        torch = self.torch
+        b = self.make_batch(False)
+        aud = torch.zeros_like(self.aud)
+        b.process_ptr(self.x.data_ptr(), self.T, self.T, aud.data_ptr(), self.cap, self.stream)
+        torch.cuda.synchronize()
+        base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                    FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
+                    AgcManualGain=30, AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+        modes = [("AM", orc.DEMOD_AM, dict(HiCutmin=500, HiCutmax=10000, LowCutmax=-500, LowCutmin=-10000)), ("FM", orc.DEMOD_FM, dict()),
+                 ("USB", orc.DEMOD_USB, dict(HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200, LowCutmin=0, Symetric=0))]
+        lo, _ = shard_channels(self.ctx, self.C * self.ctx.world)
+        res, ok = [], True
+        for c in receivers:
+            name, m, kw = modes[(lo + c) % 3]
+            r = orc.CDemodulator(2048)
+            r.SetInputSampleRate(C4_FS); r.SetDemod(m, orc.DemodInfo(**dict(base, **kw)))
+            r.SetDemodFreq(-(100e3 + 500.0 * ((lo + c) % 1024)))
+            want = r.process_append(to_c128(self.x[c]))
+            got = aud[c, :b.out_count(c)].cpu().numpy()
+            chk = dict(chain_burst_check(got, want, name), receiver=c, mode=name)
+            ok = ok and chk["ok"]
+            res.append(chk)
+        del b, aud
+        return {"receivers": res, "samples_per_receiver": self.T, "ok": ok,
+                "what": "the timed buffer, one call through a fresh strict-mode object vs oracle CDemodulator::ProcessData"}
+
     def cpu_baseline(self, budget_s=4.0):
         """the oracle's CDemodulator on ONE host core over the first three receivers' own streams (AM, FM, USB by
         turns, like the shard), m_InBufLimit windows: raw input samples per second and core"""
@@ -751,7 +913,7 @@ class C4Workload:
         v, n = cpu_rate(once, 3 * len(streams[0]), budget_s)
         return cpu_obj(v, n, "CDemodulator::ProcessData (dsp/demodulator.cpp:163-215) on receivers 0-2 of the shard")
 
-    def summary(self, ctx, steps, warmup, with_cpu=False):
+    def summary(self, ctx, steps, warmup, with_cpu=False, check=True):
         """both modes of csdr_demod_batch: `pipelined` (successive calls overlapped, a call's results are complete one
         call later: what a streaming host uses) is the headline of this object, `strict` (complete in stream order
         when the call returns) is reported beside it"""
@@ -768,6 +930,11 @@ class C4Workload:
                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}    # (the pipelined mode needs more than HIP's default 4)
         out.update(one(True))
         out["strict"] = strict
+        alg = (8.0 + 4.0 / 32.0) * n
+        out["roofline"] = roofline_obj(alg / strict["event_ms_per_step"] / 1e6, strict["event_ms_per_step"],
+                                       "whole chain, strict mode: every launch of one csdr_demod_batch_process call", alg, None)
+        if check and ctx.rank == 0:
+            out["parity_checked"] = self.parity_check()
         out["gather"] = self.gather()
         out["cpu_baseline"] = self.cpu_baseline() if with_cpu else None
         return out
@@ -827,7 +994,7 @@ def run_rank(args):
         if not args.no_secondary:
             with_cpu = ctx.world == 1 and not args.no_cpu       # CPU legs: rank 0 at N = 1 only
             c4 = C4Workload(torch, ca, ctx, CHANNELS)
-            s = c4.summary(ctx, 30, 15, with_cpu)
+            s = c4.summary(ctx, 30, 15, with_cpu, check=not args.no_check)
             if ctx.rank == 0:
                 extra["chain_c4"] = s
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
@@ -836,8 +1003,8 @@ def run_rank(args):
             del c4
             torch.cuda.empty_cache()
             if ctx.world == 1:
-                extra["chain_c2"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c2")
-                extra["chain_c5"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c5")
+                extra["chain_c2"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c2", check=not args.no_check)
+                extra["chain_c5"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c5", check=not args.no_check)
     else:
         w = C4Workload(torch, ca, ctx, args.channels)
         elapsed, kern_ms = timed_steps(torch, ctx, w.step, args.steps, args.warmup)
@@ -855,9 +1022,16 @@ def run_rank(args):
         traffic = None
         if args.workload == "c3":
             live = live_traffic() if (ctx.world == 1 and not args.no_secondary and not os.environ.get("CSDR_BENCH_NO_PMC")) else None
-            if live:
-                traffic = live["bytes"]
-                extra["traffic_measured"] = {k: v for k, v in live.items() if k != "bytes"}
+            if live and live.get("k1"):
+                traffic = live["k1"]["bytes"]
+                extra["traffic_measured"] = dict({k: v for k, v in live["k1"].items() if k != "bytes"}, source=live["source"])
+                # the secondary objects' rooflines get their counter traffic from the same two passes
+                for key, name in (("k2", "downconv_k2"), ("k3", "spectrum_c1"), ("k6", "blanker_k6"), ("chain", "chain_c4")):
+                    if live.get(key) and name in extra and "roofline" in extra[name]:
+                        r = extra[name]["roofline"]
+                        r["traffic"] = live[key]["bytes"]
+                        r["traffic_over_algorithmic"] = round(live[key]["bytes"] / r["algorithmic_bytes_per_launch"], 3)
+                        r["traffic_counters_KiB"] = {k: v for k, v in live[key].items() if k != "bytes"}
             else:
                 traffic = profiled_traffic()
                 extra["traffic_measured"] = {"source": "profiles/traffic_latest.json (same kernel sources: hash checked)" if traffic else None}
@@ -880,6 +1054,7 @@ def main(argv=None):
     ap.add_argument("--no-check", action="store_true", help="skip the post-timing parity spot check")
     ap.add_argument("--no-secondary", action="store_true", help="skip the distinct-filter and chain measurements")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)     # tests: CPU stand-in workload, gloo
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the counter passes of live_traffic()
     args = ap.parse_args(argv)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -888,7 +1063,9 @@ def main(argv=None):
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and int(os.environ.get("RANK", "0")) == 0:
         print("bench.py: --gpus %d but the launcher started %s ranks; using the launcher's" %
               (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
-    if args.stub:
+    if args.pmc_child:
+        run_pmc_child()
+    elif args.stub:
         run_stub(args)
     else:
         run_rank(args)

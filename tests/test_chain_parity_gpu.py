@@ -451,3 +451,42 @@ def test_mode_changes_do_not_grow_the_batch(oracle, pipelined):
     sm = b.smeter_all()
     for c in range(C):
         assert float(sm[c]) == pytest.approx(refs[c].GetSMeterAve(), abs=0.02), c
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["strict", "pipelined"])
+def test_calls_of_the_bench_length_not_a_multiple_of_the_window(oracle, pipelined):
+    """bench.py feeds the batch chain calls of 2^21 samples -- 105.03 of CDemodulator's 19968-sample windows
+    (demodulator.cpp:145-146, 169-174) -- where every other chain test feeds whole windows.  Two such calls per receiver
+    (AM, FM, USB) against the oracle's CDemodulator given the same samples: the oracle runs whole windows only and keeps
+    the rest for later, so it is at most one window behind; the common prefix is compared burst by burst under the
+    chain rule, and the product must have delivered everything the oracle did."""
+    import cutesdr_amd as ca
+    names, fs, n, calls = ["AM", "FM", "USB"], 2e6, 1 << 21, 2
+    x = np.stack([chain_input(m, calls * n, fs) * np.exp(2j * np.pi * 1100.0 * c * np.arange(calls * n) / fs)
+                  for c, m in enumerate(names)]).astype(np.complex64)
+    b = ca.DemodBatch(len(names), 2048); b.set_input_rate(fs)
+    refs = []
+    for c, name in enumerate(names):
+        m, kw = MODES[name]
+        b.set_demod(c, m, info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-100e3 - 1100.0 * c)
+        refs.append(r)
+    b.commit()
+    for c in range(len(names)):
+        b.set_freq(c, -100e3 - 1100.0 * c)
+    if pipelined:
+        b.set_pipelined(True)
+    got = [[] for _ in names]
+    want = [[] for _ in names]
+    for k in range(calls):
+        part = x[:, k * n:(k + 1) * n]
+        out = b.process(part)
+        for c in range(len(names)):
+            got[c].append(out[c]); want[c].append(refs[c].process_append(part[c].astype(np.complex128)))
+    for c, name in enumerate(names):
+        g, w = np.concatenate(got[c]), np.concatenate(want[c])
+        dec = 64 if name == "AM" else 32
+        assert len(g) == (calls * n // dec // 1024) * 1024                 # every whole hop of the input
+        assert 0 <= len(g) - len(w) <= 2 * 1024, (name, len(g), len(w))    # the oracle: whole windows only
+        assert len(w) >= 62 * 1024
+        check_chain_bursts(burst_errors(g[:len(w)], w), name if name == "FM" else "other", 0, (name, "2^21-sample calls"))
