@@ -123,7 +123,28 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+# CPU-side sanitizer builds of the library's HOST code (tools/sanitize_host.sh): the same sources and device code,
+# host halves instrumented (-fno-gpu-sanitize: GPU AddressSanitizer needs xnack+ code objects, which this pool does
+# not run), into cutesdr_amd/_san/<kind>/ -- never the library the product loads.
+SANITIZERS = {"asan": ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-gpu-sanitize"],
+              "tsan": ["-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-fno-gpu-sanitize"]}
+
+
+def build(force=False, verbose=False, sanitize=None):
+    global OBJ, LIB, FLAGS
+    if sanitize:
+        saved = (OBJ, LIB, FLAGS)
+        OBJ = os.path.join(HERE, "_san", sanitize)
+        LIB = os.path.join(OBJ, "libcutesdr_mi_%s.so" % sanitize)
+        FLAGS = [f for f in FLAGS if f != "-O3"] + SANITIZERS[sanitize]
+        try:
+            return _build(force, verbose, link_extra=SANITIZERS[sanitize][2:3])
+        finally:
+            OBJ, LIB, FLAGS = saved
+    return _build(force, verbose)
+
+
+def _build(force=False, verbose=False, link_extra=()):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
@@ -176,10 +197,11 @@ def build(force=False, verbose=False):
         procs.append(obj)
     reap(0)
     if force or procs or _newer(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + list(link_extra) + objs
         subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    kind = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--sanitize=")), None)
+    print(build(force="--force" in sys.argv, verbose=True, sanitize=kind))

@@ -17,6 +17,34 @@
 #include <mutex>
 #include <vector>
 
+#ifdef CSDR_SOUNDSINK_HOST_STUB
+// Sanitizer harness only (tools/sanitize_host.sh, tests/cpp/soundsink_threads.cpp): the queue, the rate loop and the
+// two-thread protocol of this file run under ThreadSanitizer / AddressSanitizer on a box WITHOUT a GPU, with the
+// device resampler replaced by a nearest-sample stand-in.  Never defined in the library the product loads.
+namespace {
+struct stub_resampler { double t = 0.0; };
+template <int W> int stub_resample(stub_resampler *r, int n, double rate, const double *in, short *out, double gain)
+{
+    int k = 0;
+    while ((int)r->t < n) {
+        for (int w = 0; w < W; w++) {
+            double v = in[W * (int)r->t + w] * gain;
+            out[W * k + w] = (short)(v > 32767.0 ? 32767.0 : (v < -32767.0 ? -32767.0 : v));
+        }
+        k++; r->t += rate;
+    }
+    r->t -= (double)n;
+    return k;
+}
+}
+#define csdr_resampler stub_resampler
+#define csdr_resampler_create(dev) (new stub_resampler())
+#define csdr_resampler_init(r, n) 0
+#define csdr_resampler_destroy(r) delete (r)
+#define csdr_resampler_resample_cpx_i16(r, n, rate, in, out, gain) stub_resample<2>(r, n, rate, in, out, gain)
+#define csdr_resampler_resample_real_i16(r, n, rate, in, out, gain) stub_resample<1>(r, n, rate, in, out, gain)
+#endif
+
 namespace {
 constexpr int kQ = 16384;                 // OUTQSIZE (soundout.h:18)
 constexpr int kRate = 48000;              // SOUNDCARD_RATE (soundout.cpp:48)
