@@ -1,0 +1,228 @@
+// capi_shard.hip -- C ABI of the multi-GPU form of the batched receive chain: ONE host object that owns
+// N shards of a csdr_demod_batch, each on its own device.  Receivers are independent (no cross-channel term anywhere in
+// dsp/), so shard s owns the contiguous channel range [s C / N, (s+1) C / N) with all its state resident on its device
+// and the data path has no collective: a process call is N asynchronous batch calls on N streams.  What does cross
+// devices is what SURVEY 8e names: the S-meters gathered to the host (csdr_demod_shard_get_smeter_all) and, for
+// receivers cut from one radio's stream (interface/sdrinterface.cpp:903 hands every CDemodulator the same buffer),
+// the broadcast of that wide-band block from the device it arrived on to every other shard's device
+// (csdr_demod_shard_process_shared: hipMemcpyPeerAsync over xGMI, one copy per device, each on its shard's stream).
+// Several shards may name the same device ordinal (tests: two shards on device 0 equal one batch of twice the width).
+// bench.py --gpus N keeps its one-process-per-GPU form (torch.distributed over RCCL): this object is for a host that
+// drives a whole node from one process, like the reference's single CSdrInterface.
+#include "capi_common.hpp"
+#include <vector>
+
+using namespace csdr;
+
+struct csdr_demod_shard {
+    int channels = 0, fft_n = 2048;
+    std::vector<int> device, first, count;               // per shard: device ordinal, channel range
+    std::vector<csdr_demod_batch *> b;
+    std::vector<hipStream_t> stream;                     // the shard's own stream (calls given no stream use it)
+    std::vector<float *> d_block; std::vector<size_t> block_cap;    // shared-stream mode: the wide-band block on each device
+    std::vector<float *> d_sm;                           // 2 x count floats per shard: S-meter averages, peaks
+    std::vector<int> input_row; int nrows = 0;           // shared-stream mode: receiver -> row of the block
+    bool committed = false;
+    ~csdr_demod_shard()
+    {
+        for (size_t s = 0; s < b.size(); s++) {
+            (void)hipSetDevice(device[s]);
+            if (stream[s]) { (void)hipStreamSynchronize(stream[s]); }
+            if (b[s]) csdr_demod_batch_destroy(b[s]);
+            if (d_block[s]) (void)hipFree(d_block[s]);
+            if (d_sm[s]) (void)hipFree(d_sm[s]);
+            if (stream[s]) (void)hipStreamDestroy(stream[s]);
+        }
+    }
+    int shard_of(int channel) const
+    {
+        for (size_t s = 0; s < first.size(); s++) if (channel >= first[s] && channel < first[s] + count[s]) return (int)s;
+        return -1;
+    }
+};
+
+extern "C" {
+
+csdr_demod_shard *csdr_demod_shard_create(const int *devices, int nshards, int channels, int fastfir_n)
+{
+    if (!devices || nshards < 1 || channels < nshards) { fail(CSDR_EINVAL, "need devices, 1 <= shards <= channels"); return nullptr; }
+    csdr_demod_shard *S = new csdr_demod_shard();
+    S->channels = channels; S->fft_n = fastfir_n;
+    for (int s = 0; s < nshards; s++) {
+        const int lo = (int)((long)channels * s / nshards), hi = (int)((long)channels * (s + 1) / nshards);
+        S->device.push_back(devices[s]); S->first.push_back(lo); S->count.push_back(hi - lo);
+        S->b.push_back(nullptr); S->stream.push_back(nullptr); S->d_block.push_back(nullptr); S->block_cap.push_back(0);
+        S->d_sm.push_back(nullptr);
+    }
+    for (int s = 0; s < nshards; s++) {
+        if (!device_ok(devices[s])) { delete S; return nullptr; }
+        S->b[s] = csdr_demod_batch_create(devices[s], S->count[s], fastfir_n);
+        if (!S->b[s] || hipStreamCreateWithFlags(&S->stream[s], hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void **)&S->d_sm[s], sizeof(float) * 2 * S->count[s]) != hipSuccess) {
+            if (S->b[s]) fail(CSDR_EHIP, "stream / buffer creation failed on device %d", devices[s]);
+            delete S;
+            return nullptr;
+        }
+    }
+    return S;
+}
+void csdr_demod_shard_destroy(csdr_demod_shard *S) { delete S; }
+
+int csdr_demod_shard_count(csdr_demod_shard *S) { return S ? (int)S->b.size() : fail(CSDR_EINVAL, "bad handle"); }
+int csdr_demod_shard_range(csdr_demod_shard *S, int shard, int *first, int *count, int *device)
+{
+    if (!S || shard < 0 || shard >= (int)S->b.size()) return fail(CSDR_EINVAL, "bad argument");
+    if (first) *first = S->first[shard];
+    if (count) *count = S->count[shard];
+    if (device) *device = S->device[shard];
+    return CSDR_OK;
+}
+int csdr_demod_shard_set_input_rate(csdr_demod_shard *S, double rate)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    for (auto *b : S->b) { const int rc = csdr_demod_batch_set_input_rate(b, rate); if (rc) return rc; }
+    return CSDR_OK;
+}
+#define SHARD_OF(S, channel, s)                                                                   \
+    if (!(S) || (channel) < 0 || (channel) >= (S)->channels) return fail(CSDR_EINVAL, "bad handle / channel"); \
+    const int s = (S)->shard_of(channel)
+/* CDemodulator::SetDemod of receiver `channel` (global id), routed to the shard that owns it */
+int csdr_demod_shard_set_demod(csdr_demod_shard *S, int channel, int mode, const csdr_demod_info *info)
+{
+    SHARD_OF(S, channel, s);
+    return csdr_demod_batch_set_demod(S->b[s], channel - S->first[s], mode, info);
+}
+int csdr_demod_shard_set_freq(csdr_demod_shard *S, int channel, double freq)
+{
+    SHARD_OF(S, channel, s);
+    return csdr_demod_batch_set_freq(S->b[s], channel - S->first[s], freq);
+}
+double csdr_demod_shard_get_output_rate(csdr_demod_shard *S, int channel)
+{
+    if (!S || channel < 0 || channel >= S->channels) return 0.0;
+    const int s = S->shard_of(channel);
+    return csdr_demod_batch_get_output_rate(S->b[s], channel - S->first[s]);
+}
+int csdr_demod_shard_out_count(csdr_demod_shard *S, int channel)
+{
+    SHARD_OF(S, channel, s);
+    return csdr_demod_batch_out_count(S->b[s], channel - S->first[s]);
+}
+int csdr_demod_shard_commit(csdr_demod_shard *S)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    for (auto *b : S->b) { const int rc = csdr_demod_batch_commit(b); if (rc) return rc; }
+    S->committed = true;
+    return CSDR_OK;
+}
+int csdr_demod_shard_set_pipelined(csdr_demod_shard *S, int on)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    for (auto *b : S->b) { const int rc = csdr_demod_batch_set_pipelined(b, on); if (rc) return rc; }
+    return CSDR_OK;
+}
+/* One pass of every shard: d_in[s] = shard s's rows [count_s][in_stride] complex fp32 resident on ITS device,
+ * d_out[s] = [count_s][out_stride] fp32 audio there.  streams: one per shard, or NULL for the object's own.
+ * Asynchronous: N batch calls on N devices, no collective. */
+int csdr_demod_shard_process(csdr_demod_shard *S, const float *const *d_in, long long in_stride, int n_per_channel,
+                             float *const *d_out, long long out_stride, void *const *streams)
+{
+    if (!S || !d_in || !d_out) return fail(CSDR_EINVAL, "bad argument");
+    int err = 0;
+    for (size_t s = 0; s < S->b.size(); s++) {
+        const int rc = csdr_demod_batch_process(S->b[s], d_in[s], in_stride, n_per_channel, d_out[s], out_stride,
+                                                streams ? streams[s] : (void *)S->stream[s]);
+        if (rc < 0 && !err) err = rc;
+    }
+    return err;
+}
+/* Shared-stream mode (one radio, many receivers): receiver c reads row input_row[c] of a block of `nrows` wide-band
+ * streams; every shard gets the map of its own receivers.  nrows must not exceed the smallest shard's receiver count
+ * (the batch object bounds its row indices by its width).  NULL: receiver c reads row c - first_s of its shard's input. */
+int csdr_demod_shard_set_input_rows(csdr_demod_shard *S, const int *input_row, int nrows)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    if (!input_row) {
+        for (auto *b : S->b) { const int rc = csdr_demod_batch_set_input_rows(b, nullptr); if (rc) return rc; }
+        S->input_row.clear(); S->nrows = 0;
+        return CSDR_OK;
+    }
+    for (size_t s = 0; s < S->b.size(); s++) if (nrows < 1 || nrows > S->count[s]) return fail(CSDR_EINVAL, "1 <= nrows <= receivers per shard");
+    for (int c = 0; c < S->channels; c++) if (input_row[c] < 0 || input_row[c] >= nrows) return fail(CSDR_EINVAL, "input row %d of receiver %d", input_row[c], c);
+    for (size_t s = 0; s < S->b.size(); s++) {
+        const int rc = csdr_demod_batch_set_input_rows(S->b[s], input_row + S->first[s]);
+        if (rc) return rc;
+    }
+    S->input_row.assign(input_row, input_row + S->channels); S->nrows = nrows;
+    return CSDR_OK;
+}
+/* One pass in shared-stream mode: d_block [nrows][in_stride] complex fp32 resident on device `src_device`, handed over
+ * ONCE; the object copies it to every other shard's device (hipMemcpyPeerAsync on that shard's stream, behind
+ * `src_stream`'s work so far) and runs every shard on its copy.  The one broadcast SURVEY 8e names. */
+int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, int src_device, void *src_stream,
+                                    long long in_stride, int n_per_channel, float *const *d_out, long long out_stride)
+{
+    if (!S || !d_block || !d_out || S->nrows < 1) return fail(CSDR_EINVAL, "bad argument (set the input rows first)");
+    if (in_stride < n_per_channel) return fail(CSDR_EINVAL, "input stride < n");
+    const size_t bytes = (size_t)S->nrows * (size_t)in_stride * 8;
+    if (!device_ok(src_device)) return CSDR_EHIP;
+    hipEvent_t ready = nullptr;
+    CSDR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    CSDR_HIP(hipEventRecord(ready, (hipStream_t)src_stream));
+    int err = 0;
+    for (size_t s = 0; s < S->b.size(); s++) {
+        if (!device_ok(S->device[s])) { err = CSDR_EHIP; break; }
+        const float *in = d_block;
+        hipError_t e = hipStreamWaitEvent(S->stream[s], ready, 0);
+        if (e == hipSuccess && S->device[s] != src_device) {
+            if (bytes > S->block_cap[s]) {
+                (void)hipStreamSynchronize(S->stream[s]);
+                if (S->d_block[s]) (void)hipFree(S->d_block[s]);
+                S->d_block[s] = nullptr; S->block_cap[s] = 0;
+                e = hipMalloc((void **)&S->d_block[s], bytes);
+                if (e == hipSuccess) S->block_cap[s] = bytes;
+            }
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(S->d_block[s], S->device[s], d_block, src_device, bytes, S->stream[s]);
+            in = S->d_block[s];
+        }
+        if (e != hipSuccess) { err = fail(CSDR_EHIP, "broadcast to device %d: %s", S->device[s], hipGetErrorString(e)); break; }
+        const int rc = csdr_demod_batch_process(S->b[s], in, in_stride, n_per_channel, d_out[s], out_stride, (void *)S->stream[s]);
+        if (rc < 0 && !err) err = rc;
+    }
+    (void)hipSetDevice(src_device);
+    (void)hipEventDestroy(ready);
+    return err;
+}
+/* waits for everything issued on the shards' own streams */
+int csdr_demod_shard_sync(csdr_demod_shard *S)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    for (size_t s = 0; s < S->b.size(); s++) {
+        if (!device_ok(S->device[s])) return CSDR_EHIP;
+        const int rc = csdr_demod_batch_flush(S->b[s], (void *)S->stream[s]);
+        if (rc) return rc;
+        CSDR_HIP(hipStreamSynchronize(S->stream[s]));
+    }
+    return CSDR_OK;
+}
+/* CSMeter::GetAve / GetPeak of EVERY receiver gathered to host arrays indexed by global channel (either may be NULL;
+ * reading the peaks resets them, smeter.cpp:98-103): one collect launch and one small copy per shard.  Synchronous. */
+int csdr_demod_shard_get_smeter_all(csdr_demod_shard *S, float *h_ave, float *h_peak)
+{
+    if (!S || (!h_ave && !h_peak)) return fail(CSDR_EINVAL, "bad argument");
+    for (size_t s = 0; s < S->b.size(); s++) {
+        if (!device_ok(S->device[s])) return CSDR_EHIP;
+        float *da = S->d_sm[s], *dp = S->d_sm[s] + S->count[s];
+        const int rc = csdr_demod_batch_get_smeter_all(S->b[s], h_ave ? da : nullptr, h_peak ? dp : nullptr, (void *)S->stream[s]);
+        if (rc) return rc;
+        if (h_ave) CSDR_HIP(hipMemcpyAsync(h_ave + S->first[s], da, sizeof(float) * S->count[s], hipMemcpyDeviceToHost, S->stream[s]));
+        if (h_peak) CSDR_HIP(hipMemcpyAsync(h_peak + S->first[s], dp, sizeof(float) * S->count[s], hipMemcpyDeviceToHost, S->stream[s]));
+    }
+    for (size_t s = 0; s < S->b.size(); s++) {
+        if (!device_ok(S->device[s])) return CSDR_EHIP;
+        CSDR_HIP(hipStreamSynchronize(S->stream[s]));
+    }
+    return CSDR_OK;
+}
+
+}  // extern "C"

@@ -661,6 +661,101 @@ class DemodBatch(_Obj):
         return [y[c, :self.out_count(c)].copy() for c in range(self.channels)]
 
 
+class ShardedDemodBatch(_Obj):
+    """csdr_demod_shard: one host object, N shards of the batched chain on N devices (several shards may share one);
+    global channel ids, contiguous ranges, no collective on the data path."""
+    _destroy = "csdr_demod_shard_destroy"
+
+    def __init__(self, devices, channels, fastfir_n=2048):
+        self.devices, self.channels, self.n = list(devices), channels, fastfir_n
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self.h = check_ptr(lib().csdr_demod_shard_create(arr, len(self.devices), channels, fastfir_n), "csdr_demod_shard_create")
+        self.ranges = []
+        for k in range(len(self.devices)):
+            f, c, d = C.c_int(), C.c_int(), C.c_int()
+            check(lib().csdr_demod_shard_range(self.h, k, C.byref(f), C.byref(c), C.byref(d)))
+            self.ranges.append((f.value, c.value, d.value))
+
+    def set_input_rate(self, rate):
+        check(lib().csdr_demod_shard_set_input_rate(self.h, rate))
+
+    def set_demod(self, channel, mode, info):
+        check(lib().csdr_demod_shard_set_demod(self.h, channel, mode, C.byref(info)), "shard_set_demod")
+
+    def commit(self):
+        check(lib().csdr_demod_shard_commit(self.h), "shard_commit")
+
+    def set_freq(self, channel, freq):
+        check(lib().csdr_demod_shard_set_freq(self.h, channel, freq))
+
+    def output_rate(self, channel):
+        return lib().csdr_demod_shard_get_output_rate(self.h, channel)
+
+    def set_pipelined(self, on=True):
+        check(lib().csdr_demod_shard_set_pipelined(self.h, int(on)), "shard_set_pipelined")
+
+    def out_count(self, channel):
+        return check(lib().csdr_demod_shard_out_count(self.h, channel))
+
+    def sync(self):
+        check(lib().csdr_demod_shard_sync(self.h), "shard_sync")
+
+    def smeter_all(self, peak=False):
+        ave = np.zeros(self.channels, dtype=np.float32)
+        pk = np.zeros(self.channels, dtype=np.float32)
+        check(lib().csdr_demod_shard_get_smeter_all(self.h, _vp(ave), _vp(pk) if peak else None), "shard_get_smeter_all")
+        return (ave, pk) if peak else ave
+
+    def set_input_rows(self, rows, nrows):
+        if rows is None:
+            check(lib().csdr_demod_shard_set_input_rows(self.h, None, 0)); return
+        a = np.ascontiguousarray(rows, dtype=np.int32)
+        assert a.shape == (self.channels,)
+        check(lib().csdr_demod_shard_set_input_rows(self.h, _vp(a), int(nrows)), "shard_set_input_rows")
+
+    def _outs(self, cap):
+        return [DeviceBuffer(4 * c * cap, d) for (_, c, d) in self.ranges]
+
+    def _collect(self, outs, cap):
+        res = []
+        for (f, c, d), o in zip(self.ranges, outs):
+            y = o.download(np.float32, c * cap).reshape(c, cap)
+            res += [y[i, :self.out_count(f + i)].copy() for i in range(c)]
+            o.free()
+        return res
+
+    def process(self, x):
+        """x complex [channels, T] (host): every shard's rows go to its device; -> list of audio rows by global channel"""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        T = x.shape[1]
+        cap = T + self.n
+        ins = []
+        for (f, c, d) in self.ranges:
+            b = DeviceBuffer(8 * c * T, d); b.upload(np.ascontiguousarray(x[f:f + c])); ins.append(b)
+        outs = self._outs(cap)
+        pin = (C.c_void_p * len(ins))(*[b.ptr for b in ins]); pout = (C.c_void_p * len(outs))(*[b.ptr for b in outs])
+        check(lib().csdr_demod_shard_process(self.h, pin, T, T, pout, cap, None), "csdr_demod_shard_process")
+        self.sync()
+        for b in ins:
+            b.free()
+        return self._collect(outs, cap)
+
+    def process_shared(self, block, src_device=0):
+        """block complex [nrows, T] (host) -> uploaded once to src_device, broadcast by the object"""
+        block = np.ascontiguousarray(block, dtype=np.complex64)
+        T = block.shape[1]
+        cap = T + self.n
+        b = DeviceBuffer(block.nbytes, src_device); b.upload(block)
+        sync(src_device)
+        outs = self._outs(cap)
+        pout = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
+        check(lib().csdr_demod_shard_process_shared(self.h, C.c_void_p(b.ptr), src_device, None, T, T, pout, cap),
+              "csdr_demod_shard_process_shared")
+        self.sync()
+        b.free()
+        return self._collect(outs, cap)
+
+
 class CFft(_Obj):
     """dsp/fft.h:24-85 -- display spectrum + plain transforms, 512..65536 points."""
     _destroy = "csdr_fft_destroy"

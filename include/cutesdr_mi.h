@@ -298,6 +298,41 @@ int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
  * chain of the same decimation stays in its row; one to another decimation moves the receiver into a muted row of a
  * matching group when there is one, else into a group of its own; a group whose rows are all muted is dropped. */
 int csdr_demod_batch_group_count(csdr_demod_batch *b, int *rows);
+/* ---- the same chain over SEVERAL devices from one host object -------------------------------------------
+ * Receivers are independent: shard s owns the contiguous channel range [s C / N, (s+1) C / N) on device devices[s], with
+ * all its state resident there; a process call is N asynchronous batch calls, no collective on the data path.  Global
+ * channel ids everywhere; set_demod / set_freq are routed to the owning shard.  What crosses devices is what the
+ * survey names: the S-meters gathered to the host, and -- for receivers cut from ONE radio's stream, as
+ * CSdrInterface hands every CDemodulator the same buffer (interface/sdrinterface.cpp:903) -- the broadcast of that
+ * block to every other shard's device (hipMemcpyPeerAsync over xGMI, one copy per device on the shard's stream).
+ * Several shards may name the same device.  A host with one PROCESS per GPU (bench.py --gpus N, torch.distributed /
+ * RCCL) uses csdr_demod_batch per rank instead. */
+typedef struct csdr_demod_shard csdr_demod_shard;
+csdr_demod_shard *csdr_demod_shard_create(const int *devices, int nshards, int channels, int fastfir_n);
+void csdr_demod_shard_destroy(csdr_demod_shard *s);
+int csdr_demod_shard_count(csdr_demod_shard *s);
+int csdr_demod_shard_range(csdr_demod_shard *s, int shard, int *first, int *count, int *device);
+int csdr_demod_shard_set_input_rate(csdr_demod_shard *s, double rate);
+int csdr_demod_shard_set_demod(csdr_demod_shard *s, int channel, int mode, const csdr_demod_info *info);
+int csdr_demod_shard_commit(csdr_demod_shard *s);
+int csdr_demod_shard_set_freq(csdr_demod_shard *s, int channel, double freq);
+double csdr_demod_shard_get_output_rate(csdr_demod_shard *s, int channel);
+int csdr_demod_shard_set_pipelined(csdr_demod_shard *s, int on);
+/* d_in[k] / d_out[k]: shard k's rows [count_k][stride] on ITS device; streams[k] or NULL (the object's own streams) */
+int csdr_demod_shard_process(csdr_demod_shard *s, const float *const *d_in, long long in_stride, int n_per_channel,
+                             float *const *d_out, long long out_stride, void *const *streams);
+int csdr_demod_shard_out_count(csdr_demod_shard *s, int channel);
+/* shared-stream mode: receiver c reads row input_row[c] (< nrows <= receivers per shard) of a wide-band block that
+ * process_shared takes ONCE, resident on src_device behind src_stream's work, and copies to the other devices */
+int csdr_demod_shard_set_input_rows(csdr_demod_shard *s, const int *input_row, int nrows);
+int csdr_demod_shard_process_shared(csdr_demod_shard *s, const float *d_block, int src_device, void *src_stream,
+                                    long long in_stride, int n_per_channel, float *const *d_out, long long out_stride);
+/* waits for everything issued on the shards' own streams (pipelined mode: flushes first) */
+int csdr_demod_shard_sync(csdr_demod_shard *s);
+/* CSMeter::GetAve / GetPeak of every receiver into HOST arrays indexed by global channel (either may be NULL; reading
+ * the peaks resets them): the gather of SURVEY 8e.  Synchronous. */
+int csdr_demod_shard_get_smeter_all(csdr_demod_shard *s, float *h_ave, float *h_peak);
+
 /* The same pass fed with the datagrams as they arrived (interface/netiobase.cpp:479-527):
  * d_packets [channels][npackets][pkt_len] bytes on the device, 4-byte aligned, pkt_len 1028 (16 bit) or 1444
  * (24 bit).  No unpack pass: the first kernel at input rate decodes the datagrams in its own loads -- the

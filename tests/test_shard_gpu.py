@@ -1,0 +1,105 @@
+"""csdr_demod_shard: the batched receive chain over several devices behind ONE host object (contiguous
+channel ranges, no collective on the data path; S-meter gather; broadcast of a shared wide-band block).  On the
+one-GPU box two shards share device 0 and must give, word for word, what one batch of twice the width gives; with more
+devices visible the same test also runs one shard per device."""
+import numpy as np
+import pytest
+
+from test_postchain_gpu import MODES, info, make_input, burst_errors, check_chain_bursts
+
+pytestmark = pytest.mark.gpu
+
+
+def _configure(obj, ca, names, fs):
+    obj.set_input_rate(fs)
+    for c, name in enumerate(names):
+        m, kw = MODES[name]
+        obj.set_demod(c, m, info(ca, **kw))
+    obj.commit()
+    for c in range(len(names)):
+        obj.set_freq(c, -100e3 - 800.0 * c)
+
+
+def _device_sets():
+    import cutesdr_amd as ca
+    n = ca._capi.lib().csdr_device_count()
+    sets = [[0, 0], [0, 0, 0]]
+    if n > 1:
+        sets.append(list(range(min(n, 4))))
+    return sets
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["strict", "pipelined"])
+def test_shards_equal_one_wide_batch(oracle, pipelined):
+    import cutesdr_amd as ca
+    fs, lim = 2e6, 19968
+    names = ["FM", "AM", "USB", "SAM", "FM", "USB", "AM", "FM", "CWU", "AM", "USB", "FM"]
+    C, n, calls = len(names), lim * 8, 3
+    x = np.stack([make_input(m if m != "CWU" else "USB", calls * n, fs) * np.exp(2j * np.pi * 800.0 * c * np.arange(calls * n) / fs)
+                  for c, m in enumerate(names)]).astype(np.complex64)
+    wide = ca.DemodBatch(C, 2048)
+    _configure(wide, ca, names, fs)
+    if pipelined:
+        wide.set_pipelined(True)
+    want = [wide.process(x[:, k * n:(k + 1) * n]) for k in range(calls)]
+    want_sm = wide.smeter_all()
+    for devices in _device_sets():
+        sh = ca.ShardedDemodBatch(devices, C, 2048)
+        assert [r[:2] for r in sh.ranges] == [(C * k // len(devices), C * (k + 1) // len(devices) - C * k // len(devices)) for k in range(len(devices))]
+        _configure(sh, ca, names, fs)
+        if pipelined:
+            sh.set_pipelined(True)
+        for k in range(calls):
+            got = sh.process(x[:, k * n:(k + 1) * n])
+            for c in range(C):
+                assert sh.output_rate(c) == wide.output_rate(c)
+                assert len(got[c]) == len(want[k][c]), (devices, c, k)
+                assert np.array_equal(got[c], want[k][c]), (devices, c, k, np.abs(got[c] - want[k][c]).max())
+        np.testing.assert_array_equal(sh.smeter_all(), want_sm)
+        # a mode change routed to the owning shard (global channel id): FM -> AM on the last receiver
+        m, kw = MODES["AM"]
+        sh.set_demod(C - 1, m, info(ca, **kw))
+        assert sh.output_rate(C - 1) == 31250.0
+        del sh
+    # and the wide batch is the oracle's chain (so are the shards)
+    r = oracle.CDemodulator(2048); m, kw = MODES[names[4]]
+    r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-100e3 - 800.0 * 4)
+    ref = np.concatenate([r.process_append(x[4, k * n:(k + 1) * n].astype(np.complex128)) for k in range(calls)])
+    g = np.concatenate([want[k][4] for k in range(calls)])
+    check_chain_bursts(burst_errors(g, ref), "FM", 0, "receiver 4 of the wide batch")
+
+
+def test_shared_block_is_broadcast_to_every_shard(oracle):
+    """one radio, many receivers: a block of two wide-band streams handed over once on device 0, every receiver of
+    every shard cut from its row (interface/sdrinterface.cpp:903), each equal to an oracle CDemodulator fed that row"""
+    import cutesdr_amd as ca
+    fs, lim = 2e6, 19968
+    names = ["FM", "AM", "USB", "FM", "AM", "USB", "FM", "AM"]
+    C, S, n = len(names), 2, lim * 8
+    t = np.arange(n)
+    station = lambda c: 100e3 + 40e3 * (c // S)
+    block = np.zeros((S, n), dtype=np.complex128)
+    for c, m in enumerate(names):
+        block[c % S] += 0.3 * make_input(m, n, fs) * np.exp(2j * np.pi * (station(c) - 100e3) * t / fs)
+    block = block.astype(np.complex64)
+    rows = np.array([c % S for c in range(C)], dtype=np.int32)
+    for devices in _device_sets():
+        if C // len(devices) < S:
+            continue
+        sh = ca.ShardedDemodBatch(devices, C, 2048)
+        sh.set_input_rate(fs)
+        for c, name in enumerate(names):
+            m, kw = MODES[name]
+            sh.set_demod(c, m, info(ca, **kw))
+        sh.commit()
+        for c in range(C):
+            sh.set_freq(c, -station(c))
+        sh.set_input_rows(rows, S)
+        got = sh.process_shared(block, src_device=devices[-1])
+        for c, name in enumerate(names):
+            r = oracle.CDemodulator(2048); m, kw = MODES[name]
+            r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-station(c))
+            want = r.process_append(block[c % S].astype(np.complex128))
+            assert len(got[c]) == len(want)
+            check_chain_bursts(burst_errors(got[c], want), name if name == "FM" else "other", 0, (devices, c, name))
+        del sh
