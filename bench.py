@@ -638,6 +638,53 @@ def chain_one_receiver(torch, ca, ctx, with_cpu, name, check=True):
     return out
 
 
+def host_form(ca, with_cpu, check=True):
+    """The path the reference's Qt host takes through the drop-in CDemodulator: complex DOUBLES in host memory, handed
+    over in calls of 256 samples (one datagram each, interface/sdrinterface.cpp:903), audio back in host memory --
+    2 MSPS, FM defaults, 2048-point filter.  PCIe, the fp64 <-> fp32 conversions and every launch are inside; one
+    receiver is latency-bound by construction.  Never `value`.  The oracle's CDemodulator on the same samples, one host
+    core, is timed beside it, and the audio of the timed samples is compared with it under the chain rule."""
+    import ctypes as C
+    import numpy as np
+    from cutesdr_amd import _capi
+    fs, fc, n, call = 2e6, 100e3, 1 << 22, 256
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(5)
+    x = 3276.7 * np.exp(1j * (2 * np.pi * fc * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t))) + 10.0 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    d = ca.CDemodulator(2048)
+    d.SetInputSampleRate(fs); d.SetDemod(ca.DEMOD_FM, fm_defaults(ca)); d.SetDemodFreq(-fc)
+    L = _capi.lib()
+    L.csdr__demod_process_calls.restype = C.c_int
+    L.csdr__demod_process_calls.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    out = np.zeros(n // 16 + 65536)
+    run = lambda: _capi.check(L.csdr__demod_process_calls(d.h, n, call, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "host form")
+    k_first = run()                                       # also the warm-up: staging buffers sized, clocks up
+    first = out[:k_first].copy()
+    reps, t0 = 3, time.perf_counter()
+    for _ in range(reps):
+        run()
+    dt = (time.perf_counter() - t0) / reps
+    res = {"config": "drop-in CDemodulator, host doubles in / out: 2 MSPS FM, %d-sample calls (the reference's call pattern), 2^22 samples per measurement" % call,
+           "raw_input_MSamples_per_s": round(n / dt / 1e6, 1), "x_real_time": round(n / dt / fs, 1),
+           "staging": "pinned windows used in turn, async H2D + chain on the object's stream, one wait per pass that returns audio",
+           "cpu_baseline": None}
+    if with_cpu or check:
+        from oracle import oracle as orc
+        r = orc.CDemodulator(2048)
+        r.SetInputSampleRate(fs); r.SetDemod(orc.DEMOD_FM, fm_defaults(orc)); r.SetDemodFreq(-fc)
+        t0 = time.perf_counter()
+        want = r.process_append(x)
+        t_first = time.perf_counter() - t0
+        if check:
+            res["parity_checked"] = dict(chain_burst_check(first, want, "FM"), samples=int(n), counts_equal=bool(k_first == len(want)))
+        if with_cpu:
+            v, m = cpu_rate(lambda: r.process_append(x), n, 2.0)
+            res["cpu_baseline"] = cpu_obj(v, m, "CDemodulator::ProcessData on the same stream")
+    del d
+    return res
+
+
 # ---------------------------------------------------------------- timing helpers
 def timed_steps(torch, ctx, step, steps, warmup, prewarm=True):
     """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both sides; returns
@@ -1003,6 +1050,7 @@ def run_rank(args):
             del c4
             torch.cuda.empty_cache()
             if ctx.world == 1:
+                extra["host_form"] = host_form(ca, with_cpu, check=not args.no_check)
                 extra["chain_c2"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c2", check=not args.no_check)
                 extra["chain_c5"] = chain_one_receiver(torch, ca, ctx, with_cpu, "c5", check=not args.no_check)
     else:

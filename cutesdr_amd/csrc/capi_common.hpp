@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include "../../include/cutesdr_mi.h"
 
@@ -48,5 +49,31 @@ inline bool device_ok(int device)
     }
     return hipSetDevice(device) == hipSuccess;
 }
+
+// Host staging of the drop-in classes' double* buffers ("host double* -> pinned staging -> HBM fp32"): a
+// page-locked fp32 buffer the DMA engines read and write directly (a pageable source goes through the runtime's own
+// bounce buffer first), grown on demand with its contents kept, and the two conversions at the boundary as plain
+// loops the host compiler vectorises (cvtpd2ps / cvtps2pd).
+struct PinnedBuf {
+    float *p = nullptr;
+    size_t cap = 0;                                      // floats
+    int reserve(size_t n)
+    {
+        if (n <= cap) return CSDR_OK;
+        float *q = nullptr;
+        n = (n + 4095) / 4096 * 4096;
+        if (hipHostMalloc((void **)&q, n * sizeof(float), hipHostMallocDefault) != hipSuccess)
+            return fail(CSDR_ENOMEM, "hipHostMalloc(%zu) failed", n * sizeof(float));
+        if (p) { memcpy(q, p, cap * sizeof(float)); (void)hipHostFree(p); }
+        p = q; cap = n;
+        return CSDR_OK;
+    }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+};
+inline void cvt_to_f32(float *__restrict dst, const double *__restrict src, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = (float)src[i]; }
+inline void cvt_to_f64(double *__restrict dst, const float *__restrict src, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = (double)src[i]; }
 
 }  // namespace csdr

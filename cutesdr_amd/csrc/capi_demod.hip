@@ -374,13 +374,22 @@ struct csdr_demod {
     ChanCfg c;
     double in_rate = 0.0;
     int limit = 1000;                   // m_InBufLimit (demodulator.cpp:54)
-    std::vector<float> inbuf;           // m_pDemodInBuf as fp32 pairs
+    // m_pDemodInBuf as fp32 pairs in PINNED memory, two windows used in turn: while window w is on its way to the
+    // device and through the chain (asynchronous, on the object's stream), the caller's next samples are converted
+    // into window w^1.  The host waits for the GPU only when a pass is due to RETURN samples (a whole hop of audio),
+    // as the reference's call pattern demands; passes that only fill the filter return at once.
+    PinnedBuf win[2], pin_out;
+    int cur = 0;
+    bool win_busy[2] = {false, false};
+    hipEvent_t ev_win[2] = {nullptr, nullptr};   // window w's copy to the device has left the pinned buffer
+    hipStream_t s = nullptr;
     int pos = 0;
     float *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
-    std::vector<float> st;
     ~csdr_demod()
     {
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        for (hipEvent_t e : ev_win) if (e) (void)hipEventDestroy(e);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
     }
@@ -596,7 +605,9 @@ csdr_demod *csdr_demod_create(int device, int fastfir_n)
     if (!device_ok(device)) return nullptr;
     csdr_demod *d = new csdr_demod();
     if (d->k.init(device, 1, fastfir_n) != CSDR_OK) { delete d; return nullptr; }
-    d->inbuf.resize(2 * 250000);                      // MAX_INBUFSIZE (demodulator.h:30)
+    bool ok = hipStreamCreateWithFlags(&d->s, hipStreamNonBlocking) == hipSuccess;
+    for (auto &e : d->ev_win) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { fail(CSDR_EHIP, "stream / event creation failed"); delete d; return nullptr; }
     csdr_downconvert_batch_set_cw_offset(d->k.dc, 0, 0.0);      // ctor: SetDemodFreq(0.0)
     csdr_downconvert_batch_set_frequency(d->k.dc, 0, 0.0);
     return d;
@@ -607,6 +618,7 @@ void csdr_demod_destroy(csdr_demod *d) { delete d; }
 int csdr_demod_set_input_rate(csdr_demod *d, double rate)
 {
     if (!d) return fail(CSDR_EINVAL, "bad handle");
+    if (d->s) CSDR_HIP(hipStreamSynchronize(d->s));   // control plane: a pass that returned no samples may still be in flight
     if (d->in_rate != rate) {
         d->in_rate = rate;
         const double r = csdr_downconvert_batch_set_data_rate(d->k.dc, 0, rate, d->c.want_bw);
@@ -620,6 +632,7 @@ int csdr_demod_set_demod(csdr_demod *d, int mode, const csdr_demod_info *info)
 {
     if (!d || !info || mode < 0 || mode > 6) return fail(CSDR_EINVAL, "bad argument");
     if (!device_ok(d->k.device)) return CSDR_EHIP;
+    if (d->s) CSDR_HIP(hipStreamSynchronize(d->s));   // control plane: a pass that returned no samples may still be in flight
     DemodInfo di;
     memcpy(&di, info, sizeof(di));
     int rc = apply_set_demod(d->k, 0, d->c, d->in_rate, mode, di);
@@ -649,37 +662,51 @@ static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out,
     if (d->limit <= 0 || d->limit > 250000) return fail(CSDR_ESTATE, "input buffer limit %d out of range", d->limit);
     if (!device_ok(d->k.device)) return CSDR_EHIP;
     int ret = 0;
-    for (int i = 0; i < n; i++) {
-        d->inbuf[2 * d->pos] = (float)in_iq[2 * i];
-        d->inbuf[2 * d->pos + 1] = (float)in_iq[2 * i + 1];
-        if (++d->pos >= d->limit) {
-            const int len = d->pos;
-            d->pos = 0;
-            if ((size_t)len > d->cap_in) {
-                if (d->d_in) (void)hipFree(d->d_in);
-                d->d_in = nullptr; d->cap_in = 0;
-                CSDR_HIP(hipMalloc((void **)&d->d_in, (size_t)len * 8));
-                d->cap_in = len;
-            }
-            const size_t need_out = (size_t)len + d->k.L;
-            if (need_out > d->cap_out) {
-                if (d->d_out) (void)hipFree(d->d_out);
-                d->d_out = nullptr; d->cap_out = 0;
-                CSDR_HIP(hipMalloc((void **)&d->d_out, need_out * 8));
-                d->cap_out = need_out;
-            }
-            CSDR_HIP(hipMemcpy(d->d_in, d->inbuf.data(), (size_t)len * 8, hipMemcpyHostToDevice));
-            const int k = d->k.step(d->d_in, len, nullptr, len, d->d_out, (long)d->cap_out, nullptr, stereo, nullptr);
-            if (k < 0) return k;
-            if (k > 0) {
-                const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
-                d->st.resize(nf);
-                CSDR_HIP(hipMemcpy(d->st.data(), d->d_out, nf * 4, hipMemcpyDeviceToHost));
-                double *dst = append ? out + (stereo ? 2 : 1) * (size_t)ret : out;
-                for (size_t j = 0; j < nf; j++) dst[j] = (double)d->st[j];
-            }
-            ret += k;
+    for (int i = 0; i < n; ) {
+        PinnedBuf &w = d->win[d->cur];
+        // the samples that fit before the window is full (at least one: a limit lowered by SetDemod below the fill
+        // runs the pass at the next sample, as `if (m_InBufPos >= m_InBufLimit)` does, demodulator.cpp:169-174)
+        int take = d->limit - d->pos;
+        if (take < 1) take = 1;
+        if (take > n - i) take = n - i;
+        if (d->win_busy[d->cur]) { CSDR_HIP(hipEventSynchronize(d->ev_win[d->cur])); d->win_busy[d->cur] = false; }
+        int rc = w.reserve(2 * ((size_t)d->pos + take));
+        if (rc) return rc;
+        cvt_to_f32(w.p + 2 * (size_t)d->pos, in_iq + 2 * (size_t)i, 2 * (size_t)take);
+        d->pos += take; i += take;
+        if (d->pos < d->limit) break;                     // the call's samples are in; the window is not full yet
+        const int len = d->pos;
+        d->pos = 0;
+        if ((size_t)len > d->cap_in) {
+            CSDR_HIP(hipStreamSynchronize(d->s));
+            if (d->d_in) (void)hipFree(d->d_in);
+            d->d_in = nullptr; d->cap_in = 0;
+            CSDR_HIP(hipMalloc((void **)&d->d_in, (size_t)len * 8));
+            d->cap_in = len;
         }
+        const size_t need_out = (size_t)len + d->k.L;
+        if (need_out > d->cap_out) {
+            CSDR_HIP(hipStreamSynchronize(d->s));
+            if (d->d_out) (void)hipFree(d->d_out);
+            d->d_out = nullptr; d->cap_out = 0;
+            CSDR_HIP(hipMalloc((void **)&d->d_out, need_out * 8));
+            d->cap_out = need_out;
+        }
+        // window -> device -> chain, all on the object's stream (d_in is reused in stream order)
+        CSDR_HIP(hipMemcpyAsync(d->d_in, w.p, (size_t)len * 8, hipMemcpyHostToDevice, d->s));
+        CSDR_HIP(hipEventRecord(d->ev_win[d->cur], d->s));
+        d->win_busy[d->cur] = true;
+        d->cur ^= 1;
+        const int k = d->k.step(d->d_in, len, nullptr, len, d->d_out, (long)d->cap_out, nullptr, stereo, d->s);
+        if (k < 0) return k;
+        if (k > 0) {                                      // a pass that returns samples: the one wait of this call
+            const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
+            if ((rc = d->pin_out.reserve(nf))) return rc;
+            CSDR_HIP(hipMemcpyAsync(d->pin_out.p, d->d_out, nf * 4, hipMemcpyDeviceToHost, d->s));
+            CSDR_HIP(hipStreamSynchronize(d->s));
+            cvt_to_f64(append ? out + (stereo ? 2 : 1) * (size_t)ret : out, d->pin_out.p, nf);
+        }
+        ret += k;
     }
     return ret;
 }
@@ -689,6 +716,23 @@ int csdr_demod_process_stereo(csdr_demod *d, int n, const double *in_iq, double 
 { return demod_process(d, n, in_iq, out_iq, true, false); }
 int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, double *out)
 { return demod_process(d, n, in_iq, out, false, true); }
+
+/* internal (bench.py `host_form`, tests; not in the public header): the reference's call pattern in one C loop --
+ * n_total samples handed over in calls of call_len (one datagram: 240 / 256 samples, interface/sdrinterface.cpp:903),
+ * every call's audio appended at out.  Returns the audio samples produced.  Saves the measurement the per-call cost
+ * of the Python binding, nothing else. */
+int csdr__demod_process_calls(csdr_demod *d, int n_total, int call_len, const double *in_iq, double *out)
+{
+    if (!d || call_len < 1 || n_total < 0 || (n_total && (!in_iq || !out))) return fail(CSDR_EINVAL, "bad argument");
+    int total = 0;
+    for (int i = 0; i < n_total; i += call_len) {
+        const int n = n_total - i < call_len ? n_total - i : call_len;
+        const int k = demod_process(d, n, in_iq + 2 * (size_t)i, out + total, false, true);
+        if (k < 0) return k;
+        total += k;
+    }
+    return total;
+}
 
 /* ------------------------------- batch ------------------------------- */
 csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_n)

@@ -315,8 +315,9 @@ int csdr__dbg_fastfir_stage(csdr_fastfir_batch *b, int stage, float *d_dbg)
 
 struct csdr_fastfir {
     csdr_fastfir_batch *b;
-    int n, pending;                  // pending < n/2 input samples not yet processed
-    std::vector<float> stage_in, stage_out;
+    int n, pending;                  // pending < n/2 input samples not yet processed (they sit at the front of pin_in)
+    PinnedBuf pin_in, pin_out;       // page-locked fp32 staging, both directions
+    hipStream_t s = nullptr;         // the object's stream: H2D copy, filter, D2H copy in order, ONE wait per call
     float *d_in, *d_out;
     size_t cap;                      // device staging capacity in samples
 };
@@ -341,6 +342,7 @@ csdr_fastfir *csdr_fastfir_create(int device, int fft_size)
     if (!b) return nullptr;
     csdr_fastfir *f = new csdr_fastfir();
     f->b = b; f->n = fft_size; f->pending = 0; f->d_in = f->d_out = nullptr; f->cap = 0;
+    if (hipStreamCreateWithFlags(&f->s, hipStreamNonBlocking) != hipSuccess) { csdr_fastfir_destroy(f); fail(CSDR_EHIP, "stream creation failed"); return nullptr; }
     return f;
 }
 
@@ -350,6 +352,7 @@ void csdr_fastfir_destroy(csdr_fastfir *f)
     (void)hipSetDevice(f->b->device);
     if (f->d_in) (void)hipFree(f->d_in);
     if (f->d_out) (void)hipFree(f->d_out);
+    if (f->s) { (void)hipStreamSynchronize(f->s); (void)hipStreamDestroy(f->s); }
     csdr_fastfir_batch_destroy(f->b);
     delete f;
 }
@@ -366,22 +369,23 @@ int csdr_fastfir_process(csdr_fastfir *f, int n, const double *in_iq, double *ou
     if (n == 0) return 0;
     if (!device_ok(f->b->device)) return CSDR_EHIP;
     const int L = f->n / 2;
-    // append to the pending (not yet hop-complete) samples, fp64 -> fp32 at the boundary
-    const size_t old = f->stage_in.size();
-    f->stage_in.resize(old + 2 * (size_t)n);
-    for (size_t i = 0; i < 2 * (size_t)n; i++) f->stage_in[old + i] = (float)in_iq[i];
-    const int avail = (int)(f->stage_in.size() / 2);
+    // append to the pending (not yet hop-complete) samples, fp64 -> fp32 at the boundary, straight into pinned memory
+    int rc = f->pin_in.reserve(2 * ((size_t)f->pending + n));
+    if (rc) return rc;
+    cvt_to_f32(f->pin_in.p + 2 * (size_t)f->pending, in_iq, 2 * (size_t)n);
+    const int avail = f->pending + n;
     const int nproc = (avail / L) * L;
-    if (nproc == 0) return 0;
-    int rc = ensure_cap(f, (size_t)nproc);
+    if (nproc == 0) { f->pending = avail; return 0; }
+    if ((rc = ensure_cap(f, (size_t)nproc))) return rc;
+    if ((rc = f->pin_out.reserve(2 * (size_t)nproc))) return rc;
+    CSDR_HIP(hipMemcpyAsync(f->d_in, f->pin_in.p, (size_t)nproc * 8, hipMemcpyHostToDevice, f->s));
+    rc = csdr_fastfir_batch_process(f->b, f->d_in, nproc, nproc, f->d_out, nproc, (void *)f->s, 0);
     if (rc) return rc;
-    CSDR_HIP(hipMemcpy(f->d_in, f->stage_in.data(), (size_t)nproc * 8, hipMemcpyHostToDevice));
-    rc = csdr_fastfir_batch_process(f->b, f->d_in, nproc, nproc, f->d_out, nproc, nullptr, 0);
-    if (rc) return rc;
-    f->stage_out.resize(2 * (size_t)nproc);
-    CSDR_HIP(hipMemcpy(f->stage_out.data(), f->d_out, (size_t)nproc * 8, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < 2 * (size_t)nproc; i++) out_iq[i] = (double)f->stage_out[i];
-    f->stage_in.erase(f->stage_in.begin(), f->stage_in.begin() + 2 * (size_t)nproc);
+    CSDR_HIP(hipMemcpyAsync(f->pin_out.p, f->d_out, (size_t)nproc * 8, hipMemcpyDeviceToHost, f->s));
+    CSDR_HIP(hipStreamSynchronize(f->s));
+    cvt_to_f64(out_iq, f->pin_out.p, 2 * (size_t)nproc);
+    f->pending = avail - nproc;
+    if (f->pending > 0) memmove(f->pin_in.p, f->pin_in.p + 2 * (size_t)nproc, 2 * (size_t)f->pending * sizeof(float));
     return nproc;
 }
 

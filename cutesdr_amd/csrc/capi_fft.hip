@@ -307,7 +307,11 @@ int csdr_fft_batch_get_waterfall_all(csdr_fft_batch *f, int max_w, double max_db
 struct csdr_fft {
     csdr_fft_batch *b;
     float *d_buf; size_t cap;
-    std::vector<float> st;
+    PinnedBuf pin;                   // page-locked fp32 staging of the frame (both directions of the plain transforms)
+    hipStream_t s = nullptr;         // the object's stream: the frame's copy and its kernels in order, no host wait in PutInDisplayFFT
+    hipEvent_t ev_h2d = nullptr;     // the last frame has left the pinned buffer
+    bool h2d_busy = false;
+    int total = 0;                   // m_TotalCount mirrored on the host: frames since the last reset (fft.cpp:515-517)
 };
 
 static int fft_host_buf(csdr_fft *f, size_t n)
@@ -328,22 +332,45 @@ csdr_fft *csdr_fft_create(int device)
     if (!b) return nullptr;
     csdr_fft *f = new csdr_fft();
     f->b = b; f->d_buf = nullptr; f->cap = 0;
+    if (hipStreamCreateWithFlags(&f->s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&f->ev_h2d, hipEventDisableTiming) != hipSuccess) {
+        if (f->s) (void)hipStreamDestroy(f->s);
+        csdr_fft_batch_destroy(b); delete f; fail(CSDR_EHIP, "stream creation failed"); return nullptr;
+    }
     return f;
 }
 void csdr_fft_destroy(csdr_fft *f)
 {
     if (!f) return;
     (void)hipSetDevice(f->b->device);
+    if (f->s) { (void)hipStreamSynchronize(f->s); (void)hipStreamDestroy(f->s); }
+    if (f->ev_h2d) (void)hipEventDestroy(f->ev_h2d);
     if (f->d_buf) (void)hipFree(f->d_buf);
     csdr_fft_batch_destroy(f->b);
     delete f;
 }
+// (the setters below synchronise the device inside the batch object: nothing of this object's stream is in flight after them)
 int csdr_fft_set_params(csdr_fft *f, int size, int invert, double db_comp, double fs)
-{ return f ? csdr_fft_batch_set_params(f->b, size, invert, db_comp, fs) : fail(CSDR_EINVAL, "bad handle"); }
+{
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    if (f->s) CSDR_HIP(hipStreamSynchronize(f->s));
+    f->total = 0;
+    return csdr_fft_batch_set_params(f->b, size, invert, db_comp, fs);
+}
 int csdr_fft_set_ave(csdr_fft *f, int ave)
-{ return f ? csdr_fft_batch_set_ave(f->b, ave) : fail(CSDR_EINVAL, "bad handle"); }
+{
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    if (f->s) CSDR_HIP(hipStreamSynchronize(f->s));
+    f->total = 0;                                        // SetFFTAve ends in ResetFFT (fft.cpp:103-113)
+    return csdr_fft_batch_set_ave(f->b, ave);
+}
 int csdr_fft_reset(csdr_fft *f)
-{ return f ? csdr_fft_batch_reset(f->b) : fail(CSDR_EINVAL, "bad handle"); }
+{
+    if (!f) return fail(CSDR_EINVAL, "bad handle");
+    if (f->s) CSDR_HIP(hipStreamSynchronize(f->s));
+    f->total = 0;
+    return csdr_fft_batch_reset(f->b);
+}
 
 /* CFft::PutInDisplayFFT (fft.cpp:267-288): n should equal the FFT size; returns m_TotalCount */
 int csdr_fft_put_display(csdr_fft *f, int n, const double *in_iq)
@@ -353,13 +380,20 @@ int csdr_fft_put_display(csdr_fft *f, int n, const double *in_iq)
     const int N = f->b->size;
     int rc = fft_host_buf(f, (size_t)N);
     if (rc) return rc;
-    f->st.assign(2 * (size_t)N, 0.f);                 // the reference keeps stale data past n; zeros here
+    if ((rc = f->pin.reserve(2 * (size_t)N))) return rc;
+    // The frame goes fp64 -> fp32 into pinned memory and from there to the device on the object's stream, the spectrum
+    // kernels behind it: nothing here waits for the GPU (the reference's caller does not either -- the readers,
+    // GetScreenIntegerFFTData / get_ave, synchronise).  The pinned buffer is reused once its last copy has left.
+    if (f->h2d_busy) { CSDR_HIP(hipEventSynchronize(f->ev_h2d)); f->h2d_busy = false; }
     const int m = n < N ? n : N;
-    for (size_t i = 0; i < 2 * (size_t)m; i++) f->st[i] = (float)in_iq[i];
-    CSDR_HIP(hipMemcpy(f->d_buf, f->st.data(), (size_t)N * 8, hipMemcpyHostToDevice));
-    rc = csdr_fft_batch_put_display(f->b, f->d_buf, N, 1, nullptr);
+    cvt_to_f32(f->pin.p, in_iq, 2 * (size_t)m);
+    if (m < N) memset(f->pin.p + 2 * (size_t)m, 0, 2 * (size_t)(N - m) * sizeof(float));   // the reference keeps stale data past n; zeros here
+    CSDR_HIP(hipMemcpyAsync(f->d_buf, f->pin.p, (size_t)N * 8, hipMemcpyHostToDevice, f->s));
+    CSDR_HIP(hipEventRecord(f->ev_h2d, f->s));
+    f->h2d_busy = true;
+    rc = csdr_fft_batch_put_display(f->b, f->d_buf, N, 1, (void *)f->s);
     if (rc) return rc;
-    return csdr_fft_batch_get_total_count(f->b, 0);
+    return ++f->total;                                   // m_TotalCount (fft.cpp:287): frames since the last reset
 }
 /* CFft::GetScreenIntegerFFTData (fft.cpp:308-410); returns the overload flag */
 int csdr_fft_get_screen(csdr_fft *f, int max_h, int max_w, double max_db, double min_db, int start_hz,
@@ -378,14 +412,17 @@ static int fft_plain(csdr_fft *f, double *inout, int sign)
     const int N = f->b->size;
     int rc = fft_host_buf(f, (size_t)N);
     if (rc) return rc;
-    f->st.resize(2 * (size_t)N);
-    for (size_t i = 0; i < 2 * (size_t)N; i++) f->st[i] = (float)inout[i];
-    CSDR_HIP(hipMemcpy(f->d_buf, f->st.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+    if ((rc = f->pin.reserve(2 * (size_t)N))) return rc;
+    if (f->h2d_busy) { CSDR_HIP(hipEventSynchronize(f->ev_h2d)); f->h2d_busy = false; }
+    cvt_to_f32(f->pin.p, inout, 2 * (size_t)N);
+    hipStream_t st = f->s;
+    CSDR_HIP(hipMemcpyAsync(f->d_buf, f->pin.p, (size_t)N * 8, hipMemcpyHostToDevice, st));
     const int l2 = log2_of(N);
-    if (l2 >= 11 && l2 <= 14) CSDR_HIP(fft_plain_launch(l2, sign, f->d_buf, f->d_buf, f->b->d_tw1, f->b->d_tw2, nullptr));
-    else CSDR_HIP(fft_generic_plain_launch(l2, sign, f->d_buf, f->d_buf, f->b->d_work, nullptr));
-    CSDR_HIP(hipMemcpy(f->st.data(), f->d_buf, (size_t)N * 8, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < 2 * (size_t)N; i++) inout[i] = (double)f->st[i];
+    if (l2 >= 11 && l2 <= 14) CSDR_HIP(fft_plain_launch(l2, sign, f->d_buf, f->d_buf, f->b->d_tw1, f->b->d_tw2, st));
+    else CSDR_HIP(fft_generic_plain_launch(l2, sign, f->d_buf, f->d_buf, f->b->d_work, st));
+    CSDR_HIP(hipMemcpyAsync(f->pin.p, f->d_buf, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    CSDR_HIP(hipStreamSynchronize(st));
+    cvt_to_f64(inout, f->pin.p, 2 * (size_t)N);
     return CSDR_OK;
 }
 int csdr_fft_fwd(csdr_fft *f, double *inout_iq) { return fft_plain(f, inout_iq, +1); }
