@@ -558,6 +558,37 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
     return out
 
 
+def packets_chain(torch, ca, ctx, c4):
+    """The C4 share fed with the radio's own 24-bit datagrams (interface/netiobase.cpp:479-527: 6 B per sample instead
+    of 8) -- no unpack pass, the down-converter decodes them in its loads -- and the same with CNoiseProc's blanker in
+    front (interface/sdrinterface.cpp:884), FUSED: the blanker kernel leaves one bit per sample, the down-converter takes
+    the delayed sample itself and zeroes it under the mask (no blanked copy of the input is written).  Strict mode."""
+    C, T, x = c4.C, c4.T, c4.x
+    npk = (T // 240) // 8 * 8                            # 1920 = 64 * 30 samples: a multiple of the largest decimation
+    Tp = npk * 240
+    pk = torch.zeros((C, npk, 1444), device=x.device, dtype=torch.uint8)
+    for c0 in range(0, C, 32):                           # the receivers' own signals in the wire format: value * 256, 3 LE bytes
+        v = torch.round(x[c0:c0 + 32, :Tp].reshape(-1, npk, 480) * 256.0).clamp(-(1 << 23), (1 << 23) - 1).to(torch.int32)
+        body = torch.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], dim=-1).to(torch.uint8).reshape(-1, npk, 1440)
+        pk[c0:c0 + 32, :, 4:] = body
+        del v, body
+    c4.set_mode(False)
+    nb = ca.NoiseProcBatch(C, device=ctx.local)
+    nb.setup(True, 50.0, 2.0, C4_FS)
+    out = {"config": "C4 share from 24-bit datagrams: %d receivers x %d samples per call, strict mode" % (C, Tp)}
+    for key, blk in (("packets_chain_ms", None), ("packets_blanker_chain_ms", nb)):
+        def run():
+            rc = ca.lib().csdr_demod_batch_process_packets(c4.b.h, pk.data_ptr(), npk, 1444, blk.h if blk is not None else None,
+                                                           c4.aud.data_ptr(), c4.cap, c4.stream)
+            assert rc == 0, ca._capi.last_error()
+        out[key] = round(gpu_ms(torch, run, 8, 20), 4)
+    out["raw_input_MSamples_per_s"] = round(C * Tp / out["packets_chain_ms"] / 1e3, 1)
+    out["with_blanker_MSamples_per_s"] = round(C * Tp / out["packets_blanker_chain_ms"] / 1e3, 1)
+    out["blanker"] = "fused: noiseblank_kernel<mask> + downconv_kernel<plan, BLK> (CSDR_BLANK_FUSED=0: two passes through a blanked fp32 copy)"
+    del nb, pk
+    return out
+
+
 def chain_one_receiver(torch, ca, ctx, with_cpu, name, check=True):
     """BASELINE configs C2 (2 MSPS -> CDownConvert -> 16384-pt CFastFIR -> AGC -> FM) and C5 (10 MSPS -> ... 2048-pt
     filter -> FM -> CFractResampler to 48 kHz): ONE receiver resident in HBM.  A single receiver cannot fill the
@@ -1047,6 +1078,7 @@ def run_rank(args):
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
                 extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu)
                 extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu))
+                extra["packets_chain"] = packets_chain(torch, ca, ctx, c4)
             del c4
             torch.cuda.empty_cache()
             if ctx.world == 1:

@@ -46,7 +46,11 @@ StreamPool &stream_pool() { static StreamPool *p = new StreamPool(); return *p; 
 
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
-                                                    long long out_stride, void *stream, const void *d_packets, int pkt_len);
+                                                    long long out_stride, void *stream, const void *d_packets, int pkt_len,
+                                                    const csdr::DcBlank *blank);
+extern "C" int csdr__noiseproc_batch_mask(struct csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const void *d_packets,
+                                          int npackets, int pkt_len, int n_per_channel, unsigned *d_mask, long long mask_stride,
+                                          const void **d_state, const float **d_hist, void *stream);
 extern "C" int csdr__downconvert_batch_copy_channel(csdr_downconvert_batch *dst, int dc, csdr_downconvert_batch *src, int sc);
 extern "C" int csdr__fastfir_batch_copy_row(csdr_fastfir_batch *dst, int dr, csdr_fastfir_batch *src, int sr);
 extern "C" int csdr__noiseproc_batch_process_packets(struct csdr_noiseproc_batch *b, const void *d_packets, int npackets,
@@ -88,6 +92,7 @@ struct ChainCore {
     hipStream_t s_dem = nullptr, s_sm = nullptr;
     hipEvent_t ev_fork = nullptr, ev_dem = nullptr, ev_sm = nullptr, ev_agc[8] = {};                       // staging capacity per row (complex samples)
     const void *pk = nullptr; int pk_len = 0;   // this call's input as datagrams (csdr_demod_batch_process_packets)
+    const DcBlank *blank = nullptr;     // this call's blanker mask, applied by the down-converter (or nullptr)
     int pending = 0;                    // decimated samples waiting for a full hop (same in every row)
     int last_out = 0;
 
@@ -229,7 +234,7 @@ struct ChainCore {
         // what follows a group's down-converter overlaps with the next group's
         if (dc_after) CSDR_HIP(hipStreamWaitEvent(s, dc_after, 0));
         rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, d_stage + 2 * (size_t)pending,
-                                                  cap, s, pk, pk_len);
+                                                  cap, s, pk, pk_len, blank);
         if (rc) return rc;
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
         m_call = m;
@@ -273,7 +278,7 @@ struct ChainCore {
         // the filter + shift of the call that last used this staging buffer must have finished with it
         if (stage_busy[sc]) { CSDR_HIP(hipStreamWaitEvent(s, ev_stage_free[sc], 0)); stage_busy[sc] = false; }
         rc = csdr__downconvert_batch_process_rows(dc, d_in, in_stride, d_in_rows, n, stage + 2 * (size_t)pending, cap, s,
-                                                  pk, pk_len);
+                                                  pk, pk_len, blank);
         if (rc) return rc;
         CSDR_HIP(hipEventRecord(ev_dc, s));
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
@@ -417,14 +422,17 @@ struct csdr_demod_batch {
     bool pipelined = false;                           // csdr_demod_batch_set_pipelined
     std::vector<int> prev_post;                       // pipelined: per core, the post-chain event of the previous call
     std::vector<char> prev_join;                      // pipelined: per core, joins[] of the previous call not yet waited for
-    float *d_blank = nullptr;                         // blanked input of process_packets
+    float *d_blank = nullptr;                         // blanked input of process_packets (two-pass form)
     long raw_cap = 0;
+    unsigned *d_mask = nullptr; long mask_cap = 0;    // the blanker's mask of process_packets (fused form): [channels][mask_cap] words
+    DcBlank blank{};
     ~csdr_demod_batch()
     {
         for (auto *k : cores) delete k;
         for (auto *p : d_rows) if (p) (void)hipFree(p);
         for (auto *p : d_out_rows) if (p) (void)hipFree(p);
         if (d_blank) (void)hipFree(d_blank);
+        if (d_mask) (void)hipFree(d_mask);
         for (auto st : streams) stream_pool().put(device, st);
         for (auto ev : joins) (void)hipEventDestroy(ev);
         for (auto ev : dc_done) (void)hipEventDestroy(ev);
@@ -930,7 +938,7 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
  * decision is taken once per FastFIR hop either way).  Asynchronous. */
 static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
                            float *d_out, long long out_stride, void *stream, bool stereo,
-                           const void *d_packets = nullptr, int pkt_len = 0)
+                           const void *d_packets = nullptr, int pkt_len = 0, const DcBlank *blank = nullptr)
 {
     if (!b || (!d_in && !d_packets) || !d_out) return fail(CSDR_EINVAL, "bad argument");
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
@@ -953,7 +961,7 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         for (size_t oi = 0; oi < b->cores.size(); oi++) {
             const size_t ki = (size_t)b->order[oi];
             ChainCore &k = *b->cores[ki];
-            k.pk = d_packets; k.pk_len = pkt_len;
+            k.pk = d_packets; k.pk_len = pkt_len; k.blank = blank;
             CSDR_HIP(hipStreamWaitEvent(b->streams[ki], b->fork, 0));
             const int rc = k.step_dc(d_in, in_stride, b->d_rows[ki], n_per_channel, b->streams[ki],
                                      phased == 2 && oi > 0 ? b->dc_done[b->order[oi - 1]] : nullptr, b->dc_done[ki]);
@@ -981,6 +989,7 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         const size_t ki = (size_t)b->order[oi];
         ChainCore &k = *b->cores[ki];
         k.pk = d_packets; k.pk_len = pkt_len;            // this call's input as datagrams, or nullptr
+        k.blank = blank;                                  // this call's blanker mask, or nullptr
         hipStream_t st = forked ? b->streams[ki] : caller;
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
         // pipelined: the caller's stream catches up with the PREVIOUS call only now, behind this call's fork
@@ -1035,7 +1044,34 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     if (n > 0x7fffffffL) return fail(CSDR_EINVAL, "%d datagrams are more samples than one call can take", npackets);
     if (!nb)        // the down-converter decodes the datagrams in its own loads: no unpacked copy, no extra pass
         return demod_batch_run(b, nullptr, 0, (int)n, d_out, out_stride, stream, false, d_packets, pkt_len);
-    // with the blanker: it decodes the datagrams in ITS loads and leaves blanked fp32 samples for the chain
+    // With the blanker.  The internal buffers below (mask / blanked samples) are single-buffered, and the blanker's
+    // history halves alternate per call: in pipelined mode the down-converters of the PREVIOUS call (on the batch's own
+    // streams) may still be reading them, and the caller's stream -- on which the blanker of this call runs -- has not
+    // joined them yet (demod_batch_run does that, later)
+    if (b->pipelined)
+        for (size_t ki = 0; ki < b->cores.size(); ki++)
+            if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
+    // FUSED (default): the blanker decides, the down-converter applies -- noiseblank_kernel leaves one bit per sample,
+    // downconv_kernel<.., BLK> reads the datagram sample delay_n + 1 behind and zeroes it under the mask in its own
+    // load.  No blanked copy of the input: 8 B written + 8 B read back per sample less, and one input stream less in
+    // the blanker ("fuses naturally into the NCO kernel's load").  CSDR_BLANK_FUSED=0: the two-pass form.
+    static const bool fused = !(getenv("CSDR_BLANK_FUSED") && atoi(getenv("CSDR_BLANK_FUSED")) == 0);
+    if (fused) {
+        const long words = (n + 31) / 32 + 64;
+        if (words > b->mask_cap) {
+            CSDR_HIP(hipDeviceSynchronize());
+            if (b->d_mask) (void)hipFree(b->d_mask);
+            b->d_mask = nullptr; b->mask_cap = 0;
+            CSDR_HIP(hipMalloc((void **)&b->d_mask, (size_t)b->channels * words * sizeof(unsigned)));
+            b->mask_cap = words;
+        }
+        b->blank.mask = b->d_mask; b->blank.mask_stride = b->mask_cap;
+        int rc = csdr__noiseproc_batch_mask(nb, nullptr, 0, d_packets, npackets, pkt_len, (int)n, b->d_mask, b->mask_cap,
+                                            &b->blank.state, &b->blank.hist, stream);
+        if (rc < 0) return rc;
+        return demod_batch_run(b, nullptr, 0, (int)n, d_out, out_stride, stream, false, d_packets, pkt_len, &b->blank);
+    }
+    // two passes: the blanker decodes the datagrams in ITS loads and leaves blanked fp32 samples for the chain
     if (n > b->raw_cap) {
         CSDR_HIP(hipDeviceSynchronize());
         if (b->d_blank) (void)hipFree(b->d_blank);
@@ -1043,12 +1079,6 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
         CSDR_HIP(hipMalloc((void **)&b->d_blank, (size_t)b->channels * n * 8));
         b->raw_cap = n;
     }
-    // d_blank is the library's own staging buffer, single-buffered: in pipelined mode the down-converters of the
-    // PREVIOUS call (on the batch's own streams) may still be reading it, and the caller's stream -- on which the
-    // blanker of this call runs -- has not joined them yet (demod_batch_run does that, later)
-    if (b->pipelined)
-        for (size_t ki = 0; ki < b->cores.size(); ki++)
-            if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
     int rc = csdr__noiseproc_batch_process_packets(nb, d_packets, npackets, pkt_len, b->d_blank, b->raw_cap, stream);
     if (rc < 0) return rc;
     return demod_batch_run(b, b->d_blank, b->raw_cap, (int)n, d_out, out_stride, stream, false);

@@ -81,7 +81,8 @@ extern "C" int csdr__downconvert_batch_copy_channel(csdr_downconvert_batch *dst,
 extern "C" int csdr__downconv_force_dynamic(int on) { return downconv_force_dynamic(on); }
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
-                                                    long long out_stride, void *stream, const void *d_packets, int pkt_len);
+                                                    long long out_stride, void *stream, const void *d_packets, int pkt_len,
+                                                    const csdr::DcBlank *blank);
 
 extern "C" {
 
@@ -195,14 +196,16 @@ int csdr_downconvert_batch_out_count(csdr_downconvert_batch *b, int channel, int
 int csdr_downconvert_batch_process(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                    int n_per_channel, float *d_out, long long out_stride, void *stream)
 {
-    return csdr__downconvert_batch_process_rows(b, d_in, in_stride, nullptr, n_per_channel, d_out, out_stride, stream, nullptr, 0);
+    return csdr__downconvert_batch_process_rows(b, d_in, in_stride, nullptr, n_per_channel, d_out, out_stride, stream, nullptr, 0, nullptr);
 }
 
 /* internal (not in the public header): input row of channel c is in_rows[c] (device array); with d_packets the
- * samples are read from datagrams ([rows][n_per_channel / per][pkt_len] bytes, wire_format.hpp) instead of d_in */
+ * samples are read from datagrams ([rows][n_per_channel / per][pkt_len] bytes, wire_format.hpp) instead of d_in; with
+ * `blank` the noise blanker's mask (csdr__noiseproc_batch_mask) is applied in the kernel's own loads */
 int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                          const int *d_in_rows, int n_per_channel, float *d_out,
-                                         long long out_stride, void *stream, const void *d_packets, int pkt_len)
+                                         long long out_stride, void *stream, const void *d_packets, int pkt_len,
+                                         const DcBlank *blank)
 {
     if (!b || (!d_in && !d_packets) || !d_out) return fail(CSDR_EINVAL, "bad handle or null buffer");
     if (n_per_channel <= 0 || (n_per_channel & 1)) return fail(CSDR_EINVAL, "n_per_channel must be even and > 0");
@@ -264,6 +267,10 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         a.chan = b->d_chan + (size_t)b->chan_cur * b->channels;
         a.chan_next = b->d_chan + (size_t)(b->chan_cur ^ 1) * b->channels;
         a.chan_list = b->d_list + b->list_off[pi]; a.amp = b->d_amp; a.in_rows = d_in_rows;
+        if (blank) {
+            a.nb_mask = blank->mask; a.nb_mask_stride = blank->mask_stride;
+            a.nb_state = (const NbChan *)blank->state; a.nb_hist = (const dc_v2f *)blank->hist;
+        }
         a.nchan = b->list_len[pi]; a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
         for (int q = 0; q < p.nstages; q++) { a.st[q] = p.st[q]; a.kind[q] = p.kind[q]; }
         // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long

@@ -85,7 +85,7 @@ int csdr_noiseproc_batch_setup(csdr_noiseproc_batch *b, int channel, int on, dou
     return CSDR_OK;
 }
 static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const WireIn &wire, int n_per_channel,
-                  float *d_out, long long out_stride, void *stream);
+                  float *d_out, long long out_stride, void *stream, unsigned *d_mask = nullptr, long long mask_stride = 0);
 int csdr_noiseproc_batch_process(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, int n_per_channel,
                                  float *d_out, long long out_stride, void *stream)
 {
@@ -108,8 +108,33 @@ int csdr__noiseproc_batch_process_packets(csdr_noiseproc_batch *b, const void *d
     return nb_run(b, nullptr, 0, WireIn{(const unsigned char *)d_packets, (long)npackets * pkt_len, pkt_len, per},
                   npackets * per, d_out, out_stride, stream);
 }
+/* internal (csdr_demod_batch_process_packets / _process with a blanker): MASK MODE -- the blanker decides, the
+ * down-converter applies.  One pass over the call's samples (float rows, or datagrams when d_packets is given) leaves one
+ * bit per sample in d_mask ([channels][mask_stride] words; set = blanked) and advances the blanker's state and
+ * history; nothing else is written.  *d_state / *d_hist receive the state array ([channels] NbChan: on, delay_n) and
+ * the raw-sample history ([channels][NB_HIST] complex: the inputs before this call) the consumer needs to take
+ * x[i - delay_n - 1] itself -- the halves as they were BEFORE this call (the kernel does not touch them). */
+int csdr__noiseproc_batch_mask(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const void *d_packets,
+                               int npackets, int pkt_len, int n_per_channel, unsigned *d_mask, long long mask_stride,
+                               const void **d_state, const float **d_hist, void *stream)
+{
+    if (!b || (!d_in && !d_packets) || !d_mask || n_per_channel < 0 || !d_state || !d_hist) return fail(CSDR_EINVAL, "bad argument");
+    if (mask_stride * 32 < n_per_channel) return fail(CSDR_EINVAL, "mask rows too short");
+    WireIn wire{nullptr, 0, 0, 0};
+    if (d_packets) {
+        if (pkt_len != 1028 && pkt_len != 1444) return fail(CSDR_EINVAL, "packet length %d", pkt_len);
+        const int per = pkt_len == 1444 ? 240 : 256;
+        if ((long)npackets * pkt_len >= (1l << 31) || ((uintptr_t)d_packets & 3) || npackets * per != n_per_channel)
+            return fail(CSDR_EINVAL, "datagram buffer: 4-byte aligned, below 2 GiB per channel, npackets x samples = n");
+        wire = WireIn{(const unsigned char *)d_packets, (long)npackets * pkt_len, pkt_len, per};
+    }
+    const size_t half = (size_t)b->channels * NB_HIST * 2;
+    *d_state = b->d_chan + (size_t)b->cur * b->channels;
+    *d_hist = b->d_hist + b->cur * half;
+    return nb_run(b, d_in, in_stride, wire, n_per_channel, nullptr, 0, stream, d_mask, mask_stride);
+}
 static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const WireIn &wire, int n_per_channel,
-                  float *d_out, long long out_stride, void *stream)
+                  float *d_out, long long out_stride, void *stream, unsigned *d_mask, long long mask_stride)
 {
     if (n_per_channel == 0) return CSDR_OK;
     if (!device_ok(b->device)) return CSDR_EHIP;
@@ -118,10 +143,14 @@ static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_strid
     a.wire = wire;
     a.chan = b->d_chan + (size_t)b->cur * b->channels; a.chan_next = b->d_chan + (size_t)(b->cur ^ 1) * b->channels; a.in = d_in; a.in_stride = in_stride; a.out = d_out; a.out_stride = out_stride;
     a.hist = b->d_hist + b->cur * half; a.hist_next = b->d_hist + (b->cur ^ 1) * half;
+    a.mask = d_mask; a.mask_stride = mask_stride;
     a.channels = b->channels; a.n = n_per_channel;
     // segments: enough workgroups to fill the chip, each at least 32 tiles long (the longest blank
     // width is 4 tiles, the moving-sum reduction at a segment start another ~10-32 tiles' worth of reads)
-    static const long want_wgs = getenv("CSDR_NB_WGS") ? atol(getenv("CSDR_NB_WGS")) : 2048;
+    // (mask mode: 74 registers, three 512-thread workgroups per CU: 3072 workgroups = four rounds measured best,
+    // 3.28 ms for the C4 share's datagram-fed chain against 3.36 with 2048 and 3.49 with 4096)
+    static const long want_env = getenv("CSDR_NB_WGS") ? atol(getenv("CSDR_NB_WGS")) : 0;
+    const long want_wgs = want_env > 0 ? want_env : (d_mask ? 3072 : 2048);
     long nseg = (want_wgs + b->channels - 1) / b->channels;
     const long tile = noiseblank_tile();
     const long min_seg = 32 * tile;

@@ -29,6 +29,7 @@ constexpr int DC_T = 64;                  // threads per workgroup
 constexpr int DC_ROW = 2 * DC_T;           // samples per row (16 B per lane)
 constexpr int DC_TILE = 512;              // input samples per tile
 constexpr int DC_ANCHOR_ROWS = 16;
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));   // a 16-byte load from an 8-byte aligned address
 
 // ---- the cascade as a compile-time plan ----------------------------------------------------------------
 // SetDataRate's stage sequences are few in practice (CIC-3s, then 11-tap half bands, then one to three longer
@@ -293,7 +294,15 @@ __device__ __forceinline__ void dc_stage_full(const v2f *E, const v2f *O, v2f *y
     }
 }
 
-template <class P>
+// value of lane + 1 (lane 63: lane 0's): the DPP wavefront rotate, no LDS
+__device__ __forceinline__ float dc_rotl1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, false));   // wave_rol:1
+}
+
+// BLK: the noise blanker's decision applied in this kernel's loads (DcArgs::nb_mask; a kernel of its own so that the
+// plain kernel keeps its registers: the blanked form carries the mask words and one more sample per tile)
+template <class P, bool BLK = false>
 __global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void downconv_kernel(DcArgs a)
 {
@@ -343,6 +352,30 @@ void downconv_kernel(DcArgs a)
     const long in_row = a.in_rows ? a.in_rows[ch] : ch;
     const v2f *in = a.in + in_row * a.in_stride;
     const unsigned char *pk = a.wire.pk ? a.wire.pk + in_row * a.wire.chan_stride : nullptr;   // datagram input
+    // blanker in front: delay D1 = delay_n + 1 (0 when the row's blanker is off: its mask is all zero), mask row, history
+    int D1 = 0;
+    const unsigned *mrow = nullptr;
+    const v2f *bhist = nullptr;
+    if constexpr (BLK) {
+        const NbChan nb = a.nb_state[in_row];
+        D1 = nb.on ? nb.delay_n + 1 : 0;
+        mrow = a.nb_mask + in_row * a.nb_mask_stride;
+        bhist = a.nb_hist + in_row * NB_HIST;
+    }
+    // one raw input sample of the stream the blanker saw: this call's, or the history's for j < 0 (BLK only)
+    auto raw_at = [&](long j) -> v2f {
+        if (j < 0) return bhist[NB_HIST + j];
+        if (pk) { const wf2 w = wire_sample(pk, a.wire.pkt_len, j); return v2f{w.x, w.y}; }
+        return in[j];
+    };
+    // samples idx, idx + 1 (idx even) as the blanker hands them over: delayed by D1, zero under the mask
+    auto blanked_pair = [&](long idx) -> v4f {
+        v2f s0 = raw_at(idx - D1), s1 = raw_at(idx + 1 - D1);
+        const unsigned m = mrow[idx >> 5] >> (idx & 31);
+        if (m & 1u) s0 = v2f{0.f, 0.f};
+        if (m & 2u) s1 = v2f{0.f, 0.f};
+        return v4f{s0.x, s0.y, s1.x, s1.y};
+    };
     v2f *out = a.out + (long)ch * a.out_stride;
     const v2f *hist = a.hist + (long)ch * a.hist_stride;
     v2f *hist_next = a.hist_next + (long)ch * a.hist_stride;
@@ -356,12 +389,54 @@ void downconv_kernel(DcArgs a)
     // through the cascade: nothing waits on HBM latency except the very first tile.
     constexpr int NR = DC_TILE / DC_ROW;
     v4f raw[NR];
+    // BLK: the tile's mask words (a lane's two samples of a row share one) and, for datagram input behind an ODD delay,
+    // the raw words of the one sample behind the tile's last pair (see the steady loop)
+    unsigned mkw = 0u;                                   // lane l & 15 holds word l & 15 of the tile's sixteen mask words
+    unsigned xw[3] = {0u, 0u, 0u};
+    // BLK: the prefetch of a COMPLETE tile at p whose delayed samples all lie in this call's input (the steady loop's
+    // condition); other tiles are read where they are consumed (blanked_pair)
+    auto fetch_blk = [&](long p, auto FMT) {
+        if constexpr (BLK) {
+            constexpr int fmt = FMT.value;                   // 0: float rows, otherwise the datagram length
+            if (!(p - D1 - 1 >= 0 && p + DC_TILE <= seg_end)) return;
+            const bool odd = D1 & 1;
+            mkw = mrow[(p >> 5) + (t & 15)];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const long i = p + r * DC_ROW + 2 * t;
+                if constexpr (fmt != 0) {
+                    const wf4 w = wire_pair_fetch(pk, fmt, i - D1 - (odd ? 1 : 0));               // an aligned pair
+                    raw[r] = v4f{w.x, w.y, w.z, w.w};
+                } else {
+                    raw[r] = *reinterpret_cast<const f4a8 *>(in + i - D1);                        // 8-byte aligned, 16 bytes
+                }
+            }
+            if constexpr (fmt != 0) {
+                if (odd) {                                      // the sample behind the tile's last aligned pair
+                    const unsigned j = (unsigned)(p + DC_TILE - 1 - D1);
+                    if constexpr (fmt == 1444) {
+                        const unsigned q = j / 240u, jj = j - q * 240u;
+                        const unsigned short *h = reinterpret_cast<const unsigned short *>(pk + (q * 1444u + 4u + 6u * jj));
+                        xw[0] = h[0]; xw[1] = h[1]; xw[2] = h[2];
+                    } else {
+                        xw[0] = *reinterpret_cast<const unsigned *>(pk + ((j >> 8) * 1028u + 4u + 4u * (j & 255u)));
+                    }
+                }
+            }
+        }
+    };
+    auto fetch_blk_any = [&](long p) {
+        if (!pk) fetch_blk(p, std::integral_constant<int, 0>{});
+        else if (a.wire.pkt_len == 1444) fetch_blk(p, std::integral_constant<int, 1444>{});
+        else fetch_blk(p, std::integral_constant<int, 1028>{});
+    };
     auto tile_len = [&](long p) {
         const long lim = ((p < seg_start) ? seg_start : seg_end) - p;
         return (int)(lim < DC_TILE ? lim : DC_TILE);
     };
     auto fetch = [&](long p) {
         if (p >= seg_end || (p < seg_start && seg == 0)) return;      // past the end / history-fed warm-up
+        if constexpr (BLK) { fetch_blk_any(p); return; }
         const int m = tile_len(p);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -407,6 +482,7 @@ void downconv_kernel(DcArgs a)
                 const bool w = pos < seg_start;
                 const long lim = w ? seg_start : hi;
                 if (!(pos + DC_TILE <= lim && (seg > 0 || pos >= 0) && cs.age + (unsigned long long)pos >= DC_AMP_N)) break;
+                if constexpr (BLK) { if (pos - D1 - 1 < 0) break; }     // the delayed samples reach into the history: general tile
                 if (anchor_rows <= 0) {
                     p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(pos + 2 * t + 1)) * a_inf;
                     p1 = cmul(p0, step1);
@@ -415,12 +491,51 @@ void downconv_kernel(DcArgs a)
                 anchor_rows -= NR;
                 {
                     v2f *e = lds + LY.roff[0] + dc_hist_of(P::KIND[0]) / 2 + t, *o = e + LY.ooff[0];
+                    bool any_blank = false;
+                    if constexpr (BLK) any_blank = __any(mkw != 0u);
+                    v4f dv[NR];
 #pragma unroll
                     for (int row = 0; row < NR; row++) {
-                        v4f v = raw[row];
+                        dv[row] = raw[row];
                         if constexpr (fmt != 0) {
-                            const wf4 d = wire_pair_decode(wf4{v.x, v.y, v.z, v.w}, fmt);
-                            v = v4f{d.x, d.y, d.z, d.w};
+                            const wf4 d = wire_pair_decode(wf4{dv[row].x, dv[row].y, dv[row].z, dv[row].w}, fmt);
+                            dv[row] = v4f{d.x, d.y, d.z, d.w};
+                        }
+                    }
+                    if constexpr (BLK && fmt != 0) {
+                        // datagrams behind an ODD delay: the lane fetched the aligned pair (e, e+1) and wants (e+1, e+2);
+                        // e+2 is the first sample of the next lane's pair (lane 63: of the next row's lane 0, and behind
+                        // the tile's last pair the one sample fetched into xw) -- a wavefront rotate, no LDS
+                        if (D1 & 1) {
+                            v2f xs;
+                            if constexpr (fmt == 1444) {
+                                const int vi = (int)((xw[0] << 8) | ((xw[1] & 0xffu) << 24)), vq = (int)(((xw[1] >> 8) << 8) | (xw[2] << 16));
+                                xs = v2f{(float)vi * (1.0f / 65536.0f), (float)vq * (1.0f / 65536.0f)};
+                            } else {
+                                xs = v2f{(float)(short)(xw[0] & 0xffffu), (float)(short)(xw[0] >> 16)};
+                            }
+#pragma unroll
+                            for (int row = 0; row < NR; row++) {
+                                const float ax = dc_rotl1(dv[row].x), ay = dc_rotl1(dv[row].y);
+                                const float bx = row + 1 < NR ? dc_rotl1(dv[row + 1 < NR ? row + 1 : row].x) : xs.x;
+                                const float by = row + 1 < NR ? dc_rotl1(dv[row + 1 < NR ? row + 1 : row].y) : xs.y;
+                                const bool lastlane = t == DC_T - 1;
+                                raw[row] = v4f{dv[row].z, dv[row].w, lastlane ? bx : ax, lastlane ? by : ay};
+                            }
+#pragma unroll
+                            for (int row = 0; row < NR; row++) dv[row] = raw[row];
+                        }
+                    }
+#pragma unroll
+                    for (int row = 0; row < NR; row++) {
+                        v4f v = dv[row];
+                        if constexpr (BLK) {
+                            if (any_blank) {                                   // (rare: a tile with an impulse in it)
+                                // word 4 row + (t >> 4) of the tile's sixteen; tiles start at multiples of 512: (i & 31) = 2t & 31
+                                const unsigned m = (unsigned)__shfl((int)mkw, 4 * row + (t >> 4)) >> ((2 * t) & 31);
+                                if (m & 1u) { v.x = 0.f; v.y = 0.f; }
+                                if (m & 2u) { v.z = 0.f; v.w = 0.f; }
+                            }
                         }
                         e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
                         o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
@@ -429,7 +544,9 @@ void downconv_kernel(DcArgs a)
                     }
                 }
                 lds_barrier();
-                if (pos + 2 * DC_TILE <= lim) {                 // the next tile is complete too: all rows, no bounds
+                if constexpr (BLK) {
+                    fetch_blk(pos + DC_TILE, FMT);
+                } else if (pos + 2 * DC_TILE <= lim) {          // the next tile is complete too: all rows, no bounds
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
                         const long i = pos + DC_TILE + r * DC_ROW + 2 * t;
@@ -511,7 +628,8 @@ void downconv_kernel(DcArgs a)
                 v2f *e = r0 + t, *o = r0o + t;
 #pragma unroll
                 for (int row = 0; row < NR; row++) {
-                    const v4f v = unwire(raw[row]);
+                    v4f v;
+                    if constexpr (BLK) v = blanked_pair(pos + row * DC_ROW + 2 * t); else v = unwire(raw[row]);
                     e[row * DC_T] = cmul(v2f{v.x, v.y}, p0);
                     o[row * DC_T] = cmul(v2f{v.z, v.w}, p1);
                     p0 = cmul(p0, rowstep);
@@ -523,7 +641,8 @@ void downconv_kernel(DcArgs a)
                 const int i = row * DC_ROW + 2 * t;
                 const long gi = pos + i;                       // sample index within the call
                 if (i < n) {
-                    const v4f v = unwire(raw[row]);
+                    v4f v;
+                    if constexpr (BLK) v = blanked_pair(gi); else v = unwire(raw[row]);
                     v2f x0 = cmul(v2f{v.x, v.y}, p0), x1 = cmul(v2f{v.z, v.w}, p1);
                     const unsigned long long age = cs.age + (unsigned long long)gi;
                     if (age + 1 < DC_AMP_N) {                   // start-up envelope (the phasors carry a_inf)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "wire_format.hpp"
+#include "frontend_kernels.h"
 
 namespace csdr {
 
@@ -39,11 +40,26 @@ struct DcArgs {
     const int *chan_list;                    // optional [nchan] channel ids of this launch
     const int *in_rows;                      // optional [channels]: input row of each channel id
     const float *amp;                        // [DC_AMP_N] amplitude envelope a_n
+    // Optional noise blanker in front (CNoiseProc::ProcessBlanker, dsp/noiseproc.cpp:121-176, in MASK MODE:
+    // noiseblank_kernel has left one bit per sample): sample i of the call, as the reference's in-place blanker would
+    // have handed it over (interface/sdrinterface.cpp:884), is
+    //     mask bit i set ? 0 : raw[i - delay_n - 1]          raw[j < 0] = nb_hist[NB_HIST + j], the inputs before this call
+    // taken in this kernel's own loads -- no blanked copy of the input is ever written.  All indexed by INPUT ROW.
+    const unsigned *nb_mask; long nb_mask_stride;   // [rows][stride] words; nullptr: no blanker
+    const NbChan *nb_state;                         // [rows]: on (off: no delay, mask all zero), delay_n
+    const dc_v2f *nb_hist;                          // [rows][NB_HIST]
     int nchan, n_in, nstages, W, seg_len, nseg;
     int roff[DC_MAX_STAGES + 2];             // LDS region of each stage's input (the last one: tile outputs)
     int ooff[DC_MAX_STAGES + 1];             // offset of the odd-sample half inside region s
     int kind[DC_MAX_STAGES];                 // 3 = CIC3, otherwise the half-band length (11, 15, .. 51)
     DcStage st[DC_MAX_STAGES];
+};
+
+// what a caller hands over to have the blanker's mask applied (csdr__downconvert_batch_process_rows)
+struct DcBlank {
+    const unsigned *mask; long mask_stride;
+    const void *state;                   // [rows] NbChan
+    const float *hist;                   // [rows][NB_HIST] complex
 };
 
 hipError_t downconv_launch(DcArgs &a, hipStream_t stream);

@@ -52,6 +52,15 @@ hipError_t downconv_launch(DcArgs &a, hipStream_t stream)
             if (same) return p->launch(a, stream);
         }
     // per launch: the attribute belongs to the current device, and a process may drive several
+    if (a.nb_mask) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<DcPlanDyn, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((downconv_kernel<DcPlanDyn, true>), dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
+        return hipGetLastError();
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<DcPlanDyn>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -17,6 +17,15 @@ hipError_t DC_CAT(downconv_launch_plan_, DC_PLAN_ID)(DcArgs &a, hipStream_t stre
     using P = DcPlanT<DC_PLAN_KINDS>;
     const int lds = dc_layout_of(P::KIND, P::NS).slots * 8 + 64;
     // per launch: the attribute belongs to the current device, and a process may drive several
+    if (a.nb_mask) {                                    // the blanker's mask applied in the kernel's own loads
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<P, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((downconv_kernel<P, true>), dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
+        return hipGetLastError();
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<P>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -22,6 +22,11 @@ struct NbArgs {
     const float *in;  long in_stride;   // complex fp32 [channels][in_stride]; unused when wire.pk is set
     WireIn wire;                        // optional: the call's samples as datagrams (wire_format.hpp)
     float *out;       long out_stride;  // complex fp32 [channels][out_stride]; may alias `in` only if hist is kept
+    unsigned *mask;   long mask_stride; // MASK MODE (out == nullptr): instead of the blanked, delayed samples the kernel
+                                        // leaves one bit per sample -- bit i & 31 of word i >> 5 of row [channels]
+                                        // [mask_stride] set = sample i of the call is blanked -- and the consumer (the
+                                        // down-converter) takes x[i - delay_n - 1] itself and zeroes it under the mask:
+                                        // no 8-byte write and re-read per sample, no third input stream here
     const float *hist; float *hist_next;    // [channels][NB_HIST] complex: the last NB_HIST inputs, ping-pong
     int channels, n;
     int nseg, seg_len;                  // each channel's call is cut into nseg segments of seg_len samples (a

@@ -63,6 +63,9 @@ __device__ __forceinline__ int wave_incl_scan_max(int v, int)
 // the value of the lane in front (lane 0: NB_NEVER)
 __device__ __forceinline__ int wave_prev_lane(int v) { return __builtin_amdgcn_update_dpp(NB_NEVER, v, 0x138, 0xf, 0xf, false); }
 
+// MASK: the kernel's mask mode as an instantiation of its own (no third input stream, no sample output: fewer
+// registers, more waves)
+template <bool MASK>
 __global__ __launch_bounds__(NB_T)
 void noiseblank_kernel(NbArgs a)
 {
@@ -72,6 +75,8 @@ void noiseblank_kernel(NbArgs a)
     const NbChan C = a.chan[ch];                        // state at the start of the call (the last segment writes chan_next)
     const f2 *in = reinterpret_cast<const f2 *>(a.in) + (long)ch * a.in_stride;
     f2 *out = reinterpret_cast<f2 *>(a.out) + (long)ch * a.out_stride;
+    constexpr bool mask_mode = MASK;
+    unsigned *mrow = mask_mode ? a.mask + (long)ch * a.mask_stride : nullptr;
     const f2 *hist = reinterpret_cast<const f2 *>(a.hist) + (long)ch * NB_HIST;
     f2 *hist_next = reinterpret_cast<f2 *>(a.hist_next) + (long)ch * NB_HIST;
     const int n = a.n;
@@ -130,7 +135,7 @@ void noiseblank_kernel(NbArgs a)
                 pair_words(i0, pw); pair_words(i0 + 2u, pw + 3);
                 const unsigned eo = (i0 - (unsigned)M1) & ~1u, ed = (i0 - (unsigned)D1) & ~1u;
                 pair_words(eo, pw + 6); pair_words(eo + 2u, pw + 9); pair_words(eo + 4u, pw + 12);
-                pair_words(ed, pw + 15); pair_words(ed + 2u, pw + 18); pair_words(ed + 4u, pw + 21);
+                if (!mask_mode) { pair_words(ed, pw + 15); pair_words(ed + 2u, pw + 18); pair_words(ed + 4u, pw + 21); }
                 praw = true;
                 return;
             }
@@ -148,13 +153,14 @@ void noiseblank_kernel(NbArgs a)
                         put(slot, k, f2{v.x, v.y}); put(slot, k + 1, f2{v.z, v.w});
                     }
                 };
-                ld(p, 0); ld(p - M1, 1); ld(p - D1, 2);
+                ld(p, 0); ld(p - M1, 1);
+                if (!mask_mode) ld(p - D1, 2);
                 return;
             }
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 const long i = b0 + (long)t * NB_PER + k;
-                if (i < seg_b) { put(0, k, IN(i)); put(1, k, X(i - M1)); put(2, k, X(i - D1)); }
+                if (i < seg_b) { put(0, k, IN(i)); put(1, k, X(i - M1)); if (!mask_mode) put(2, k, X(i - D1)); }
             }
         };
         // the prefetched tile as samples: new, leaving, delayed
@@ -170,13 +176,14 @@ void noiseblank_kernel(NbArgs a)
                     if (odd) { pair(w, skip, dst[0]); pair(w + 3, dst[1], dst[2]); pair(w + 6, dst[3], skip); }
                     else { pair(w, dst[0], dst[1]); pair(w + 3, dst[2], dst[3]); }
                 };
-                four(pw + 6, M1 & 1, xo); four(pw + 15, D1 & 1, xdl);
+                four(pw + 6, M1 & 1, xo);
+                if (!mask_mode) four(pw + 15, D1 & 1, xdl);
             } else {
 #pragma unroll
                 for (int k = 0; k < NB_PER; k++) {
                     x[k] = f2{__uint_as_float(pw[2 * k]), __uint_as_float(pw[2 * k + 1])};
                     xo[k] = f2{__uint_as_float(pw[2 * NB_PER + 2 * k]), __uint_as_float(pw[2 * NB_PER + 2 * k + 1])};
-                    xdl[k] = f2{__uint_as_float(pw[4 * NB_PER + 2 * k]), __uint_as_float(pw[4 * NB_PER + 2 * k + 1])};
+                    if (!mask_mode) xdl[k] = f2{__uint_as_float(pw[4 * NB_PER + 2 * k]), __uint_as_float(pw[4 * NB_PER + 2 * k + 1])};
                 }
             }
         };
@@ -228,6 +235,21 @@ void noiseblank_kernel(NbArgs a)
             if (upto > before) before = upto;
             int tile_last = NB_NEVER;
             for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
+            if (mask_mode) {
+                // a thread's four blank flags are a nibble; eight neighbouring lanes make a word of the mask row (tiles
+                // start at multiples of the tile length, so words never straddle tiles; a warm-up tile is skipped whole)
+                unsigned nib = 0;
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) {
+                    const int r = t * NB_PER + k;
+                    const int l = lt[k] > before ? lt[k] : before;
+                    if (r < nvalid && r - l < W) nib |= 1u << k;
+                }
+                unsigned wv = nib << (4 * (lane & 7));
+                wv |= (unsigned)__shfl_xor((int)wv, 1); wv |= (unsigned)__shfl_xor((int)wv, 2); wv |= (unsigned)__shfl_xor((int)wv, 4);
+                static_assert(NB_PER == 4, "eight lanes x four samples = one 32-bit word of the mask");
+                if ((lane & 7) == 0 && nskip == 0 && t * NB_PER < nvalid) mrow[(base + (long)t * NB_PER) >> 5] = wv;
+            } else {
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 const int r = t * NB_PER + k;
@@ -235,6 +257,7 @@ void noiseblank_kernel(NbArgs a)
                     const int l = lt[k] > before ? lt[k] : before;
                     out[base + r] = (r - l < W) ? f2{0.f, 0.f} : xd[k];
                 }
+            }
             }
             S0 += total;
             if (tile_last > NB_NEVER) last = (long long)base + tile_last;
@@ -251,7 +274,9 @@ void noiseblank_kernel(NbArgs a)
     } else {
         if (t == 0 && last_seg) a.chan_next[ch] = C;
     }
-    if (!C.on && (pk || a.out != a.in)) {
+    if (!C.on && mask_mode)                                 // off: nothing is blanked (and the consumer applies no delay)
+        for (long wv = (seg_a >> 5) + t; wv < ((seg_b + 31) >> 5); wv += NB_T) mrow[wv] = 0u;
+    if (!C.on && !mask_mode && (pk || a.out != a.in)) {
         for (long i = seg_a + t; i < seg_b; i += NB_T) out[i] = IN(i);  // off: the data passes through (:125-129)
     }
     // the last NB_HIST inputs of [history | this call] are the next call's history
@@ -261,7 +286,8 @@ void noiseblank_kernel(NbArgs a)
 
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(noiseblank_kernel, dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
+    if (a.out == nullptr) hipLaunchKernelGGL(noiseblank_kernel<true>, dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
+    else hipLaunchKernelGGL(noiseblank_kernel<false>, dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
     return hipGetLastError();
 }
 
