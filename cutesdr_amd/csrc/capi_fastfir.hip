@@ -29,7 +29,7 @@ struct csdr_fastfir_batch {
     int hist_cur;                     // which half holds the previous call's tail
     int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
     int variant;                      // 0: generic kernel (every size); 2: pipelined build (N = 16384, fastfir2_kernels.hip);
-                                      // 3: 128 threads x 16 points (N = 2048, fastfir16_kernels.hip)
+                                      // 3: 128 threads x 16 points (N = 2048, fastfir16_kernels.hip); 4: 256 x 16 (N = 4096, same file)
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
@@ -55,6 +55,10 @@ static void build_perm(csdr_fastfir_batch *b)
     if (b->n == 2048) {
         b->perm2.resize(b->n);
         for (int i = 0; i < b->n; i++) b->perm2[i] = fastfir16_bin_of(i);
+    }
+    if (b->n == 4096) {
+        b->perm2.resize(b->n);
+        for (int i = 0; i < b->n; i++) b->perm2[i] = fastfir4k_bin_of(i);
     }
 }
 
@@ -98,7 +102,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
         // N = 16384 runs the software-pipelined build; CSDR_FASTFIR_VARIANT=0
         // forces the generic kernel (diagnostics; launches it cannot take fall back to the generic one anyway)
         const char *v = getenv("CSDR_FASTFIR_VARIANT");
-        b->variant = (v && atoi(v) == 0) ? 0 : (fft_size == 16384 ? 2 : (fft_size == 2048 ? 3 : 0));
+        b->variant = (v && atoi(v) == 0) ? 0 : (fft_size == 16384 ? 2 : (fft_size == 2048 ? 3 : (fft_size == 4096 ? 4 : 0)));
     }
     b->d_h = b->d_h2 = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
@@ -115,7 +119,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
             tw2[2 * (k * 32 + i)] = (float)std::cos(a); tw2[2 * (k * 32 + i) + 1] = (float)std::sin(a);
         }
     bool ok = hipMalloc((void **)&b->d_h, hbytes) == hipSuccess &&
-              ((fft_size != 16384 && fft_size != 2048) || (hipMalloc((void **)&b->d_h2, hbytes) == hipSuccess && hipMemset(b->d_h2, 0, hbytes) == hipSuccess)) &&
+              ((fft_size != 16384 && fft_size != 2048 && fft_size != 4096) || (hipMalloc((void **)&b->d_h2, hbytes) == hipSuccess && hipMemset(b->d_h2, 0, hbytes) == hipSuccess)) &&
               hipMalloc((void **)&b->d_hist, histbytes) == hipSuccess &&
               hipMalloc((void **)&b->d_tw1, 8192) == hipSuccess &&
               hipMalloc((void **)&b->d_tw2, 8192) == hipSuccess &&
@@ -244,7 +248,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
         // whose workgroups fill whole rounds of the resident slots best (CUs of the device x workgroups per CU
         // at this size: the LDS block is N*8.5 bytes), fewest runs on a tie -- longer runs re-read
         // less overlap.  C3 (256 channels, N=16384): one run of 64 blocks per channel.
-        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : (b->variant == 3 ? 6 : 8)));
+        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? (b->variant == 4 ? 3 : 4) : (b->variant == 3 ? 6 : 8)));
         const long slots = (long)b->cus * per_cu;
         long best_runs = 1; double best_eff = -1.0;
         const long max_runs = std::min<long>(a.nblocks, std::max<long>(1, 4 * ((slots + b->channels - 1) / b->channels)));
@@ -262,6 +266,9 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     if (b->variant == 3) {
         a.h = (const v4f_h *)b->d_h2;         // its own H order
         CSDR_HIP(fastfir16_launch(a, s));
+    } else if (b->variant == 4) {
+        a.h = (const v4f_h *)b->d_h2;
+        CSDR_HIP(fastfir4k_launch(a, s));
     } else if (b->variant >= 2) {
         a.h = (const v4f_h *)b->d_h2;         // its own H order
         CSDR_HIP(fastfir2_launch(a, s));     // any block count (pairs, then a single trailing block)

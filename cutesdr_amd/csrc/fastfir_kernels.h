@@ -37,5 +37,8 @@ int fastfir2_bin_of(int t, int j, int e);
 // N = 2048 as 128 threads x 16 points (fastfir16_kernels.hip): H in its own order, slot i <-> bin fastfir16_bin_of(i)
 hipError_t fastfir16_launch(const FastFirArgs &a, hipStream_t stream);
 int fastfir16_bin_of(int slot);
+// N = 4096 as 256 threads x 16 points (the same file): slot i <-> bin fastfir4k_bin_of(i)
+hipError_t fastfir4k_launch(const FastFirArgs &a, hipStream_t stream);
+int fastfir4k_bin_of(int slot);
 
 }  // namespace csdr

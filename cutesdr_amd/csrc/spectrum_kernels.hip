@@ -343,6 +343,120 @@ void spectrum16_kernel(SpectrumArgs a)
     if (over) a.overload[ch] = 1;
 }
 
+// ---- the 2048-point display spectrum the same way (round 4): 128 threads x 16 points, N = 16 x 8 x 16 ----------------
+// spectrum_kernel<11> is ONE wave of 32 points per thread.  Here: pass A as above (samples 128 a + t), pass B over the
+// eight points b of a COLUMN PAIR per thread (thread (ka, c pair): 2 x 8 points, twiddle W_128^{c kb}), pass C the 16
+// consecutive points of row t = 8 ka + kb -> bin ka + 16 kb + 128 kc.  B -> C inside the eight threads that own ka.
+constexpr int SPEC8_LDS = (2048 + 2 * 128) * 8;
+__global__ __launch_bounds__(128)
+void spectrum8_kernel(SpectrumArgs a)
+{
+    constexpr int N = 2048, T = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+    const int t = threadIdx.x, ch = blockIdx.x / a.nparts, part = blockIdx.x % a.nparts;
+    const int f0 = (int)((long)a.nframes * part / a.nparts), f1 = (int)((long)a.nframes * (part + 1) / a.nparts);
+    const v2f *tw1 = reinterpret_cast<const v2f *>(a.tw1);           // W_N^n, n < 1024
+    const int cp = t & 7;                                             // pass B: columns 2 cp, 2 cp + 1 of ka = t >> 3
+    const v2f wA = tw1[t], wB0 = tw1[16 * (2 * cp)], wB1 = tw1[16 * (2 * cp + 1)];   // W_N^t; W_128^c = W_N^{16 c}
+    const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
+    float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
+    int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    total += f0;                                              // counters at this group's first frame
+    ave_count = ave_count + f0 < a.ave_size ? ave_count + f0 : (ave_count > a.ave_size ? ave_count : a.ave_size);
+    int over = 0;
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int kbin = (tt >> 3) + 16 * (tt & 7);               // this thread's bins: kbin + 128 kc
+    float sm[16], wn[16];
+    static_for<0, 16>([&](auto Rr) {
+        constexpr int r = Rr.value;
+        sm[r] = a.nparts == 1 ? sum[((kbin + 128 * r) + N / 2) & (N - 1)] : 0.f;   // display order, fft.cpp:564-589
+        wn[r] = a.win[128 * r + t];
+    });
+    v2f pwA[16];
+    twiddle_powers<16>(wA, pwA);
+    v2f nxt[16];
+    auto fetch = [&](int f) {
+        const v2f *src = in + (long)f * N + t;
+#pragma unroll
+        for (int q = 0; q < 16; q++) nxt[q] = src[128 * q];
+    };
+    if (f0 < f1) fetch(f0);
+    for (int f = f0; f < f1; f++) {
+        v2f x[16];
+        static_for<0, 16>([&](auto Q) {
+            constexpr int q = Q.value;
+            const v2f s_ = nxt[q];
+            if (s_.x > 32000.0f) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
+            x[bitrev<16>(q)] = v2f{wn[q] * s_.y, wn[q] * s_.x};    // I/Q swapped, fft.cpp:280-281
+        });
+        if (f + 1 < f1) fetch(f + 1);
+        const float prev_count = (float)ave_count;
+        total++;                                                  // CpxFFT counters, fft.cpp:515-517
+        if (ave_count < a.ave_size) ave_count++;
+        // ---- pass A
+        dft_dit<16, +1>(x);
+        static_for<1, 16>([&](auto K) { x[K.value] = cmul(x[K.value], pwA[K.value]); });
+        __syncthreads();                       // the previous frame's pass C has read its rows
+        static_for<0, 16>([&](auto K) { lds[pad16(128 * K.value + t)] = x[K.value]; });
+        __syncthreads();
+        // ---- pass B: (ka, column pair) = (t >> 3, t & 7): point (b, c) at lds[18 (8 ka + b) + c]
+        {
+            v2f *cell = lds + 18 * (8 * (t >> 3)) + 2 * cp;
+            v2f y0[8], y1[8];
+            static_for<0, 8>([&](auto B) {
+                const v4f v = *reinterpret_cast<const v4f *>(cell + 18 * B.value);
+                y0[bitrev<8>(B.value)] = v2f{v.x, v.y}; y1[bitrev<8>(B.value)] = v2f{v.z, v.w};
+            });
+            dft_dit<8, +1>(y0);
+            dft_dit<8, +1>(y1);
+            v2f p0[8], p1[8];
+            twiddle_powers<8>(opaque(wB0), p0);
+            twiddle_powers<8>(opaque(wB1), p1);
+            static_for<0, 8>([&](auto K) {
+                constexpr int k = K.value;
+                if constexpr (k != 0) { y0[k] = cmul(y0[k], p0[k]); y1[k] = cmul(y1[k], p1[k]); }
+                *reinterpret_cast<v4f *>(cell + 18 * k) = v4f{y0[k].x, y0[k].y, y1[k].x, y1[k].y};
+            });
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- pass C: the 16 consecutive points of row t
+        {
+            const v2f *row = lds + 18 * t;
+            static_for<0, 8>([&](auto J) {
+                const v4f v = *reinterpret_cast<const v4f *>(row + 2 * J.value);
+                x[bitrev<16>(2 * J.value)] = v2f{v.x, v.y};
+                x[bitrev<16>(2 * J.value + 1)] = v2f{v.z, v.w};
+            });
+            dft_dit<16, +1>(x);
+        }
+        const float inv_prev = 1.0f / prev_count;
+        static_for<0, 16>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const float p = x[r].x * x[r].x + x[r].y * x[r].y;
+            if (total <= a.ave_size) sm[r] = sm[r] + p;
+            else sm[r] = sm[r] - sm[r] * inv_prev + p;            // minus the previous mean (fft.cpp:570-574)
+        });
+    }
+    if (a.nparts > 1) {
+        float *dst = a.part + ((long)ch * a.nparts + part) * N;
+        static_for<0, 16>([&](auto Rr) { dst[((kbin + 128 * Rr.value) + N / 2) & (N - 1)] = sm[Rr.value]; });
+    } else if (a.nframes > 0) {
+        static_for<0, 16>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const int j = ((kbin + 128 * r) + N / 2) & (N - 1);
+            const float m = sm[r] / (float)ave_count;
+            sum[j] = sm[r]; pwr[j] = m;
+            ave[j] = (float)((double)log10f(m + a.kc) + a.kb);
+        });
+    }
+    if (t == 0 && a.nparts == 1) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }
+    if (over) a.overload[ch] = 1;
+}
+
 // plain transform: out[k] = sum_n in[n] e^{sign j 2 pi n k / N}; sign=-1 via conjugation
 template <int LOG2N>
 __global__ __launch_bounds__(SpecCfg<LOG2N>::T)
@@ -430,6 +544,8 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     static const bool wide = !(getenv("CSDR_SPEC16") && atoi(getenv("CSDR_SPEC16")) == 0);
     if (LOG2N == 12 && wide)
         hipLaunchKernelGGL(spectrum16_kernel, dim3(a.channels * a.nparts), dim3(256), SPEC16_LDS, s, a);
+    else if (LOG2N == 11 && wide)
+        hipLaunchKernelGGL(spectrum8_kernel, dim3(a.channels * a.nparts), dim3(128), SPEC8_LDS, s, a);
     else
         hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
     if (a.nparts > 1) {
