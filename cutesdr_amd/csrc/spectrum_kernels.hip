@@ -457,6 +457,148 @@ void spectrum8_kernel(SpectrumArgs a)
     if (over) a.overload[ch] = 1;
 }
 
+// ---- the 8192-point display spectrum with sixteen points per thread (round 4): 512 threads, N = 16 x 32 x 16 -------------
+// spectrum_kernel<13> is 256 threads x 32 points at 300 registers (2.7 TB/s).  The middle pass has 32 points per column,
+// two threads' worth: the column (ka, c) is split by the PARITY of b over a pair of neighbouring lanes (h = t & 1) --
+// each does a 16-point DIT over its b = 2 j + h, the odd one applies W_32^{kj}, and the radix-2 butterfly that joins the
+// halves takes the partner's sixteen values over the DPP quad permute (1,0,3,2): no LDS, no barrier.
+//   n = 512 a + 16 b + c     k = ka + 16 kb + 512 kc     kb = kj + 16 h        LDS cell of (ka, x, c): 18 (32 ka + x) + c
+//   A  thread t           : samples 512 a + t, DFT over a, twiddle W_N^{t ka}
+//   B  thread (ka, c, h)  : DFT over b as above, twiddle W_512^{c kb}, back to rows kb of the same columns
+//   C  thread t = 32 ka + kb : its 16 consecutive points, DFT over c                   -> bin ka + 16 kb + 512 kc
+// B -> C inside the half-wave that owns ka.  One workgroup per CU would fit twice (74 KB of LDS); registers allow one.
+constexpr int SPEC32_LDS = (8192 + 2 * 512) * 8;
+__device__ __forceinline__ v2f pair_swap(v2f v)           // the value of lane t ^ 1
+{
+    return v2f{__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0xB1, 0xf, 0xf, false)),
+               __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xf, 0xf, false))};
+}
+__global__ __launch_bounds__(512)
+void spectrum32_kernel(SpectrumArgs a)
+{
+    constexpr int N = 8192, T = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+    const int t = threadIdx.x, ch = blockIdx.x / a.nparts, part = blockIdx.x % a.nparts;
+    const int f0 = (int)((long)a.nframes * part / a.nparts), f1 = (int)((long)a.nframes * (part + 1) / a.nparts);
+    const v2f *tw1 = reinterpret_cast<const v2f *>(a.tw1);           // W_N^n, n < 1024
+    const int hB = t & 1, cB = (t >> 1) & 15, kaB = t >> 5;          // pass B: (ka, c, h)
+    const v2f wA = tw1[t];                                            // W_N^t
+    const v2f wB = tw1[16 * cB];                                      // W_512^c = W_N^{16 c}
+    v2f wH;                                                           // W_512^{16 c h} = W_32^{c h} = W_N^{256 c h}: quadrant of W_N
+    {
+        const int m = 256 * cB * hB;
+        v2f v = tw1[m & 1023];
+        const int q = (m >> 10) & 3;
+        if (q == 1) v = v2f{-v.y, v.x}; else if (q == 2) v = -v; else if (q == 3) v = v2f{v.y, -v.x};
+        wH = v;
+    }
+    const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
+    float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
+    int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
+    total += f0;                                              // counters at this group's first frame
+    ave_count = ave_count + f0 < a.ave_size ? ave_count + f0 : (ave_count > a.ave_size ? ave_count : a.ave_size);
+    int over = 0;
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int kbin = (tt >> 5) + 16 * (tt & 31);              // pass C row t = 32 ka + kb: bins kbin + 512 kc
+    float sm[16], wn[16];
+    static_for<0, 16>([&](auto Rr) {
+        constexpr int r = Rr.value;
+        sm[r] = a.nparts == 1 ? sum[((kbin + 512 * r) + N / 2) & (N - 1)] : 0.f;   // display order, fft.cpp:564-589
+        wn[r] = a.win[512 * r + t];
+    });
+    v2f nxt[16];
+    auto fetch = [&](int f) {
+        const v2f *src = in + (long)f * N + t;
+#pragma unroll
+        for (int q = 0; q < 16; q++) nxt[q] = src[512 * q];
+    };
+    if (f0 < f1) fetch(f0);
+    for (int f = f0; f < f1; f++) {
+        v2f x[16];
+        static_for<0, 16>([&](auto Q) {
+            constexpr int q = Q.value;
+            const v2f s_ = nxt[q];
+            if (s_.x > 32000.0f) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
+            x[bitrev<16>(q)] = v2f{wn[q] * s_.y, wn[q] * s_.x};    // I/Q swapped, fft.cpp:280-281
+        });
+        if (f + 1 < f1) fetch(f + 1);
+        const float prev_count = (float)ave_count;
+        total++;                                                  // CpxFFT counters, fft.cpp:515-517
+        if (ave_count < a.ave_size) ave_count++;
+        // ---- pass A
+        dft_dit<16, +1>(x);
+        {
+            v2f pw[16];
+            twiddle_powers<16>(opaque(wA), pw);
+            static_for<1, 16>([&](auto K) { x[K.value] = cmul(x[K.value], pw[K.value]); });
+        }
+        __syncthreads();                       // the previous frame's pass C has read its rows
+        static_for<0, 16>([&](auto K) { lds[pad16(512 * K.value + t)] = x[K.value]; });
+        __syncthreads();
+        // ---- pass B: column (ka, c), the half b = 2 j + h
+        {
+            v2f *col = lds + 18 * (32 * kaB + hB) + cB;                          // point b = 2 j + h at col[36 j]
+            static_for<0, 16>([&](auto J) { x[bitrev<16>(J.value)] = lds_ld8(col + 36 * J.value); });
+            dft_dit<16, +1>(x);                                                   // Y_h[kj]
+            // the odd half times W_32^{kj} (constants), then the butterfly with the partner lane's half
+            static_for<0, 16>([&](auto K) {
+                constexpr int k = K.value;
+                const v2f w32 = v2f{(float)__builtin_cos(6.283185307179586476925286766559 * k / 32.0),
+                                    (float)__builtin_sin(6.283185307179586476925286766559 * k / 32.0)};
+                const v2f mine = hB ? cmul(x[k], w32) : x[k];
+                const v2f other = pair_swap(mine);
+                x[k] = hB ? other - mine : mine + other;          // h = 0: Y0 + w Y1 -> kb = kj;  h = 1: Y0 - w Y1 -> kb = kj + 16
+            });
+            v2f pw[16];
+            twiddle_powers<16>(opaque(wB), pw);                   // W_512^{c kj}
+            static_for<0, 16>([&](auto K) {
+                constexpr int k = K.value;
+                v2f v = x[k];
+                if constexpr (k != 0) v = cmul(v, pw[k]);
+                v = hB ? cmul(v, wH) : v;                         // times W_512^{16 c h}
+                lds_st8(lds + 18 * (32 * kaB + k + 16 * hB) + cB, v);
+            });
+        }
+        // B -> C stays inside the thirty-two threads that own ka
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- pass C: the 16 consecutive points of row t
+        {
+            const v2f *row = lds + 18 * t;
+            static_for<0, 8>([&](auto J) {
+                const v4f v = *reinterpret_cast<const v4f *>(row + 2 * J.value);
+                x[bitrev<16>(2 * J.value)] = v2f{v.x, v.y};
+                x[bitrev<16>(2 * J.value + 1)] = v2f{v.z, v.w};
+            });
+            dft_dit<16, +1>(x);
+        }
+        const float inv_prev = 1.0f / prev_count;
+        static_for<0, 16>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const float p = x[r].x * x[r].x + x[r].y * x[r].y;
+            if (total <= a.ave_size) sm[r] = sm[r] + p;
+            else sm[r] = sm[r] - sm[r] * inv_prev + p;            // minus the previous mean (fft.cpp:570-574)
+        });
+    }
+    if (a.nparts > 1) {
+        float *dst = a.part + ((long)ch * a.nparts + part) * N;
+        static_for<0, 16>([&](auto Rr) { dst[((kbin + 512 * Rr.value) + N / 2) & (N - 1)] = sm[Rr.value]; });
+    } else if (a.nframes > 0) {
+        static_for<0, 16>([&](auto Rr) {
+            constexpr int r = Rr.value;
+            const int j = ((kbin + 512 * r) + N / 2) & (N - 1);
+            const float m = sm[r] / (float)ave_count;
+            sum[j] = sm[r]; pwr[j] = m;
+            ave[j] = (float)((double)log10f(m + a.kc) + a.kb);
+        });
+    }
+    if (t == 0 && a.nparts == 1) { a.counters[2 * ch] = ave_count; a.counters[2 * ch + 1] = total; }
+    if (over) a.overload[ch] = 1;
+}
+
 // plain transform: out[k] = sum_n in[n] e^{sign j 2 pi n k / N}; sign=-1 via conjugation
 template <int LOG2N>
 __global__ __launch_bounds__(SpecCfg<LOG2N>::T)
@@ -546,7 +688,11 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
         hipLaunchKernelGGL(spectrum16_kernel, dim3(a.channels * a.nparts), dim3(256), SPEC16_LDS, s, a);
     else if (LOG2N == 11 && wide)
         hipLaunchKernelGGL(spectrum8_kernel, dim3(a.channels * a.nparts), dim3(128), SPEC8_LDS, s, a);
-    else
+    else if (LOG2N == 13 && wide) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spectrum32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SPEC32_LDS);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(spectrum32_kernel, dim3(a.channels * a.nparts), dim3(512), SPEC32_LDS, s, a);
+    } else
         hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
     if (a.nparts > 1) {
         hipLaunchKernelGGL(spectrum_alpha_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
