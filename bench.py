@@ -785,6 +785,32 @@ class C3Workload:
         return {"channels": chans, "samples_each": self.T, "max_err_over_max_abs_x": worst, "tolerance": 2e-5,
                 "ok": bool(worst <= 2e-5)}
 
+    def other_sizes(self, ctx, steps=60):
+        """The same launch at CFastFIR's other sizes (dsp/fastfir.cpp:55-56 as a parameter: 2048 is the reference's own,
+        what every receiver of the chain runs), 16 B per sample as the headline, and the single-pass display spectrum
+        sizes on the same buffer (8 B per bin read)."""
+        torch = self.torch
+        out = {"fastfir": {}, "spectrum": {}}
+        n = self.C * self.T
+        for size in (2048, 4096, 8192):
+            fir = self.ca.FastFirBatch(self.C, size, device=ctx.local)
+            fir.setup(-5000, 5000, 0, FS)
+            ms = gpu_ms(torch, lambda: fir.process_ptr(self.x.data_ptr(), self.T, self.T, self.y.data_ptr(), self.T, self.stream, 0), 20, steps)
+            out["fastfir"][str(size)] = {"ms": round(ms, 4), "GBps_at_16B_per_sample": round(16.0 * n / ms / 1e6, 1),
+                                         "frac": round(16.0 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del fir
+        for size in (2048, 4096, 8192, 16384):
+            fb = self.ca.FftBatch(self.C, device=ctx.local)
+            fb.set_params(size, False, 0.0, C4_FS); fb.set_ave(1)
+            ms = gpu_ms(torch, lambda: fb.put_display_ptr(self.x.data_ptr(), self.T, self.T // size, self.stream), 5, 20)
+            out["spectrum"][str(size)] = {"ms": round(ms, 4), "GBps_at_8B_per_bin": round(8.0 * n / ms / 1e6, 1),
+                                          "frac": round(8.0 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del fb
+        out["note"] = ("%d channels x 2^%d samples per launch; fastfir 16384 is the headline; kernels: 2048 fastfir16_kernel, 4096 "
+                       "fastfir4k_kernel (round 4), 8192 generic; spectrum 2048 / 4096 / 8192 at sixteen points per thread (2048 and "
+                       "8192: round 4), 16384 generic" % (self.C, self.T.bit_length() - 1))
+        return out
+
     def distinct_filters(self, ctx, steps=100):
         """Same launch with one H per channel (pass-bands staggered by 10 Hz): +16 B/sample of filter reads."""
         torch = self.torch
@@ -1066,6 +1092,8 @@ def run_rank(args):
             extra["parity_checked"] = w.parity_check()
         if ctx.rank == 0 and not args.no_secondary:
             extra["distinct_filters"] = w.distinct_filters(ctx)
+            if ctx.world == 1:
+                extra["fastfir_sizes"] = w.other_sizes(ctx)
         chans, samples = w.C, w.T
         del w
         torch.cuda.empty_cache()
