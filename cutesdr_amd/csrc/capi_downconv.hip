@@ -3,6 +3,7 @@
 #include "downconv_kernels.h"
 #include "dc_host.hpp"
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 using namespace csdr;
@@ -276,9 +277,13 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         // segments: enough workgroups to fill the chip, each at least 8 tiles and 8 warm-ups long
         long min_seg = (long)DC_TILE_SAMPLES * 8;
         if (min_seg < (long)p.W * 8) min_seg = (long)p.W * 8;
-        // at most 8192 workgroups = two full rounds of the chip's 4096 one-wave slots (256 CUs x 16): a few more
-        // would start a third, nearly empty round (86 channels x 96 segments = 8256 took 1.8x the time of 85 x 96)
-        long nseg = 8192 / a.nchan;
+        // ONE full round of the chip's 4096 one-wave slots (256 CUs x 16) -- round 4: every segment pays its warm-up
+        // (W samples run through the cascade for nothing: 1024 for the FM plan, 2560 for AM), and with two rounds (8192,
+        // rounds 1-3) an 86-receiver group's segments were 43 tiles long: 5-12 % of warm-up.  One round: per-plan launches
+        // -3 / -4 / -5 % (FM / SSB / AM, 86 receivers x 2^21), the strict chain -1.6 %, pipelined +-0.  (A few workgroups more
+        // than a whole number of rounds start a nearly empty one: 86 x 96 = 8256 took 1.8x the time of 85 x 96.)
+        static const long dc_wgs = getenv("CSDR_DC_WGS") ? atol(getenv("CSDR_DC_WGS")) : 4096;
+        long nseg = dc_wgs / a.nchan;
         if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
         if (nseg < 1) nseg = 1;
         long seg_len = (n_per_channel + nseg - 1) / nseg;
