@@ -176,13 +176,19 @@ void spectrum_kernel(SpectrumArgs a)
     });
     // the samples of frame f+1 are fetched while frame f goes through its transform (one workgroup has only two
     // waves and three share a CU: nothing else would hide the HBM latency of a frame's 32 loads per thread)
-    v2f nxt[32];
+    // (not at N = 16384: a workgroup is 512 threads there, two waves per SIMD and so at most 256 registers per wave;
+    // with the prefetched frame on top of the points and the running sums the kernel spilled 80 of them -- 324 bytes
+    // of scratch per lane -- and ran at 1.5 TB/s; the second wave of the SIMD hides the loads instead: round 4)
+    constexpr bool PREFETCH = LOG2N < 14;
+    v2f nxt[PREFETCH ? 32 : 1];
     auto fetch = [&](int f) {
-        const v2f *src = in + (long)f * N;
+        if constexpr (PREFETCH) {
+            const v2f *src = in + (long)f * N;
 #pragma unroll
-        for (int e = 0; e < G; e++)
+            for (int e = 0; e < G; e++)
 #pragma unroll
-            for (int n1 = 0; n1 < R0; n1++) nxt[e * R0 + n1] = src[1024 * n1 + Cfg::col(t, e)];
+                for (int n1 = 0; n1 < R0; n1++) nxt[e * R0 + n1] = src[1024 * n1 + Cfg::col(t, e)];
+        }
     };
     if (f0 < f1) fetch(f0);
     for (int f = f0; f < f1; f++) {
@@ -192,7 +198,8 @@ void spectrum_kernel(SpectrumArgs a)
 #pragma unroll
             for (int n1 = 0; n1 < R0; n1++) {
                 const int i = 1024 * n1 + Cfg::col(t, e);
-                const v2f s = nxt[e * R0 + n1];
+                v2f s;
+                if constexpr (PREFETCH) s = nxt[e * R0 + n1]; else s = in[(long)f * N + i];
                 const float w = a.win[i];
                 if (s.x > 32000.0f) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
                 x[e * R0 + n1] = v2f{w * s.y, w * s.x};           // I/Q swapped, fft.cpp:280-281
@@ -202,11 +209,12 @@ void spectrum_kernel(SpectrumArgs a)
         total++;                                                  // CpxFFT counters, fft.cpp:515-517
         if (ave_count < a.ave_size) ave_count++;
         fft_fwd_passes<LOG2N>(x, lds, tw2, w1);        // (its own barrier keeps it behind the previous frame's pass C)
+        const float inv_prev = 1.0f / prev_count;      // (one division per frame instead of one per bin, as in spectrum16_kernel)
         static_for<0, 32>([&](auto Rr) {
             constexpr int r = Rr.value;
             const float p = x[r].x * x[r].x + x[r].y * x[r].y;
             if (total <= a.ave_size) sm[r] = sm[r] + p;
-            else sm[r] = sm[r] - sm[r] / prev_count + p;          // minus the previous mean (fft.cpp:570-574)
+            else sm[r] = sm[r] - sm[r] * inv_prev + p;            // minus the previous mean (fft.cpp:570-574)
         });
     }
     if (a.nparts > 1) {
