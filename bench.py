@@ -226,7 +226,7 @@ def profiled_traffic():
     return None
 
 
-K2_ALONE_GRID = 8192 * 64          # 256 receivers x 32 segments, one wave each (capi_downconv.hip's segment rule)
+K2_ALONE_GRID = 4096 * 64          # 256 receivers x 16 segments, one wave each (capi_downconv.hip's segment rule: one round)
 
 
 def live_traffic(timeout_s=240):
