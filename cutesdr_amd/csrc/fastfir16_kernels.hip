@@ -21,7 +21,7 @@ namespace csdr {
 namespace {
 constexpr int F16_N = 2048, F16_T = 128, F16_L = 1024;
 constexpr int F16_LDS_DATA = 18 * 128;                   // 128 rows of 16 (+2)
-constexpr int F16_LDS_BYTES = (F16_LDS_DATA + 128) * 8;  // + the 8 x 16 twiddles of F2 / I2
+constexpr int F16_LDS_BYTES = (F16_LDS_DATA + 256) * 8;  // + the 8 x 16 twiddles of F2 / I2, [kb][c] and [c][kb]
 __device__ __forceinline__ int row18(int row, int c) { return 18 * row + c; }
 }  // namespace
 
@@ -54,6 +54,9 @@ void fastfir16_kernel(FastFirArgs a)
         v2f v = tw1[m & 1023];
         if (m & 1024) v = -v;
         twB[t] = v;
+        // ... and transposed for I3, whose lanes differ in kb: [kb][c] there is a stride of 32 banks (PMC: a quarter of
+        // this kernel's LDS cycles were bank conflicts), [c][kb] is eight neighbouring cells
+        twB[128 + 8 * (t & 15) + (t >> 4)] = v;
     }
     v2f pw[16];                                           // W_N^{t ka}: resident
     twiddle_powers<16>(tw1[t], pw);
@@ -110,8 +113,7 @@ void fastfir16_kernel(FastFirArgs a)
                     y0[r] = cmul(y0[r], v2f{w.x, w.y});
                     y1[r] = cmul(y1[r], v2f{w.z, w.w});
                 }
-                cell[18 * kb] = y0[r];
-                cell[18 * kb + 1] = y1[r];
+                *reinterpret_cast<v4f *>(cell + 18 * kb) = v4f{y0[r].x, y0[r].y, y1[r].x, y1[r].y};
             });
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -133,9 +135,11 @@ void fastfir16_kernel(FastFirArgs a)
             dft_dit<16, -1>(x);
             static_for<0, 16>([&](auto Cc) {
                 constexpr int c = Cc.value;
-                if constexpr (c != 0) x[c] = cmul_conj(x[c], twB[16 * kb3 + c]);
-                row[c] = x[c];
+                if constexpr (c != 0) x[c] = cmul_conj(x[c], twB[128 + 8 * c + kb3]);
             });
+#pragma unroll
+            for (int q = 0; q < 8; q++)                   // two cells per store, like the loads: no two rows of a pass in one bank
+                *reinterpret_cast<v4f *>(row + 2 * q) = v4f{x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -152,7 +156,7 @@ void fastfir16_kernel(FastFirArgs a)
             dft_dit<8, -1>(y0);
             dft_dit<8, -1>(y1);
 #pragma unroll
-            for (int q = 0; q < 8; q++) { cell[18 * q] = y0[q]; cell[18 * q + 1] = y1[q]; }
+            for (int q = 0; q < 8; q++) *reinterpret_cast<v4f *>(cell + 18 * q) = v4f{y0[q].x, y0[q].y, y1[q].x, y1[q].y};
         }
         __syncthreads();
         // ---------------- I1: conjugate twiddle, DIT back over ka, the valid half out ----------------
@@ -192,12 +196,16 @@ int fastfir16_bin_of(int slot)
 // threads x 32 points, two waves per workgroup at 272 registers (2.2 TB/s at 256 channels x 2^19).  Same three passes as
 // above with B = 16 points in the middle one, so that F2 / I2 take ONE column of sixteen per thread (thread (ka, c))
 // instead of a column pair of eight, and the pass twiddle W_256^{c kb} needs the quadrant of W_N (N = 4096: W_N^1024 = j).
-//   n = 256 a + 16 b + c     k = ka + 16 kb + 256 kc        LDS cell of (ka, x, c): 18 (16 ka + x) + c
+//   n = 256 a + 16 b + c     k = ka + 16 kb + 256 kc        LDS cell of (ka, x, c): 304 ka + 18 x + c
 // F2 -> F3 -> I2 stay inside the wave that owns ka (four per wave); H slot kc * 256 + t3 for thread t3 = 16 ka + kb.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int F4K_N = 4096, F4K_T = 256, F4K_L = 2048;
-constexpr int F4K_LDS_DATA = 18 * 256;
+// A ka plane is 16 rows of 18 cells + 16 cells of padding: 288 cells are 576 words, a multiple of the 64 banks, and the
+// four ka of a wave in F2 / I2 (same column, same row) would meet in one bank -- with the pad a ka step is 32 banks
+// (PMC: 38 % of this kernel's LDS cycles were bank conflicts before)
+constexpr int F4K_KA = 18 * 16 + 16;
+constexpr int F4K_LDS_DATA = F4K_KA * 16;
 constexpr int F4K_LDS_BYTES = (F4K_LDS_DATA + 256) * 8;  // + the 16 x 16 twiddles of F2 / I2
 }  // namespace
 
@@ -275,12 +283,12 @@ void fastfir4k_kernel(FastFirArgs a)
             constexpr int r = Rr.value, ka = bitrev<16>(r);
             if constexpr (ka != 0) x[r] = cmul(x[r], pw[ka]);
             // (no barrier in front: these are the cells this thread itself read in I1 of the previous block)
-            lds[row18(16 * ka + (t >> 4), t & 15)] = x[r];
+            lds[F4K_KA * ka + row18(t >> 4, t & 15)] = x[r];
         });
         __syncthreads();
         // ---------------- F2: DIF over b for this column, twiddle, in place ----------------
         {
-            v2f *cell = lds + row18(16 * ka2, c2);        // (ka, b, c) at cell + 18 b
+            v2f *cell = lds + F4K_KA * ka2 + c2;          // (ka, b, c) at cell + 18 b
 #pragma unroll
             for (int q = 0; q < 16; q++) x[q] = cell[18 * q];
             dft_dif<16, +1>(x);
@@ -298,7 +306,7 @@ void fastfir4k_kernel(FastFirArgs a)
             v2f hv[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) hv[q] = H[T * q + t];        // slot kc * 256 + t (L2)
-            v2f *row = lds + 18 * t;
+            v2f *row = lds + F4K_KA * ka2 + 18 * c2;      // row (ka, kb) = (t >> 4, t & 15)
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const v4f v = *reinterpret_cast<const v4f *>(row + 2 * q);
@@ -309,16 +317,20 @@ void fastfir4k_kernel(FastFirArgs a)
             dft_dit<16, -1>(x);
             static_for<0, 16>([&](auto Cc) {
                 constexpr int c = Cc.value;
-                if constexpr (c != 0) x[c] = cmul_conj(x[c], twB[16 * c2 + c]);     // (kb of this row = t & 15)
-                row[c] = x[c];
+                // W_256^{c kb}, kb = t & 15: the table is symmetric, and read as [c][kb] the sixteen kb of a wave are
+                // sixteen neighbouring cells ([kb][c] is a stride of 32 banks: eight lanes to a bank)
+                if constexpr (c != 0) x[c] = cmul_conj(x[c], twB[16 * c + c2]);
             });
+#pragma unroll
+            for (int q = 0; q < 8; q++)                   // two cells per store, like the loads: no two rows of a pass in one bank
+                *reinterpret_cast<v4f *>(row + 2 * q) = v4f{x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---------------- I2: DIT back over kb for this column, in place ----------------
         {
-            v2f *cell = lds + row18(16 * ka2, c2);
+            v2f *cell = lds + F4K_KA * ka2 + c2;
             static_for<0, 16>([&](auto Rr) {
                 constexpr int r = Rr.value, kb = bitrev<16>(r);
                 x[r] = cell[18 * kb];
@@ -331,7 +343,7 @@ void fastfir4k_kernel(FastFirArgs a)
         // ---------------- I1: conjugate twiddle, DIT back over ka, the valid half out ----------------
         static_for<0, 16>([&](auto Rr) {
             constexpr int r = Rr.value, ka = bitrev<16>(r);
-            x[r] = lds[row18(16 * ka + (t >> 4), t & 15)];
+            x[r] = lds[F4K_KA * ka + row18(t >> 4, t & 15)];
             if constexpr (ka != 0) x[r] = cmul_conj(x[r], pw[ka]);
         });
         dft_dit<16, -1>(x);

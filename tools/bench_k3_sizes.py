@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 x = torch.randn((C, T, 2), device=dev, dtype=torch.float32) * 3276.7
 st = torch.cuda.current_stream().cuda_stream
 out = {}
-for n in (2048, 4096, 8192, 16384):
+for n in ([int(a) for a in sys.argv[1:]] or (2048, 4096, 8192, 16384)):
     fb = ca.FftBatch(C); fb.set_params(n, False, 0.0, 2e6); fb.set_ave(1)
     f = lambda: fb.put_display_ptr(x.data_ptr(), T, T // n, st)
     for _ in range(10): f()
