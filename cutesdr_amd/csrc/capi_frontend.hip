@@ -12,6 +12,7 @@ using namespace csdr;
 struct NbHost {                          // the SetupBlanker comparands (noiseproc.cpp:80-86)
     bool configured = false, on = false;
     double thresh = 0, width = 0, fs = 0;
+    int mag_n = 0;                       // as on the device (a rate-only change does not reconfigure: not derivable from fs)
 };
 
 struct csdr_noiseproc_batch {
@@ -45,7 +46,7 @@ static int nb_setup_one(csdr_noiseproc_batch *b, int c, int on, double thresh, d
     n.delay_n = n.width_n / 2;
     n.sum = 0.0;
     n.since_trig = 1LL << 40;
-    h.configured = true; h.on = on != 0; h.thresh = thresh; h.width = width; h.fs = fs;
+    h.configured = true; h.on = on != 0; h.thresh = thresh; h.width = width; h.fs = fs; h.mag_n = n.mag_n;
     CSDR_HIP(hipDeviceSynchronize());
     for (int k = 0; k < 2; k++) CSDR_HIP(hipMemcpy(b->d_chan + (size_t)k * b->channels + c, &n, sizeof(n), hipMemcpyHostToDevice));
     const size_t row = (size_t)NB_HIST * 8, half = (size_t)b->channels * row;
@@ -145,14 +146,20 @@ static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_strid
     a.hist = b->d_hist + b->cur * half; a.hist_next = b->d_hist + (b->cur ^ 1) * half;
     a.mask = d_mask; a.mask_stride = mask_stride;
     a.channels = b->channels; a.n = n_per_channel;
+    static const bool ring_env = !(getenv("CSDR_NB_RING") && atoi(getenv("CSDR_NB_RING")) == 0);
+    a.ring = d_mask && ring_env;
+    for (int c = 0; c < b->channels && a.ring; c++)
+        if (b->h[c].on && (b->h[c].mag_n + 1 < noiseblank_ring_min() || b->h[c].mag_n + 1 > noiseblank_ring_max())) a.ring = 0;
     // segments: enough workgroups to fill the chip, each at least 32 tiles long (the longest blank
     // width is 4 tiles, the moving-sum reduction at a segment start another ~10-32 tiles' worth of reads)
     // (mask mode: 74 registers, three 512-thread workgroups per CU: 3072 workgroups = four rounds measured best,
     // 3.28 ms for the C4 share's datagram-fed chain against 3.36 with 2048 and 3.49 with 4096)
+    // (mask mode with the ring: two workgroups per CU -- 64 KB of ring each -- and ONE round of them: 1.07 ms against
+    // 1.11 with two rounds, 1.18 with six)
     static const long want_env = getenv("CSDR_NB_WGS") ? atol(getenv("CSDR_NB_WGS")) : 0;
-    const long want_wgs = want_env > 0 ? want_env : (d_mask ? 3072 : 2048);
+    const long want_wgs = want_env > 0 ? want_env : (a.ring ? 512 : (d_mask ? 3072 : 2048));
     long nseg = (want_wgs + b->channels - 1) / b->channels;
-    const long tile = noiseblank_tile();
+    const long tile = noiseblank_tile(d_mask != nullptr);
     const long min_seg = 32 * tile;
     if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
     if (nseg < 1) nseg = 1;

@@ -15,6 +15,7 @@
 // unpack_kernel replaces the datagram conversion loops of CUdpThread::OnreadyRead
 // (interface/netiobase.cpp:497-503, 521-526); spurcal_kernel the running I/Q means of
 // CSdrInterface::NcoSpurCalibrate (interface/sdrinterface.cpp:829-848).
+#include <cstdlib>
 #include "frontend_kernels.h"
 
 namespace csdr {
@@ -26,11 +27,34 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
 #ifndef NB_THREADS
 #define NB_THREADS 512
 #endif
+// Samples per thread and tile: four, and EIGHT in the mask form with the ring (below).  Round 4, C4 share from 24-bit
+// datagrams, per launch: two streams x 4 per thread 1.40 ms (74 registers, three workgroups per CU; bound by the
+// fabric: 6.6 GB at 4.8 TB/s); two streams x 8: 18 % fewer vector instructions and the same 1.40 ms (123 registers, two
+// workgroups per CU); ring x 4: 1.27 ms, now bound by the vector unit (84 % busy, 305 instructions per wave and
+// 256 samples -- most of them per tile and thread: datagram addresses, the two scans, the workgroup sums, the mask
+// word); ring x 8: 1.07 ms (92 registers, 64 KB of ring, two workgroups per CU, one round of 512 workgroups).
 #ifndef NB_PER_THREAD
 #define NB_PER_THREAD 4
 #endif
-constexpr int NB_T = NB_THREADS, NB_PER = NB_PER_THREAD, NB_TILE = NB_T * NB_PER;
-int noiseblank_tile() { return NB_TILE; }
+#ifndef NB_PER_THREAD_RING
+#define NB_PER_THREAD_RING 8
+#endif
+constexpr int NB_T = NB_THREADS;
+template <bool RING> struct NbTile { static constexpr int PER = RING ? NB_PER_THREAD_RING : NB_PER_THREAD, TILE = NB_T * PER; };
+// (the host cuts segments before it knows which mask form runs: a multiple of both tiles)
+int noiseblank_tile(bool mask) { return mask && NbTile<true>::TILE > NbTile<false>::TILE ? NbTile<true>::TILE : NbTile<false>::TILE; }
+static_assert(NbTile<true>::TILE % NbTile<false>::TILE == 0, "segments are whole tiles of either form");
+// RING (mask form): the magnitudes of a workgroup's last NB_RING samples stay in LDS, so that the sample LEAVING the
+// moving-sum window -- mag_n + 1 = 10 001 samples, 60 KB of datagrams, behind the new one -- is not fetched and decoded
+// a second time.  That second stream was half of the mask form's traffic (counters: 2 x 3.23 GB at the fabric per
+// launch of the C4 share, 4.8 TB/s -- the 96 windows of an XCD's resident workgroups are 5.8 MB against 4 MB of L2,
+// so the Infinity Cache served it, not L2).  An instantiation of its own (RING), so that neither form carries the
+// other's registers.  Taken by the host when every channel with the blanker on has one tile <= mag_n + 1 <= NB_RING - one tile
+// (no barrier between a tile's ring writes and its own ring reads is needed then); else the two-stream form.
+// (Round 3 tried a ring in the three-stream fp32 kernel, where that stream was a third of less traffic, and dropped it.)
+constexpr int NB_RING = 4 * NbTile<true>::TILE;             // 16384 magnitudes: a whole number of tiles
+int noiseblank_ring_min() { return NbTile<true>::TILE; }
+int noiseblank_ring_max() { return NB_RING - NbTile<true>::TILE; }
 
 // Wave scans on the DPP network (row_shr 1, 2, 4, 8, then row_bcast 15 into rows 1, 3 and row_bcast 31 into rows
 // 2, 3; a step without a source lane reads the identity) instead of __shfl_up: a 64-bit shuffle is two
@@ -65,17 +89,22 @@ __device__ __forceinline__ int wave_prev_lane(int v) { return __builtin_amdgcn_u
 
 // MASK: the kernel's mask mode as an instantiation of its own (no third input stream, no sample output: fewer
 // registers, more waves)
-template <bool MASK>
+template <bool MASK, bool RING = false>
 __global__ __launch_bounds__(NB_T)
 void noiseblank_kernel(NbArgs a)
 {
     __shared__ double wsum[NB_T / 64];
     __shared__ int wmax[NB_T / 64];
+    extern __shared__ __attribute__((aligned(16))) float nb_ring[];    // [NB_RING] (RING)
+    static_assert(!RING || MASK, "the ring belongs to the mask form");
     const int ch = blockIdx.x / a.nseg, seg = blockIdx.x % a.nseg, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const NbChan C = a.chan[ch];                        // state at the start of the call (the last segment writes chan_next)
     const f2 *in = reinterpret_cast<const f2 *>(a.in) + (long)ch * a.in_stride;
     f2 *out = reinterpret_cast<f2 *>(a.out) + (long)ch * a.out_stride;
     constexpr bool mask_mode = MASK;
+    constexpr int NB_PER = NbTile<RING>::PER, NB_TILE = NbTile<RING>::TILE, NB_NP = NB_PER / 2;
+    static_assert(NB_PER % 2 == 0 && 240 % NB_PER == 0 && 32 % NB_PER == 0,
+                  "a thread's samples are whole sample pairs of one 24-bit datagram and a whole fraction of a mask word");
     unsigned *mrow = mask_mode ? a.mask + (long)ch * a.mask_stride : nullptr;
     const f2 *hist = reinterpret_cast<const f2 *>(a.hist) + (long)ch * NB_HIST;
     f2 *hist_next = reinterpret_cast<f2 *>(a.hist_next) + (long)ch * NB_HIST;
@@ -96,13 +125,25 @@ void noiseblank_kernel(NbArgs a)
         double S0 = C.sum;
         long long last = -C.since_trig;                    // index of the last trigger, relative to this call
         long first = 0;
+        constexpr bool ring = RING;                         // (the host has checked NB_TILE <= M1 <= NB_RING - NB_TILE)
+        auto rslot = [](long i) -> int { const int r = (int)(i % NB_RING); return r < 0 ? r + NB_RING : r; };   // (start-up paths only)
+        if (ring && seg == 0) {
+            // the window in front of the call: from the history, once per channel and call
+            for (long k = -(long)M1 + t; k < 0; k += NB_T) { const f2 v = X(k); nb_ring[rslot(k)] = fmaxf(fabsf(v.x), fabsf(v.y)); }
+            __syncthreads();
+        }
         if (seg > 0) {
             // a later segment rebuilds its start state: the moving sum at its warm-up origin is a plain
             // reduction over the mag_n+1 samples before it, and width_n samples of warm-up (outputs
             // dropped) recover the blank window that may reach into the segment
             first = seg_a - (long)((W + NB_TILE - 1) / NB_TILE) * NB_TILE;         // >= 0: seg_len >= 4 warm-ups
             double part = 0.0;
-            for (long k = first - M1 + t; k < first; k += NB_T) { const f2 v = X(k); part += (double)fmaxf(fabsf(v.x), fabsf(v.y)); }
+            for (long k = first - M1 + t; k < first; k += NB_T) {
+                const f2 v = X(k);
+                const float m = fmaxf(fabsf(v.x), fabsf(v.y));
+                part += (double)m;
+                if (ring) nb_ring[rslot(k)] = m;            // ... which is the window the first tile needs in the ring
+            }
             part = wave_incl_scan_add(part, lane);
             if (lane == 63) wsum[w] = part;
             __syncthreads();
@@ -115,13 +156,13 @@ void noiseblank_kernel(NbArgs a)
         // one tile ahead, so that they are in flight while the current tile goes through its scans
         // pw: the prefetched tile -- three streams x NB_PER samples as fp32 pairs (slot s at 2*NB_PER*s), or, for a tile
         // inside 24-bit datagrams, the raw words (new stream: 2 sample pairs = 6 words at 0; leaving and delayed stream:
-        // 3 pairs = 9 words at 6 and 15), decoded where they are consumed so that the fetch does not wait for itself
-        static_assert(NB_PER == 4, "the datagram fetch takes a thread's four samples as sample pairs");
+        // 3 pairs = 9 words at 6 and 15 -- with four samples per thread; NB_NP pairs, then twice NB_NP + 1 in general),
+        // decoded where they are consumed so that the fetch does not wait for itself
         unsigned pw[6 * NB_PER];
         bool praw = false;                                  // uniform: what the last fetch left in pw
         auto put = [&](int slot, int k, f2 v) { pw[2 * NB_PER * slot + 2 * k] = __float_as_uint(v.x); pw[2 * NB_PER * slot + 2 * k + 1] = __float_as_uint(v.y); };
         auto fetch = [&](long b0) {
-            const bool inside = b0 - M1 >= 0 && b0 - D1 >= 0 && b0 + NB_TILE <= seg_b;
+            const bool inside = (ring || (b0 - M1 >= 0 && b0 - D1 >= 0)) && b0 + NB_TILE <= seg_b;
             praw = false;
             if (pk && pkt_len == 1444 && inside) {
                 // 24-bit datagrams: a sample pair (even index) is 12 bytes at a 4-byte aligned offset and never straddles a
@@ -132,10 +173,18 @@ void noiseblank_kernel(NbArgs a)
                     const unsigned *wp = reinterpret_cast<const unsigned *>(pk + (q * 1444u + 4u + 6u * j));
                     dst[0] = wp[0]; dst[1] = wp[1]; dst[2] = wp[2];
                 };
-                pair_words(i0, pw); pair_words(i0 + 2u, pw + 3);
                 const unsigned eo = (i0 - (unsigned)M1) & ~1u, ed = (i0 - (unsigned)D1) & ~1u;
-                pair_words(eo, pw + 6); pair_words(eo + 2u, pw + 9); pair_words(eo + 4u, pw + 12);
-                if (!mask_mode) { pair_words(ed, pw + 15); pair_words(ed + 2u, pw + 18); pair_words(ed + 4u, pw + 21); }
+#pragma unroll
+                for (int p = 0; p < NB_NP; p++) pair_words(i0 + 2u * p, pw + 3 * p);
+                if (!ring) {
+#pragma unroll
+                    for (int p = 0; p < NB_NP; p++) pair_words(eo + 2u * p, pw + 3 * NB_NP + 3 * p);
+                    if (M1 & 1) pair_words(eo + 2u * NB_NP, pw + 6 * NB_NP);    // (uniform) an odd start touches one pair more
+                }
+                if (!mask_mode) {
+#pragma unroll
+                    for (int p = 0; p <= NB_NP; p++) pair_words(ed + 2u * p, pw + 6 * NB_NP + 3 + 3 * p);
+                }
                 praw = true;
                 return;
             }
@@ -153,14 +202,15 @@ void noiseblank_kernel(NbArgs a)
                         put(slot, k, f2{v.x, v.y}); put(slot, k + 1, f2{v.z, v.w});
                     }
                 };
-                ld(p, 0); ld(p - M1, 1);
+                ld(p, 0);
+                if (!ring) ld(p - M1, 1);
                 if (!mask_mode) ld(p - D1, 2);
                 return;
             }
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 const long i = b0 + (long)t * NB_PER + k;
-                if (i < seg_b) { put(0, k, IN(i)); put(1, k, X(i - M1)); if (!mask_mode) put(2, k, X(i - D1)); }
+                if (i < seg_b) { put(0, k, IN(i)); if (!ring) put(1, k, X(i - M1)); if (!mask_mode) put(2, k, X(i - D1)); }
             }
         };
         // the prefetched tile as samples: new, leaving, delayed
@@ -170,40 +220,82 @@ void noiseblank_kernel(NbArgs a)
                     const wf4 v = wire_pair_decode(wf4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), 0.f}, 1444);
                     a = f2{v.x, v.y}; b = f2{v.z, v.w};
                 };
-                pair(pw, x[0], x[1]); pair(pw + 3, x[2], x[3]);
-                auto four = [&](const unsigned *w, bool odd, f2 *dst) {   // odd is uniform: each side decodes what it needs
+#pragma unroll
+                for (int p = 0; p < NB_NP; p++) pair(pw + 3 * p, x[2 * p], x[2 * p + 1]);
+                auto many = [&](const unsigned *w, bool odd, f2 *dst) {   // odd is uniform: each side decodes what it needs
                     f2 skip;
-                    if (odd) { pair(w, skip, dst[0]); pair(w + 3, dst[1], dst[2]); pair(w + 6, dst[3], skip); }
-                    else { pair(w, dst[0], dst[1]); pair(w + 3, dst[2], dst[3]); }
+                    if (odd) {
+                        pair(w, skip, dst[0]);
+#pragma unroll
+                        for (int p = 1; p < NB_NP; p++) pair(w + 3 * p, dst[2 * p - 1], dst[2 * p]);
+                        pair(w + 3 * NB_NP, dst[NB_PER - 1], skip);
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < NB_NP; p++) pair(w + 3 * p, dst[2 * p], dst[2 * p + 1]);
+                    }
                 };
-                four(pw + 6, M1 & 1, xo);
-                if (!mask_mode) four(pw + 15, D1 & 1, xdl);
+                if (!ring) many(pw + 3 * NB_NP, M1 & 1, xo);
+                if (!mask_mode) many(pw + 6 * NB_NP + 3, D1 & 1, xdl);
             } else {
 #pragma unroll
                 for (int k = 0; k < NB_PER; k++) {
                     x[k] = f2{__uint_as_float(pw[2 * k]), __uint_as_float(pw[2 * k + 1])};
-                    xo[k] = f2{__uint_as_float(pw[2 * NB_PER + 2 * k]), __uint_as_float(pw[2 * NB_PER + 2 * k + 1])};
+                    if (!ring) xo[k] = f2{__uint_as_float(pw[2 * NB_PER + 2 * k]), __uint_as_float(pw[2 * NB_PER + 2 * k + 1])};
                     if (!mask_mode) xdl[k] = f2{__uint_as_float(pw[4 * NB_PER + 2 * k]), __uint_as_float(pw[4 * NB_PER + 2 * k + 1])};
                 }
             }
         };
         fetch(first);
+        int rb = ring ? rslot(first) : 0;                   // ring slot of the tile's first sample (tiles divide the ring)
         for (long base = first; base < seg_b; base += NB_TILE) {
             f2 xd[NB_PER], xn[NB_PER], xl[NB_PER], xt[NB_PER];
             float mag[NB_PER];
             double d[NB_PER], run = 0.0;
             take(xn, xl, xt);
+            float far[NB_PER];                              // ring form: the magnitudes leaving the window
+            if constexpr (mask_mode) {
+                if (ring) {
+                    // a thread's NB_PER window-leaving magnitudes start at an arbitrary (uniform) offset from a 16-byte
+                    // boundary of the ring: NB_PER / 4 + 1 aligned reads, picked apart by that offset
+                    int f0 = rb - M1 + t * NB_PER;          // > -NB_RING
+                    f0 = f0 < 0 ? f0 + NB_RING : f0;
+                    const float4 *src = reinterpret_cast<const float4 *>(nb_ring);
+                    float q[NB_PER + 4];
+#pragma unroll
+                    for (int v = 0; v <= NB_PER / 4; v++) {
+                        int fv = (f0 >> 2) + v;             // (NB_RING is a multiple of four: no 16-byte read straddles the wrap)
+                        fv = fv >= NB_RING / 4 ? fv - NB_RING / 4 : fv;
+                        const float4 w4 = src[fv];
+                        q[4 * v] = w4.x; q[4 * v + 1] = w4.y; q[4 * v + 2] = w4.z; q[4 * v + 3] = w4.w;
+                    }
+                    switch ((unsigned)(-M1) & 3u) {         // = f0 & 3: base and t * NB_PER are multiples of four
+#define NB_PICK(O_) case O_: _Pragma("unroll") for (int k = 0; k < NB_PER; k++) far[k] = q[O_ + k]; break;
+                        NB_PICK(0) NB_PICK(1) NB_PICK(2) default: NB_PICK(3)
+#undef NB_PICK
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
                 mag[k] = 0.f; d[k] = 0.0; xd[k] = f2{0.f, 0.f};
                 if (base + (long)t * NB_PER + k < seg_b) {
-                    const f2 x = xn[k], xo = xl[k];
+                    const f2 x = xn[k];
                     xd[k] = xt[k];
                     mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
-                    d[k] = (double)mag[k] - (double)fmaxf(fabsf(xo.x), fabsf(xo.y));
+                    float mo;
+                    if (mask_mode && ring) mo = far[k];
+                    else { const f2 xo = xl[k]; mo = fmaxf(fabsf(xo.x), fabsf(xo.y)); }
+                    d[k] = (double)mag[k] - (double)mo;
                 }
                 run += d[k];
                 d[k] = run;                                // thread-local inclusive prefix
+            }
+            if constexpr (mask_mode) {
+                if (ring) {                                 // this tile's magnitudes: read again mag_n + 1 samples from now
+                    float4 *dst = reinterpret_cast<float4 *>(nb_ring) + ((rb + t * NB_PER) >> 2);
+#pragma unroll
+                    for (int v = 0; v < NB_PER / 4; v++) dst[v] = make_float4(mag[4 * v], mag[4 * v + 1], mag[4 * v + 2], mag[4 * v + 3]);
+                }
             }
             if (base + NB_TILE < seg_b) fetch(base + NB_TILE);
             const double incl = wave_incl_scan_add(run, lane);
@@ -236,8 +328,10 @@ void noiseblank_kernel(NbArgs a)
             int tile_last = NB_NEVER;
             for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
             if (mask_mode) {
-                // a thread's four blank flags are a nibble; eight neighbouring lanes make a word of the mask row (tiles
-                // start at multiples of the tile length, so words never straddle tiles; a warm-up tile is skipped whole)
+                // a thread's blank flags are a nibble (a byte with eight samples per thread); eight (four) neighbouring
+                // lanes make a word of the mask row (tiles start at multiples of the tile length, so words never
+                // straddle tiles; a warm-up tile is skipped whole)
+                constexpr int LPW = 32 / NB_PER;            // lanes per mask word
                 unsigned nib = 0;
 #pragma unroll
                 for (int k = 0; k < NB_PER; k++) {
@@ -245,10 +339,10 @@ void noiseblank_kernel(NbArgs a)
                     const int l = lt[k] > before ? lt[k] : before;
                     if (r < nvalid && r - l < W) nib |= 1u << k;
                 }
-                unsigned wv = nib << (4 * (lane & 7));
-                wv |= (unsigned)__shfl_xor((int)wv, 1); wv |= (unsigned)__shfl_xor((int)wv, 2); wv |= (unsigned)__shfl_xor((int)wv, 4);
-                static_assert(NB_PER == 4, "eight lanes x four samples = one 32-bit word of the mask");
-                if ((lane & 7) == 0 && nskip == 0 && t * NB_PER < nvalid) mrow[(base + (long)t * NB_PER) >> 5] = wv;
+                unsigned wv = nib << (NB_PER * (lane & (LPW - 1)));
+#pragma unroll
+                for (int sh = 1; sh < LPW; sh <<= 1) wv |= (unsigned)__shfl_xor((int)wv, sh);
+                if ((lane & (LPW - 1)) == 0 && nskip == 0 && t * NB_PER < nvalid) mrow[(base + (long)t * NB_PER) >> 5] = wv;
             } else {
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
@@ -260,6 +354,7 @@ void noiseblank_kernel(NbArgs a)
             }
             }
             S0 += total;
+            if (ring) { rb += NB_TILE; rb = rb >= NB_RING ? rb - NB_RING : rb; }
             if (tile_last > NB_NEVER) last = (long long)base + tile_last;
             __syncthreads();                               // wsum / wmax reused by the next tile
         }
@@ -286,8 +381,11 @@ void noiseblank_kernel(NbArgs a)
 
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 {
-    if (a.out == nullptr) hipLaunchKernelGGL(noiseblank_kernel<true>, dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
-    else hipLaunchKernelGGL(noiseblank_kernel<false>, dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
+    if (a.out == nullptr && a.ring)
+        hipLaunchKernelGGL((noiseblank_kernel<true, true>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
+    else if (a.out == nullptr)
+        hipLaunchKernelGGL((noiseblank_kernel<true, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
+    else hipLaunchKernelGGL((noiseblank_kernel<false, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
     return hipGetLastError();
 }
 

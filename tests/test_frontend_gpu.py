@@ -207,6 +207,74 @@ def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len, fs, width):
             assert np.array_equal(got[c], want.astype(np.complex64)), (npk, c)
 
 
+@pytest.mark.parametrize("fs,width", [(2e6, 20.0), (2000200.0, 21.0), (500e3, 100.0), (6e6, 10.0)],
+                         ids=["ring-odd-lag", "ring-even-lag", "window-below-a-tile", "window-beyond-the-ring"])
+@pytest.mark.parametrize("src", ["rows", 1028, 1444])
+def test_blank_mask_is_bit_exact(oracle, src, fs, width):
+    """The blanker's MASK form (what csdr_demod_batch_process_packets runs in front of the fused down-converter): one
+    bit per sample, no samples out.  Applied to the input the way the down-converter applies it -- out[i] = 0 under the
+    mask, else x[i - delay_n - 1] -- the mask must give the oracle blanker's output word for word.  Float rows and
+    both datagram formats; sample rates whose 5 ms window takes the LDS ring of magnitudes (10 001 / 10 002 samples:
+    both parities of the aligned ring reads) and rates that fall back to the two-stream form (2 501: shorter than a
+    tile; 30 001: longer than the ring); ragged calls, one of them long enough for several segments per channel (later
+    segments rebuild the window sum and the ring from the samples in front of them)."""
+    import ctypes as C_
+    import cutesdr_amd as ca
+    L = ca.lib()
+    L.csdr__noiseproc_batch_mask.restype = C_.c_int
+    L.csdr__noiseproc_batch_mask.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_longlong, C_.c_void_p, C_.c_int, C_.c_int, C_.c_int,
+                                             C_.c_void_p, C_.c_longlong, C_.POINTER(C_.c_void_p), C_.POINTER(C_.c_void_p),
+                                             C_.c_void_p]
+    Cn = 3
+    per = 240 if src == 1444 else 256
+    counts = [3, 130, 1, 1200, 77]                             # datagrams (or 256-sample rows) per call
+    tot = sum(counts) * per
+    rng = np.random.default_rng(17)
+    x = [1500.0 * (rng.standard_normal(tot) + 1j * rng.standard_normal(tot)) for _ in range(Cn)]
+    for xc in x:
+        xc[rng.random(tot) < 2e-4] += 25000.0
+    if src == "rows":
+        xs = [xc.astype(np.complex64) for xc in x]
+    else:
+        raw = np.stack([(_pack24 if src == 1444 else _pack16)(xc) for xc in x])
+        xs = [oracle.unpack_packets(raw[c], src).astype(np.complex64) for c in range(Cn)]
+    nb = ca.NoiseProcBatch(Cn); nb.setup(True, 25.0, width, fs)
+    refs = []
+    for c in range(Cn):
+        q = oracle.CNoiseProc(); q.SetupBlanker(True, 25.0, width, fs); refs.append(q)
+    delay1 = int(width * 1e-6 * fs) // 2 + 1                   # delay_n + 1 (noiseproc.cpp:92-99)
+    k0, blanked = 0, 0
+    for npk in counts:
+        n = npk * per
+        a0 = k0 * per
+        words = (n + 31) // 32 + 64
+        dm = ca.DeviceBuffer(Cn * words * 4)
+        st, hi = C_.c_void_p(), C_.c_void_p()
+        if src == "rows":
+            part = np.ascontiguousarray(np.stack([xc[a0:a0 + n] for xc in xs]))
+            dp = ca.DeviceBuffer(part.nbytes); dp.upload(part)
+            rc = L.csdr__noiseproc_batch_mask(nb.h, C_.c_void_p(dp.ptr), n, None, 0, 0, n, C_.c_void_p(dm.ptr), words,
+                                              C_.byref(st), C_.byref(hi), None)
+        else:
+            part = np.ascontiguousarray(raw[:, k0:k0 + npk])
+            dp = ca.DeviceBuffer(part.nbytes); dp.upload(part)
+            rc = L.csdr__noiseproc_batch_mask(nb.h, None, 0, C_.c_void_p(dp.ptr), npk, src, n, C_.c_void_p(dm.ptr), words,
+                                              C_.byref(st), C_.byref(hi), None)
+        assert rc == 0
+        ca.sync()
+        m = dm.download(np.uint32, Cn * words).reshape(Cn, words)
+        for c in range(Cn):
+            bits = ((m[c, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:n].astype(bool)
+            idx = np.arange(a0, a0 + n) - delay1
+            delayed = np.where(idx >= 0, xs[c][np.maximum(idx, 0)], 0).astype(np.complex64)
+            got = np.where(bits, np.complex64(0), delayed)
+            want = refs[c].ProcessBlanker(xs[c][a0:a0 + n].astype(np.complex128)).astype(np.complex64)
+            assert np.array_equal(got, want), (npk, c, np.nonzero(got != want)[0][:5])
+            blanked += int(bits.sum())
+        k0 += npk
+    assert 0 < blanked < tot                                   # the case blanks, and not everything
+
+
 def test_pipelined_packets_with_blanker_give_the_strict_mode_words():
     """csdr_demod_batch_process_packets with a blanker, pipelined mode: the blanker of call k+1 writes the batch's
     own staging buffer while the down-converters of call k (on the batch's internal streams) may still be reading
