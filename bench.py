@@ -258,7 +258,7 @@ def live_traffic(timeout_s=240):
                     counts = json.loads(line)["pmc_child"]
             if not counts:
                 return None
-            acc = {"k1": [], "k2": [], "k3": 0.0, "k6": [], "chain": 0.0}
+            acc = {"k1": [], "k2": [], "k3": 0.0, "k6": [], "k6m": [], "chain": 0.0}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row["Kernel_Name"]
@@ -271,6 +271,8 @@ def live_traffic(timeout_s=240):
                         acc["k2"].append(v)
                     elif "spectrum" in name:
                         acc["k3"] += v
+                    elif "noiseblank_kernel<true" in name:
+                        acc["k6m"].append(v)
                     elif "noiseblank_kernel" in name:
                         acc["k6"].append(v)
                     else:
@@ -278,11 +280,11 @@ def live_traffic(timeout_s=240):
             if len(acc["k1"]) < 3:
                 return None
             mean = lambda v: sum(v) / len(v) if v else None
-            per[counter] = {"k1": mean(acc["k1"]), "k2": mean(acc["k2"]), "k6": mean(acc["k6"]),
+            per[counter] = {"k1": mean(acc["k1"]), "k2": mean(acc["k2"]), "k6": mean(acc["k6"]), "k6m": mean(acc["k6m"]),
                             "k3": acc["k3"] / counts["k3"] if counts.get("k3") else None,
                             "chain": acc["chain"] / counts["chain"] if counts.get("chain") else None}
         res = {}
-        for key in ("k1", "k2", "k3", "k6", "chain"):
+        for key in ("k1", "k2", "k3", "k6", "k6m", "chain"):
             f, w = per["FETCH_SIZE"].get(key), per["WRITE_SIZE"].get(key)
             res[key] = None if f is None or w is None else {"bytes": (2.0 * f + w) * 1024.0, "FETCH_SIZE_KiB": round(f, 1),
                                                             "WRITE_SIZE_KiB": round(w, 1)}
@@ -332,11 +334,20 @@ def run_pmc_child():
         nb.process_ptr(c4.x.data_ptr(), T, T, xb.data_ptr(), T, st)
     torch.cuda.synchronize()
     del nb, xb
+    npk = (T // 240) // 8 * 8
+    pk = datagrams_of(torch, c4.x, npk)
+    nb = ca.NoiseProcBatch(C, device=ctx.local)
+    nb.setup(True, 50.0, 2.0, C4_FS)
+    run, mask = blank_mask_call(torch, ca, nb, pk, npk, st)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    del nb, pk, mask
     c4.set_mode(False)
     for _ in range(4):
         c4.step()
     torch.cuda.synchronize()
-    print(json.dumps({"pmc_child": {"k1": 6, "k2": 3, "k3": 3, "k6": 3, "chain": 4}}), flush=True)
+    print(json.dumps({"pmc_child": {"k1": 6, "k2": 3, "k3": 3, "k6": 3, "k6m": 3, "chain": 4}}), flush=True)
 
 
 # ---------------------------------------------------------------- CPU baseline
@@ -558,6 +569,40 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
     return out
 
 
+def blank_mask_call(torch, ca, nb, pk, npk, stream):
+    """csdr__noiseproc_batch_mask (the blanker pass csdr_demod_batch_process_packets runs in front of the fused
+    down-converters) on a datagram buffer, alone: returns a callable and the mask buffer it fills."""
+    import ctypes as C_
+    L = ca.lib()
+    L.csdr__noiseproc_batch_mask.restype = C_.c_int
+    L.csdr__noiseproc_batch_mask.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_longlong, C_.c_void_p, C_.c_int, C_.c_int, C_.c_int,
+                                             C_.c_void_p, C_.c_longlong, C_.POINTER(C_.c_void_p), C_.POINTER(C_.c_void_p),
+                                             C_.c_void_p]
+    C, n = pk.shape[0], npk * 240
+    words = (n + 31) // 32 + 64
+    mask = torch.empty((C, words), device=pk.device, dtype=torch.int32)
+    st, hi = C_.c_void_p(), C_.c_void_p()
+
+    def run():
+        rc = L.csdr__noiseproc_batch_mask(nb.h, None, 0, C_.c_void_p(pk.data_ptr()), npk, 1444, n, C_.c_void_p(mask.data_ptr()),
+                                          words, C_.byref(st), C_.byref(hi), C_.c_void_p(stream))
+        assert rc == 0, ca._capi.last_error()
+    return run, mask
+
+
+def datagrams_of(torch, x, npk):
+    """the receivers' own signals in the radio's 24-bit wire format: value * 256, 3 LE bytes, 240 samples + 4 header
+    bytes per datagram (interface/netiobase.cpp:479-527)"""
+    C = x.shape[0]
+    pk = torch.zeros((C, npk, 1444), device=x.device, dtype=torch.uint8)
+    for c0 in range(0, C, 32):
+        v = torch.round(x[c0:c0 + 32, :npk * 240].reshape(-1, npk, 480) * 256.0).clamp(-(1 << 23), (1 << 23) - 1).to(torch.int32)
+        body = torch.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], dim=-1).to(torch.uint8).reshape(-1, npk, 1440)
+        pk[c0:c0 + 32, :, 4:] = body
+        del v, body
+    return pk
+
+
 def packets_chain(torch, ca, ctx, c4):
     """The C4 share fed with the radio's own 24-bit datagrams (interface/netiobase.cpp:479-527: 6 B per sample instead
     of 8) -- no unpack pass, the down-converter decodes them in its loads -- and the same with CNoiseProc's blanker in
@@ -566,12 +611,7 @@ def packets_chain(torch, ca, ctx, c4):
     C, T, x = c4.C, c4.T, c4.x
     npk = (T // 240) // 8 * 8                            # 1920 = 64 * 30 samples: a multiple of the largest decimation
     Tp = npk * 240
-    pk = torch.zeros((C, npk, 1444), device=x.device, dtype=torch.uint8)
-    for c0 in range(0, C, 32):                           # the receivers' own signals in the wire format: value * 256, 3 LE bytes
-        v = torch.round(x[c0:c0 + 32, :Tp].reshape(-1, npk, 480) * 256.0).clamp(-(1 << 23), (1 << 23) - 1).to(torch.int32)
-        body = torch.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], dim=-1).to(torch.uint8).reshape(-1, npk, 1440)
-        pk[c0:c0 + 32, :, 4:] = body
-        del v, body
+    pk = datagrams_of(torch, x, npk)
     c4.set_mode(False)
     nb = ca.NoiseProcBatch(C, device=ctx.local)
     nb.setup(True, 50.0, 2.0, C4_FS)
@@ -584,8 +624,16 @@ def packets_chain(torch, ca, ctx, c4):
         out[key] = round(gpu_ms(torch, run, 8, 20), 4)
     out["raw_input_MSamples_per_s"] = round(C * Tp / out["packets_chain_ms"] / 1e3, 1)
     out["with_blanker_MSamples_per_s"] = round(C * Tp / out["packets_blanker_chain_ms"] / 1e3, 1)
-    out["blanker"] = "fused: noiseblank_kernel<mask> + downconv_kernel<plan, BLK> (CSDR_BLANK_FUSED=0: two passes through a blanked fp32 copy)"
-    del nb, pk
+    out["blanker"] = ("fused: noiseblank_kernel<mask, ring> (one bit per sample; the 5 ms window's magnitudes in an LDS ring) + "
+                      "downconv_kernel<plan, BLK> (CSDR_BLANK_FUSED=0: two passes through a blanked fp32 copy)")
+    # the mask kernel of that chain alone, roofline-shaped: datagram bytes in, one bit per sample out
+    run, mask = blank_mask_call(torch, ca, nb, pk, npk, c4.stream)
+    ms = gpu_ms(torch, run, 5, 20)
+    alg = float(C) * (npk * 1444 + Tp / 8.0)
+    out["mask_kernel"] = {"config": "the blanker pass of that chain alone: %d receivers x %d datagrams in, one bit per sample out" % (C, npk),
+                          "ms_per_launch": round(ms, 4),
+                          "roofline": roofline_obj(alg / ms / 1e6, ms, "csdr::noiseblank_kernel<true, true>", alg, None)}
+    del nb, pk, mask
     return out
 
 
@@ -1140,6 +1188,11 @@ def run_rank(args):
                         r["traffic"] = live[key]["bytes"]
                         r["traffic_over_algorithmic"] = round(live[key]["bytes"] / r["algorithmic_bytes_per_launch"], 3)
                         r["traffic_counters_KiB"] = {k: v for k, v in live[key].items() if k != "bytes"}
+                if live.get("k6m") and "mask_kernel" in extra.get("packets_chain", {}):
+                    r = extra["packets_chain"]["mask_kernel"]["roofline"]
+                    r["traffic"] = live["k6m"]["bytes"]
+                    r["traffic_over_algorithmic"] = round(live["k6m"]["bytes"] / r["algorithmic_bytes_per_launch"], 3)
+                    r["traffic_counters_KiB"] = {k: v for k, v in live["k6m"].items() if k != "bytes"}
             else:
                 traffic = profiled_traffic()
                 extra["traffic_measured"] = {"source": "profiles/traffic_latest.json (same kernel sources: hash checked)" if traffic else None}
