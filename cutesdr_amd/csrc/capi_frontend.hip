@@ -147,15 +147,16 @@ static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_strid
     a.mask = d_mask; a.mask_stride = mask_stride;
     a.channels = b->channels; a.n = n_per_channel;
     static const bool ring_env = !(getenv("CSDR_NB_RING") && atoi(getenv("CSDR_NB_RING")) == 0);
-    a.ring = d_mask && ring_env;
+    a.ring = ring_env;
     for (int c = 0; c < b->channels && a.ring; c++)
-        if (b->h[c].on && (b->h[c].mag_n + 1 < noiseblank_ring_min() || b->h[c].mag_n + 1 > noiseblank_ring_max())) a.ring = 0;
+        if (b->h[c].on && (b->h[c].mag_n + 1 < noiseblank_ring_min(d_mask != nullptr) ||
+                           b->h[c].mag_n + 1 > noiseblank_ring_max(d_mask != nullptr))) a.ring = 0;
     // segments: enough workgroups to fill the chip, each at least 32 tiles long (the longest blank
     // width is 4 tiles, the moving-sum reduction at a segment start another ~10-32 tiles' worth of reads)
     // (mask mode: 74 registers, three 512-thread workgroups per CU: 3072 workgroups = four rounds measured best,
     // 3.28 ms for the C4 share's datagram-fed chain against 3.36 with 2048 and 3.49 with 4096)
-    // (mask mode with the ring: two workgroups per CU -- 64 KB of ring each -- and ONE round of them: 1.07 ms against
-    // 1.11 with two rounds, 1.18 with six)
+    // (with the ring: two workgroups per CU -- 64 KB of ring each -- and ONE round of them: mask form 1.07 ms against
+    // 1.11 with two rounds, 1.18 with six; sample form 2.20 against 2.24 and 2.29 with four)
     static const long want_env = getenv("CSDR_NB_WGS") ? atol(getenv("CSDR_NB_WGS")) : 0;
     const long want_wgs = want_env > 0 ? want_env : (a.ring ? 512 : (d_mask ? 3072 : 2048));
     long nseg = (want_wgs + b->channels - 1) / b->channels;

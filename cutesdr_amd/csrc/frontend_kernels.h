@@ -29,15 +29,15 @@ struct NbArgs {
                                         // no 8-byte write and re-read per sample, no third input stream here
     const float *hist; float *hist_next;    // [channels][NB_HIST] complex: the last NB_HIST inputs, ping-pong
     int channels, n;
-    int ring;                           // mask mode: the window's magnitudes stay in an LDS ring (frontend_kernels.hip) --
-                                        // only when EVERY channel with the blanker on has noiseblank_ring_min() <=
-                                        // mag_n + 1 <= noiseblank_ring_max()
+    int ring;                           // the window's magnitudes stay in an LDS ring (frontend_kernels.hip) -- only when
+                                        // EVERY channel with the blanker on has noiseblank_ring_min(mask form?) <=
+                                        // mag_n + 1 <= noiseblank_ring_max(mask form?)
     int nseg, seg_len;                  // each channel's call is cut into nseg segments of seg_len samples (a
                                         // multiple of 1024, >= 4 blank widths), one workgroup each
 };
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream);
-int noiseblank_ring_min();
-int noiseblank_ring_max();
+int noiseblank_ring_min(bool mask);
+int noiseblank_ring_max(bool mask);
 int noiseblank_tile(bool mask);        // samples per tile of the kernel (its mask form: a.out == nullptr): segment lengths are multiples of it
 
 // packets: [channels][npackets][pkt_len] bytes, pkt_len 1028 (16 bit, 256 samples) or 1444 (24 bit, 240);

@@ -40,21 +40,25 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
 #define NB_PER_THREAD_RING 8
 #endif
 constexpr int NB_T = NB_THREADS;
-template <bool RING> struct NbTile { static constexpr int PER = RING ? NB_PER_THREAD_RING : NB_PER_THREAD, TILE = NB_T * PER; };
+template <bool MASK, bool RING> struct NbTile { static constexpr int PER = MASK && RING ? NB_PER_THREAD_RING : NB_PER_THREAD, TILE = NB_T * PER; };
 // (the host cuts segments before it knows which mask form runs: a multiple of both tiles)
-int noiseblank_tile(bool mask) { return mask && NbTile<true>::TILE > NbTile<false>::TILE ? NbTile<true>::TILE : NbTile<false>::TILE; }
-static_assert(NbTile<true>::TILE % NbTile<false>::TILE == 0, "segments are whole tiles of either form");
-// RING (mask form): the magnitudes of a workgroup's last NB_RING samples stay in LDS, so that the sample LEAVING the
+int noiseblank_tile(bool mask) { return mask && NbTile<true, true>::TILE > NbTile<true, false>::TILE ? NbTile<true, true>::TILE : NbTile<false, false>::TILE; }
+static_assert(NbTile<true, true>::TILE % NbTile<true, false>::TILE == 0 && NbTile<false, true>::TILE == NbTile<false, false>::TILE,
+              "segments are whole tiles of either form");
+// RING: the magnitudes of a workgroup's last NB_RING samples stay in LDS, so that the sample LEAVING the
 // moving-sum window -- mag_n + 1 = 10 001 samples, 60 KB of datagrams, behind the new one -- is not fetched and decoded
 // a second time.  That second stream was half of the mask form's traffic (counters: 2 x 3.23 GB at the fabric per
 // launch of the C4 share, 4.8 TB/s -- the 96 windows of an XCD's resident workgroups are 5.8 MB against 4 MB of L2,
 // so the Infinity Cache served it, not L2).  An instantiation of its own (RING), so that neither form carries the
 // other's registers.  Taken by the host when every channel with the blanker on has one tile <= mag_n + 1 <= NB_RING - one tile
 // (no barrier between a tile's ring writes and its own ring reads is needed then); else the two-stream form.
-// (Round 3 tried a ring in the three-stream fp32 kernel, where that stream was a third of less traffic, and dropped it.)
-constexpr int NB_RING = 4 * NbTile<true>::TILE;             // 16384 magnitudes: a whole number of tiles
-int noiseblank_ring_min() { return NbTile<true>::TILE; }
-int noiseblank_ring_max() { return NB_RING - NbTile<true>::TILE; }
+// The sample form (three streams: new, leaving, delayed; fp32 rows out) takes the ring too, four samples per thread: its
+// leaving stream was a third of 24 B per sample at the fabric.  (Round 3 tried a ring there -- 44 KB per 256-thread
+// workgroup, every channel -- and dropped it: 3.36 against 2.86 ms.)
+constexpr int NB_RING = 4 * NbTile<true, true>::TILE;       // 16384 magnitudes: a whole number of tiles of either form
+static_assert(NB_RING % NbTile<false, true>::TILE == 0, "tiles divide the ring");
+int noiseblank_ring_min(bool mask) { return mask ? NbTile<true, true>::TILE : NbTile<false, true>::TILE; }
+int noiseblank_ring_max(bool mask) { return NB_RING - noiseblank_ring_min(mask); }
 
 // Wave scans on the DPP network (row_shr 1, 2, 4, 8, then row_bcast 15 into rows 1, 3 and row_bcast 31 into rows
 // 2, 3; a step without a source lane reads the identity) instead of __shfl_up: a 64-bit shuffle is two
@@ -96,13 +100,12 @@ void noiseblank_kernel(NbArgs a)
     __shared__ double wsum[NB_T / 64];
     __shared__ int wmax[NB_T / 64];
     extern __shared__ __attribute__((aligned(16))) float nb_ring[];    // [NB_RING] (RING)
-    static_assert(!RING || MASK, "the ring belongs to the mask form");
     const int ch = blockIdx.x / a.nseg, seg = blockIdx.x % a.nseg, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const NbChan C = a.chan[ch];                        // state at the start of the call (the last segment writes chan_next)
     const f2 *in = reinterpret_cast<const f2 *>(a.in) + (long)ch * a.in_stride;
     f2 *out = reinterpret_cast<f2 *>(a.out) + (long)ch * a.out_stride;
     constexpr bool mask_mode = MASK;
-    constexpr int NB_PER = NbTile<RING>::PER, NB_TILE = NbTile<RING>::TILE, NB_NP = NB_PER / 2;
+    constexpr int NB_PER = NbTile<MASK, RING>::PER, NB_TILE = NbTile<MASK, RING>::TILE, NB_NP = NB_PER / 2;
     static_assert(NB_PER % 2 == 0 && 240 % NB_PER == 0 && 32 % NB_PER == 0,
                   "a thread's samples are whole sample pairs of one 24-bit datagram and a whole fraction of a mask word");
     unsigned *mrow = mask_mode ? a.mask + (long)ch * a.mask_stride : nullptr;
@@ -162,7 +165,7 @@ void noiseblank_kernel(NbArgs a)
         bool praw = false;                                  // uniform: what the last fetch left in pw
         auto put = [&](int slot, int k, f2 v) { pw[2 * NB_PER * slot + 2 * k] = __float_as_uint(v.x); pw[2 * NB_PER * slot + 2 * k + 1] = __float_as_uint(v.y); };
         auto fetch = [&](long b0) {
-            const bool inside = (ring || (b0 - M1 >= 0 && b0 - D1 >= 0)) && b0 + NB_TILE <= seg_b;
+            const bool inside = (ring || b0 - M1 >= 0) && (mask_mode || b0 - D1 >= 0) && b0 + NB_TILE <= seg_b;
             praw = false;
             if (pk && pkt_len == 1444 && inside) {
                 // 24-bit datagrams: a sample pair (even index) is 12 bytes at a 4-byte aligned offset and never straddles a
@@ -253,8 +256,8 @@ void noiseblank_kernel(NbArgs a)
             double d[NB_PER], run = 0.0;
             take(xn, xl, xt);
             float far[NB_PER];                              // ring form: the magnitudes leaving the window
-            if constexpr (mask_mode) {
-                if (ring) {
+            if constexpr (RING) {
+                {
                     // a thread's NB_PER window-leaving magnitudes start at an arbitrary (uniform) offset from a 16-byte
                     // boundary of the ring: NB_PER / 4 + 1 aligned reads, picked apart by that offset
                     int f0 = rb - M1 + t * NB_PER;          // > -NB_RING
@@ -283,15 +286,15 @@ void noiseblank_kernel(NbArgs a)
                     xd[k] = xt[k];
                     mag[k] = fmaxf(fabsf(x.x), fabsf(x.y));
                     float mo;
-                    if (mask_mode && ring) mo = far[k];
+                    if (ring) mo = far[k];
                     else { const f2 xo = xl[k]; mo = fmaxf(fabsf(xo.x), fabsf(xo.y)); }
                     d[k] = (double)mag[k] - (double)mo;
                 }
                 run += d[k];
                 d[k] = run;                                // thread-local inclusive prefix
             }
-            if constexpr (mask_mode) {
-                if (ring) {                                 // this tile's magnitudes: read again mag_n + 1 samples from now
+            if constexpr (RING) {
+                {                                           // this tile's magnitudes: read again mag_n + 1 samples from now
                     float4 *dst = reinterpret_cast<float4 *>(nb_ring) + ((rb + t * NB_PER) >> 2);
 #pragma unroll
                     for (int v = 0; v < NB_PER / 4; v++) dst[v] = make_float4(mag[4 * v], mag[4 * v + 1], mag[4 * v + 2], mag[4 * v + 3]);
@@ -381,11 +384,21 @@ void noiseblank_kernel(NbArgs a)
 
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 {
-    if (a.out == nullptr && a.ring)
+    if (a.out == nullptr && a.ring) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&noiseblank_kernel<true, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NB_RING * 4);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL((noiseblank_kernel<true, true>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
+    }
     else if (a.out == nullptr)
         hipLaunchKernelGGL((noiseblank_kernel<true, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
-    else hipLaunchKernelGGL((noiseblank_kernel<false, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
+    else if (a.ring) {
+        // per launch: the attribute belongs to the current device (static + dynamic LDS are above 64 KB)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&noiseblank_kernel<false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NB_RING * 4);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((noiseblank_kernel<false, true>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
+    } else hipLaunchKernelGGL((noiseblank_kernel<false, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
     return hipGetLastError();
 }
 
