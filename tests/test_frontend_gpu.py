@@ -277,6 +277,61 @@ def test_blank_mask_is_bit_exact(oracle, src, fs, width):
     assert 0 < blanked < tot                                   # the case blanks, and not everything
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_blanker_random_rates_around_the_ring_limits(oracle, seed):
+    """Both forms of the blanker at random sample rates, thresholds, widths and call lengths -- rates drawn around the
+    limits of the LDS-ring form (a 5 ms window of 2048 / 4096 samples at its lower end, 12288 / 14336 at its upper one:
+    0.41, 0.82, 2.46 and 2.87 MS/s) so that neighbouring windows take different kernels -- against the oracle, word for
+    word: the sample form's output, and the mask form's bits applied to the input."""
+    import ctypes as C_
+    import cutesdr_amd as ca
+    L = ca.lib()
+    L.csdr__noiseproc_batch_mask.restype = C_.c_int
+    L.csdr__noiseproc_batch_mask.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_longlong, C_.c_void_p, C_.c_int, C_.c_int, C_.c_int,
+                                             C_.c_void_p, C_.c_longlong, C_.POINTER(C_.c_void_p), C_.POINTER(C_.c_void_p),
+                                             C_.c_void_p]
+    rng = np.random.default_rng(1000 + seed)
+    edge = [2048, 4096, 12288, 14336][seed % 4]
+    win = int(edge + rng.integers(-3, 4))                      # mag_n + 1 within three samples of a limit
+    fs = (win - 1 + 0.5) / 0.005                                # mag_n = (int)(0.005 fs)
+    thresh = float(rng.uniform(10.0, 80.0))
+    width = float(rng.uniform(1.0, 60.0))                      # microseconds
+    Cn = 2
+    calls = [int(v) for v in rng.integers(1, 60000, size=4)] + [300000]
+    tot = sum(calls)
+    xs = []
+    for c in range(Cn):
+        x = impulsive(seed * 10 + c, tot, fs, rate=3e-4)
+        xs.append(x.astype(np.complex64))
+    g = ca.NoiseProcBatch(Cn); g.setup(True, thresh, width, fs)
+    m = ca.NoiseProcBatch(Cn); m.setup(True, thresh, width, fs)
+    refs = []
+    for c in range(Cn):
+        q = oracle.CNoiseProc(); q.SetupBlanker(True, thresh, width, fs); refs.append(q)
+    delay1 = max(1, min(int(width * 1e-6 * fs), 4096)) // 2 + 1
+    a0 = 0
+    for n in calls:
+        part = np.ascontiguousarray(np.stack([x[a0:a0 + n] for x in xs]))
+        got = g.process(part)
+        words = (n + 31) // 32 + 64
+        dp, dm = ca.DeviceBuffer(part.nbytes), ca.DeviceBuffer(Cn * words * 4)
+        dp.upload(part)
+        st, hi = C_.c_void_p(), C_.c_void_p()
+        assert L.csdr__noiseproc_batch_mask(m.h, C_.c_void_p(dp.ptr), n, None, 0, 0, n, C_.c_void_p(dm.ptr), words,
+                                            C_.byref(st), C_.byref(hi), None) == 0
+        ca.sync()
+        mw = dm.download(np.uint32, Cn * words).reshape(Cn, words)
+        for c in range(Cn):
+            want = refs[c].ProcessBlanker(xs[c][a0:a0 + n].astype(np.complex128)).astype(np.complex64)
+            assert np.array_equal(got[c], want), ("samples", win, n, c, np.nonzero(got[c] != want)[0][:5])
+            bits = ((mw[c, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:n].astype(bool)
+            idx = np.arange(a0, a0 + n) - delay1
+            delayed = np.where(idx >= 0, xs[c][np.maximum(idx, 0)], 0).astype(np.complex64)
+            masked = np.where(bits, np.complex64(0), delayed)
+            assert np.array_equal(masked, want), ("mask", win, n, c, np.nonzero(masked != want)[0][:5])
+        a0 += n
+
+
 def test_pipelined_packets_with_blanker_give_the_strict_mode_words():
     """csdr_demod_batch_process_packets with a blanker, pipelined mode: the blanker of call k+1 writes the batch's
     own staging buffer while the down-converters of call k (on the batch's internal streams) may still be reading
