@@ -642,25 +642,31 @@ void fft_plain_kernel(const v2f *in, v2f *out, const v2f *tw1g, const v2f *tw2g,
 }
 
 // The weight alpha_g = product of the per-frame factors (1 - 1/count once the average is full) of every frame group,
-// and the average count after the call: the same for all bins of a channel, so one thread per channel walks the
-// frames ONCE (the combine kernel used to do this walk in each of its channels x N threads: 0.18 of K3's 1.6 ms).
+// and the average count after the call: the same for all bins of a channel (the combine kernel used to do this walk in
+// each of its channels x N threads: 0.18 of K3's 1.6 ms).  One thread per (channel, frame group): the counters at a
+// group's first frame follow from those at the call's start in closed form, so the groups' walks -- the same float
+// operations in the same order as one walk over all frames -- run side by side (round 4: one thread per channel took
+// 40 us of the C1 call's 940 for its 512 sequential divisions).
 __global__ void spectrum_alpha_kernel(SpectrumArgs a)
 {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = idx / a.nparts, g = idx - ch * a.nparts;
     if (ch >= a.channels) return;
-    int ave_count = a.counters[2 * ch], total = a.counters[2 * ch + 1];
-    for (int g = 0; g < a.nparts; g++) {
-        const int f0 = (int)((long)a.nframes * g / a.nparts), f1 = (int)((long)a.nframes * (g + 1) / a.nparts);
-        float al = 1.f;                                            // product of the group's alpha_f
-        for (int f = f0; f < f1; f++) {
-            const float prev = (float)ave_count;
-            total++;
-            if (ave_count < a.ave_size) ave_count++;
-            if (total > a.ave_size) al = al - al / prev;
-        }
-        a.alpha[(long)ch * a.nparts + g] = al;
+    const int ave0 = a.counters[2 * ch], total0 = a.counters[2 * ch + 1];
+    // after k frames: total0 + k, and the average count saturates at ave_size (a count above it -- the average was
+    // shortened -- stays)
+    auto ave_after = [&](int k) { return ave0 < a.ave_size ? (ave0 + k < a.ave_size ? ave0 + k : a.ave_size) : ave0; };
+    const int f0 = (int)((long)a.nframes * g / a.nparts), f1 = (int)((long)a.nframes * (g + 1) / a.nparts);
+    int ave_count = ave_after(f0), total = total0 + f0;
+    float al = 1.f;                                                // product of the group's alpha_f
+    for (int f = f0; f < f1; f++) {
+        const float prev = (float)ave_count;
+        total++;
+        if (ave_count < a.ave_size) ave_count++;
+        if (total > a.ave_size) al = al - al / prev;
     }
-    a.alpha[(long)a.channels * a.nparts + ch] = (float)ave_count;
+    a.alpha[(long)ch * a.nparts + g] = al;
+    if (g == 0) a.alpha[(long)a.channels * a.nparts + ch] = (float)ave_after(a.nframes);
 }
 // folds the frame groups of spectrum_kernel (nparts > 1) into the running sum, writes mean and bels
 __global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
@@ -703,7 +709,7 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     } else
         hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
     if (a.nparts > 1) {
-        hipLaunchKernelGGL(spectrum_alpha_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(spectrum_alpha_kernel, dim3((a.channels * a.nparts + 63) / 64), dim3(64), 0, s, a);
         hipLaunchKernelGGL(spectrum_combine_kernel, dim3(Cfg::N / 256, a.channels), dim3(256), 0, s, a, (int)Cfg::N);
         hipLaunchKernelGGL(spectrum_count_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
     }
