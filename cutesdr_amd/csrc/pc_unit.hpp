@@ -48,6 +48,9 @@ struct PcUnit {
     bool no_output = false;
     hipStream_t s_side = nullptr;                        // the whole-call S-meter runs here, beside the walk
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
+    hipStream_t sm_borrow = nullptr;                     // set per call by the batch chain, not owned: an EXISTING stream
+                                                         // that has nothing left to do in this call -- the whole-call
+                                                         // S-meter of the group whose walk ends the call runs there
     std::vector<PcChannel> h;            // host mirror (authoritative for parameters)
     std::vector<HostAgc> hagc;
     std::vector<HostFir> fir_am, fir_sam, fir_fm;
@@ -206,16 +209,17 @@ struct PcUnit {
             // stream per plan group the process goes past the hardware queues it is given; opt-in for diagnostics only)
             static const bool side = getenv("CSDR_SM_SIDE") && atoi(getenv("CSDR_SM_SIDE")) != 0;
             const bool alone = !(a.flags & (PC_DO_AGC | PC_DO_DEMOD));
-            if (side && !alone) {
-                if (!s_side) {
-                    CSDR_HIP(hipStreamCreateWithFlags(&s_side, hipStreamNonBlocking));
+            if ((side || sm_borrow) && !alone) {
+                if (!sm_borrow && !s_side) CSDR_HIP(hipStreamCreateWithFlags(&s_side, hipStreamNonBlocking));
+                if (!ev_side_fork) {
                     CSDR_HIP(hipEventCreateWithFlags(&ev_side_fork, hipEventDisableTiming));
                     CSDR_HIP(hipEventCreateWithFlags(&ev_side_join, hipEventDisableTiming));
                 }
+                hipStream_t ss = sm_borrow ? sm_borrow : s_side;
                 CSDR_HIP(hipEventRecord(ev_side_fork, stream));
-                CSDR_HIP(hipStreamWaitEvent(s_side, ev_side_fork, 0));
-                CSDR_HIP(smeter_call_launch(a, s_side));
-                CSDR_HIP(hipEventRecord(ev_side_join, s_side));
+                CSDR_HIP(hipStreamWaitEvent(ss, ev_side_fork, 0));
+                CSDR_HIP(smeter_call_launch(a, ss));
+                CSDR_HIP(hipEventRecord(ev_side_join, ss));
                 sm_forked = true;
             } else {
                 CSDR_HIP(smeter_call_launch(a, stream));
