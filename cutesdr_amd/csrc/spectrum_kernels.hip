@@ -647,26 +647,34 @@ void fft_plain_kernel(const v2f *in, v2f *out, const v2f *tw1g, const v2f *tw2g,
 // group's first frame follow from those at the call's start in closed form, so the groups' walks -- the same float
 // operations in the same order as one walk over all frames -- run side by side (round 4: one thread per channel took
 // 40 us of the C1 call's 940 for its 512 sequential divisions).
+// One workgroup per channel (thread g = frame group g, in rounds of the block size): once every thread has read the
+// counters, thread 0 moves them -- what spectrum_count_kernel did in a launch of its own.
 __global__ void spectrum_alpha_kernel(SpectrumArgs a)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ch = idx / a.nparts, g = idx - ch * a.nparts;
-    if (ch >= a.channels) return;
+    const int ch = blockIdx.x;
     const int ave0 = a.counters[2 * ch], total0 = a.counters[2 * ch + 1];
-    // after k frames: total0 + k, and the average count saturates at ave_size (a count above it -- the average was
-    // shortened -- stays)
-    auto ave_after = [&](int k) { return ave0 < a.ave_size ? (ave0 + k < a.ave_size ? ave0 + k : a.ave_size) : ave0; };
-    const int f0 = (int)((long)a.nframes * g / a.nparts), f1 = (int)((long)a.nframes * (g + 1) / a.nparts);
-    int ave_count = ave_after(f0), total = total0 + f0;
-    float al = 1.f;                                                // product of the group's alpha_f
-    for (int f = f0; f < f1; f++) {
-        const float prev = (float)ave_count;
-        total++;
-        if (ave_count < a.ave_size) ave_count++;
-        if (total > a.ave_size) al = al - al / prev;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ave_count = ave0 + a.nframes;
+        a.counters[2 * ch] = ave_count < a.ave_size ? ave_count : (ave0 > a.ave_size ? ave0 : a.ave_size);
+        a.counters[2 * ch + 1] = total0 + a.nframes;
     }
-    a.alpha[(long)ch * a.nparts + g] = al;
-    if (g == 0) a.alpha[(long)a.channels * a.nparts + ch] = (float)ave_after(a.nframes);
+    for (int g = threadIdx.x; g < a.nparts; g += blockDim.x) {
+        // after k frames: total0 + k, and the average count saturates at ave_size (a count above it -- the average was
+        // shortened -- stays)
+        auto ave_after = [&](int k) { return ave0 < a.ave_size ? (ave0 + k < a.ave_size ? ave0 + k : a.ave_size) : ave0; };
+        const int f0 = (int)((long)a.nframes * g / a.nparts), f1 = (int)((long)a.nframes * (g + 1) / a.nparts);
+        int ave_count = ave_after(f0), total = total0 + f0;
+        float al = 1.f;                                                // product of the group's alpha_f
+        for (int f = f0; f < f1; f++) {
+            const float prev = (float)ave_count;
+            total++;
+            if (ave_count < a.ave_size) ave_count++;
+            if (total > a.ave_size) al = al - al / prev;
+        }
+        a.alpha[(long)ch * a.nparts + g] = al;
+        if (g == 0) a.alpha[(long)a.channels * a.nparts + ch] = (float)ave_after(a.nframes);
+    }
 }
 // folds the frame groups of spectrum_kernel (nparts > 1) into the running sum, writes mean and bels
 __global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
@@ -680,16 +688,6 @@ __global__ void spectrum_combine_kernel(SpectrumArgs a, int n)
     a.sum[(long)ch * n + j] = sm; a.pwr[(long)ch * n + j] = m;
     a.ave[(long)ch * n + j] = (float)((double)log10f(m + a.kc) + a.kb);
 }
-// the counters move once per channel, after every bin has read them
-__global__ void spectrum_count_kernel(SpectrumArgs a)
-{
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= a.channels) return;
-    int ave_count = a.counters[2 * ch] + a.nframes;
-    a.counters[2 * ch] = ave_count < a.ave_size ? ave_count : (a.counters[2 * ch] > a.ave_size ? a.counters[2 * ch] : a.ave_size);
-    a.counters[2 * ch + 1] += a.nframes;
-}
-
 template <int LOG2N>
 static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
 {
@@ -709,9 +707,8 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     } else
         hipLaunchKernelGGL(spectrum_kernel<LOG2N>, dim3(a.channels * a.nparts), dim3(Cfg::T), Cfg::LDS_BYTES, s, a);
     if (a.nparts > 1) {
-        hipLaunchKernelGGL(spectrum_alpha_kernel, dim3((a.channels * a.nparts + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(spectrum_alpha_kernel, dim3(a.channels), dim3(64), 0, s, a);
         hipLaunchKernelGGL(spectrum_combine_kernel, dim3(Cfg::N / 256, a.channels), dim3(256), 0, s, a, (int)Cfg::N);
-        hipLaunchKernelGGL(spectrum_count_kernel, dim3((a.channels + 63) / 64), dim3(64), 0, s, a);
     }
     return hipGetLastError();
 }
