@@ -151,10 +151,17 @@ int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long i
     a.in = d_in; a.in_stride = in_stride; a.win = f->d_win; a.tw1 = f->d_tw1; a.tw2 = f->d_tw2;
     a.sum = f->d_sum; a.pwr = f->d_pwr; a.ave = f->d_ave; a.counters = f->d_cnt; a.overload = f->d_over;
     a.channels = f->channels; a.nframes = nframes; a.ave_size = f->ave_size;
-    // long calls on few channels: cut each channel's frames into groups so that ~1024 workgroups exist
+    // long calls on few channels: cut each channel's frames into groups so that ONE round of workgroups fills the chip --
+    // 4 / 2 / 1 workgroups per CU at 4096 / 8192 / 16384 points (their LDS images; 2048 points fit eight, and measure 2 %
+    // better with four).  (Until round 4 the target was 1024 workgroups for every size: at 16384 points that was four
+    // rounds, and a workgroup's start -- tables, window, sums, the first frame's latency -- costs five frames' time:
+    // 0.39 ms for 256 channels x 32 frames against 0.33; 8192 points -2 %.)
     a.nparts = 1; a.part = nullptr; a.alpha = nullptr;
     {
-        long np = (1024 + f->channels - 1) / f->channels;
+        const int l2n = log2_of(f->size);
+        const long per_cu = l2n <= 12 ? 4 : (l2n == 13 ? 2 : 1);
+        const long slots = (l2n >= 11 && l2n <= 14) ? 256 * per_cu : 1024;
+        long np = (slots + f->channels - 1) / f->channels;
         if (np > nframes / 8) np = nframes / 8;
         if (np > 1) {
             const size_t need = (size_t)f->channels * np * f->size + (size_t)f->channels * (np + 1);   // + the group weights
