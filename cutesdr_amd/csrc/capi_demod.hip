@@ -1014,6 +1014,9 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
             static const bool borrow = !(getenv("CSDR_CHAIN_SM_BORROW") && atoi(getenv("CSDR_CHAIN_SM_BORROW")) == 0);
             k.pc.sm_borrow = (borrow && forked && !b->pipelined && oi > 0 && oi + 1 == b->cores.size())
                                  ? b->streams[b->order[0]] : nullptr;
+            // ONE group (a single receiver, or receivers of one plan): the call is that group's walk from end to end, and
+            // the S-meter scan beside it on a side stream of its own is 6 % of a C2 / C5 call
+            k.pc.sm_own_side = borrow && !forked;
             rc = k.step(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_out_rows[ki], stereo, st,
                         forked && oi > 0 && dc_chained ? b->dc_done[b->order[oi - 1]] : nullptr, forked ? b->dc_done[ki] : nullptr);
             k.pc.sm_borrow = nullptr;

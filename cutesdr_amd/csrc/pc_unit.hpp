@@ -48,6 +48,8 @@ struct PcUnit {
     bool no_output = false;
     hipStream_t s_side = nullptr;                        // the whole-call S-meter runs here, beside the walk
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
+    bool sm_own_side = false;                            // set by the batch chain when it is ONE plan group: the S-meter may
+                                                         // take a side stream of this unit's own (one more stream in all)
     hipStream_t sm_borrow = nullptr;                     // set per call by the batch chain, not owned: an EXISTING stream
                                                          // that has nothing left to do in this call -- the whole-call
                                                          // S-meter of the group whose walk ends the call runs there
@@ -209,7 +211,7 @@ struct PcUnit {
             // stream per plan group the process goes past the hardware queues it is given; opt-in for diagnostics only)
             static const bool side = getenv("CSDR_SM_SIDE") && atoi(getenv("CSDR_SM_SIDE")) != 0;
             const bool alone = !(a.flags & (PC_DO_AGC | PC_DO_DEMOD));
-            if ((side || sm_borrow) && !alone) {
+            if ((side || sm_borrow || sm_own_side) && !alone) {
                 if (!sm_borrow && !s_side) CSDR_HIP(hipStreamCreateWithFlags(&s_side, hipStreamNonBlocking));
                 if (!ev_side_fork) {
                     CSDR_HIP(hipEventCreateWithFlags(&ev_side_fork, hipEventDisableTiming));
