@@ -6,6 +6,14 @@
 #include <cstdlib>
 #include <vector>
 
+// the shortest segment a launch is cut into: tiles, and multiples of the plan's warm-up (see the segment rule below)
+#ifndef CSDR_DC_MINSEG_TILES
+#define CSDR_DC_MINSEG_TILES 1
+#endif
+#ifndef CSDR_DC_MINSEG_W
+#define CSDR_DC_MINSEG_W 1
+#endif
+
 using namespace csdr;
 
 struct csdr_downconvert_batch {
@@ -274,12 +282,13 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         }
         a.nchan = b->list_len[pi]; a.n_in = n_per_channel; a.nstages = p.nstages; a.W = p.W;
         for (int q = 0; q < p.nstages; q++) { a.st[q] = p.st[q]; a.kind[q] = p.kind[q]; }
-        // segments: enough workgroups to fill the chip, each at least 4 tiles and 2 warm-ups long.  (8 and 8 until round 4:
-        // the floor only binds for one or a few receivers, where it left most of the chip idle -- a 10 MSPS receiver's
-        // call of 2^24 samples ran as 868 workgroups; inside one round a launch's time goes as segment + warm-up, so more,
-        // shorter segments win until the round is full: C5's down-converter 117 -> 45 us, C2's 50 -> 35.)
-        long min_seg = (long)DC_TILE_SAMPLES * 4;
-        if (min_seg < (long)p.W * 2) min_seg = (long)p.W * 2;
+        // segments: enough workgroups to fill the chip, each at least one tile and one warm-up long.  (8 and 8 until round 4:
+        // the floor only binds for one or a few receivers and for short calls, where it left most of the chip idle -- a
+        // 10 MSPS receiver's call of 2^24 samples ran as 868 workgroups, a 19968-sample pass of the host form as two.
+        // Inside one round a launch's time goes as segment + warm-up, so more, shorter segments win until the round is
+        // full: C5's down-converter 117 -> 45 us, the host form's 40 -> 13 us per pass, 188 -> 260 MS/s.)
+        long min_seg = (long)DC_TILE_SAMPLES * CSDR_DC_MINSEG_TILES;
+        if (min_seg < (long)p.W * CSDR_DC_MINSEG_W) min_seg = (long)p.W * CSDR_DC_MINSEG_W;
         // ONE full round of the chip's 4096 one-wave slots (256 CUs x 16) -- round 4: every segment pays its warm-up
         // (W samples run through the cascade for nothing: 1024 for the FM plan, 2560 for AM), and with two rounds (8192,
         // rounds 1-3) an 86-receiver group's segments were 43 tiles long: 5-12 % of warm-up.  One round: per-plan launches
