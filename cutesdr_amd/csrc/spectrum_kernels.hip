@@ -671,6 +671,7 @@ __global__ void spectrum_alpha_kernel(SpectrumArgs a)
             total++;
             if (ave_count < a.ave_size) ave_count++;
             if (total > a.ave_size) al = al - al / prev;
+            if (al == 0.f) break;                                      // (no averaging: the first frame already forgets everything)
         }
         a.alpha[(long)ch * a.nparts + g] = al;
         if (g == 0) a.alpha[(long)a.channels * a.nparts + ch] = (float)ave_after(a.nframes);
