@@ -151,3 +151,87 @@ def test_one_wave_per_channel_path_in_child_process():
             % (here, os.path.join(here, "test_randomized_gpu.py")))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_batch_chain_random_receivers(oracle, seed):
+    """A batch of receivers nobody hand-picked: random modes, random filter edges inside each mode's limits (so the
+    receivers fall into several decimator plan groups), random AGC settings (hang, slope, threshold, decay; a few with
+    the AGC off on manual gain), random carrier offsets and levels, two calls of random whole-window lengths -- each
+    receiver against its own oracle CDemodulator under the chain rule of test_postchain_gpu.py, burst by burst from
+    the first, the S-meters within 0.02 dB."""
+    import cutesdr_amd as ca
+    import test_postchain_gpu as T
+    from util_signals import fm_carrier, am_carrier, tones_plus_noise
+    rng = np.random.default_rng(4200 + seed)
+    fs, C = 2e6, 10
+    names = ["AM", "SAM", "FM", "USB", "LSB", "CWU"]
+    cfg = []
+    for c in range(C):
+        name = names[int(rng.integers(0, len(names)))] if c >= len(names) else names[c]
+        m, kw = T.MODES[name]
+        kw = dict(kw)
+        if name in ("AM", "SAM"):
+            hw = int(rng.integers(20, 80)) * 100                        # 2 .. 8 kHz either side
+            kw.update(HiCut=hw, LowCut=-hw)
+        elif name == "FM":
+            hw = int(rng.integers(50, 120)) * 100                       # 5 .. 12 kHz
+            kw.update(HiCut=hw, LowCut=-hw)
+        elif name == "USB":
+            kw.update(HiCut=int(rng.integers(18, 36)) * 100, LowCut=int(rng.integers(1, 3)) * 100)
+        elif name == "LSB":
+            kw.update(HiCut=-int(rng.integers(1, 3)) * 100, LowCut=-int(rng.integers(18, 36)) * 100)
+        else:
+            hw = int(rng.integers(2, 9)) * 100
+            kw.update(HiCut=hw, LowCut=-hw)
+        # (SAM keeps its AGC: with the loop pulling in on a carrier amplified by a fixed 30-50 dB, the start-up difference
+        # of its first burst scales with that gain -- 2e-3 ... 2e-2 of full scale -- and says nothing about the chain)
+        agc_on = name == "SAM" or rng.random() < 0.8
+        kw.update(AgcOn=int(agc_on), AgcHangOn=int(rng.random() < 0.3), AgcSlope=int(rng.integers(0, 11)),
+                  AgcThresh=int(rng.integers(-110, -30)), AgcDecay=int(rng.integers(30, 1500)),
+                  AgcManualGain=int(rng.integers(0, 31)))        # (a fixed 46-49 dB puts USB audio -- and with it the fp32
+                                                                  # rounding both sides differ by -- at 250 x full scale)
+        off = 100e3 + 700.0 * c + float(rng.integers(-200, 200))
+        dbfs = float(rng.uniform(-45.0, -8.0))
+        cfg.append((name, m, kw, off, dbfs))
+    calls = [19968 * int(rng.integers(8, 14)), 19968 * int(rng.integers(3, 9))]
+    n = sum(calls)
+    x = np.empty((C, n), dtype=np.complex64)
+    for c, (name, m, kw, off, dbfs) in enumerate(cfg):
+        if name == "FM":
+            s = fm_carrier(n, fs, off, dbfs=dbfs)
+        elif name in ("AM", "SAM"):
+            s = am_carrier(n, fs, off, dbfs=dbfs, channel=c)
+        else:
+            d = {"USB": 1100.0, "LSB": -1100.0, "CWU": 0.0}[name]
+            s = tones_plus_noise(9 + c, n, fs, [off + d, off + 1.6 * d + 250.0]) * 10 ** ((dbfs + 20.0) / 20.0)
+        x[c] = s.astype(np.complex64)
+    b = ca.DemodBatch(C, 2048)
+    b.set_input_rate(fs)
+    refs = []
+    for c, (name, m, kw, off, dbfs) in enumerate(cfg):
+        b.set_demod(c, m, T.info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, T.info(oracle, **kw)); r.SetDemodFreq(-off)
+        refs.append(r)
+    b.commit()
+    for c, (name, m, kw, off, dbfs) in enumerate(cfg):
+        b.set_freq(c, -off)
+    assert b.group_count()[0] >= 2                               # the receivers do spread over plan groups
+    a0, first = 0, [0] * C
+    for ncall in calls:
+        got = b.process(x[:, a0:a0 + ncall])
+        for c, (name, m, kw, off, dbfs) in enumerate(cfg):
+            want = refs[c].process_append(x[c, a0:a0 + ncall].astype(np.complex128))
+            assert len(got[c]) == len(want), (seed, c, name)        # (a narrow plan may not fill a hop in a short call)
+            if not len(want):
+                continue
+            errs = T.burst_errors(got[c], want)
+            # (SAM locking onto a carrier up to 200 Hz off its tuning: 3-6e-3 of full scale in the burst of the pull-in,
+            # 3-10e-4 in the next, 2e-6 from the third -- the chain rule's steady bound from burst 2 stands)
+            T.check_chain_bursts(errs, name, first[c], (seed, c, name, kw),
+                                 from_zero=(1.5e-2 * FULL_SCALE if name == "SAM" else T.FROM_ZERO))
+            first[c] += len(want) // 1024
+        a0 += ncall
+    sm = b.smeter_all()
+    for c in range(C):
+        assert abs(float(sm[c]) - refs[c].GetSMeterAve()) <= 0.02, (seed, c, cfg[c][0])
