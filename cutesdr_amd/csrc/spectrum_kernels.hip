@@ -493,13 +493,16 @@ void spectrum32_kernel(SpectrumArgs a)
     const int hB = t & 1, cB = (t >> 1) & 15, kaB = t >> 5;          // pass B: (ka, c, h)
     const v2f wA = tw1[t];                                            // W_N^t
     const v2f wB = tw1[16 * cB];                                      // W_512^c = W_N^{16 c}
-    v2f wH;                                                           // W_512^{16 c h} = W_32^{c h} = W_N^{256 c h}: quadrant of W_N
-    {
-        const int m = 256 * cB * hB;
-        v2f v = tw1[m & 1023];
-        const int q = (m >> 10) & 3;
-        if (q == 1) v = v2f{-v.y, v.x}; else if (q == 2) v = -v; else if (q == 3) v = v2f{v.y, -v.x};
-        wH = v;
+    v2f wH;                                                           // W_512^{16 c h} = W_32^{c h} = W_N^{256 c h}, c h < 16:
+    {                                                                 // the table holds an OCTANT of W_N at N = 8192 (W_N^1024 = e^{j pi/4})
+        const int m = 256 * cB * hB;                                  // < 4096: up to three eighth turns beyond the table entry
+        const v2f v = tw1[m & 1023];
+        const int o = (m >> 10) & 3;
+        constexpr float r = 0.70710678118654752440f;
+        if (o == 0) wH = v;
+        else if (o == 1) wH = v2f{r * (v.x - v.y), r * (v.x + v.y)};
+        else if (o == 2) wH = v2f{-v.y, v.x};
+        else wH = v2f{-r * (v.x + v.y), r * (v.x - v.y)};
     }
     const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
     float *sum = a.sum + (long)ch * N, *pwr = a.pwr + (long)ch * N, *ave = a.ave + (long)ch * N;
