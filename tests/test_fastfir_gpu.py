@@ -33,7 +33,7 @@ def test_batch_matches_oracle_shared_filter(oracle, n):
         assert err <= TOL * np.abs(x[c]).max(), (c, err)
 
 
-@pytest.mark.parametrize("n,C,hops", [(2048, 16, 37), (2048, 24, 5), (16384, 8, 5)])
+@pytest.mark.parametrize("n,C,hops", [(2048, 16, 37), (2048, 24, 5), (4096, 16, 21), (4096, 24, 5), (8192, 8, 9), (16384, 8, 5)])
 def test_batch_channel_counts_that_are_multiples_of_eight(oracle, n, C, hops):
     """With eight channels or a multiple, the runs of a channel are laid over the workgroup index so that they share
     an XCD (the other branch of the kernels' index mapping); a prime hop count gives ragged runs."""
@@ -52,7 +52,7 @@ def test_batch_channel_counts_that_are_multiples_of_eight(oracle, n, C, hops):
         assert np.abs(y[c] - ref).max() <= TOL * np.abs(x[c]).max(), c
 
 
-@pytest.mark.parametrize("n", [2048, 16384])
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
 def test_batch_distinct_filters_and_response(oracle, n):
     """(both sizes that have a kernel of their own: 16384 the pipelined one, 2048 the 128-thread one)"""
     import cutesdr_amd as ca
@@ -73,7 +73,7 @@ def test_batch_distinct_filters_and_response(oracle, n):
         assert np.abs(y[c] - ref).max() <= TOL * np.abs(x[c]).max()
 
 
-@pytest.mark.parametrize("n", [2048, 16384])
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
 def test_batch_streaming_state_and_run_lengths(oracle, n):
     import cutesdr_amd as ca
     C, fs = 2, 62500.0
