@@ -260,3 +260,20 @@ def test_fft_batch_many_frames_are_split_into_groups(oracle, ave, n):
                 refs[c].PutInDisplayFFT(x[c, k * n:(k + 1) * n])
             assert b.total_count(c) == (frames * (call + 1) if call < 2 else frames)    # (SetFFTAve resets, fft.cpp:103-113)
             assert_spectrum_close(b.ave_buf(c).astype(np.float64), refs[c].ave_buf())
+
+
+def test_fft_batch_one_channel_many_groups(oracle):
+    """One channel, 600 frames of 2048 points in a call: 75 frame groups -- more than the 64 threads of the kernel that
+    computes the groups' averaging weights (it takes them in rounds) -- against the frame-by-frame oracle, two calls."""
+    import cutesdr_amd as ca
+    n, frames, fs, ave = 2048, 600, 2e6, 7
+    b = ca.FftBatch(1)
+    b.set_params(n, False, 0.0, fs); b.set_ave(ave)
+    r = oracle.CFft(); r.SetFFTParams(n, False, 0.0, fs); r.SetFFTAve(ave)
+    for call in range(2):
+        x = tones_plus_noise(300 + call, frames * n, fs, [333e3, -120e3 + 70e3 * call])[None, :]
+        b.put_display(x)
+        for k in range(frames):
+            r.PutInDisplayFFT(x[0, k * n:(k + 1) * n])
+        assert b.total_count(0) == frames * (call + 1)
+        assert_spectrum_close(b.ave_buf(0).astype(np.float64), r.ave_buf())
