@@ -277,3 +277,24 @@ def test_fft_batch_one_channel_many_groups(oracle):
             r.PutInDisplayFFT(x[0, k * n:(k + 1) * n])
         assert b.total_count(0) == frames * (call + 1)
         assert_spectrum_close(b.ave_buf(0).astype(np.float64), r.ave_buf())
+
+
+@pytest.mark.parametrize("n", [512, 1024, 32768])
+def test_fft_batch_many_frames_multi_kernel_sizes(oracle, n):
+    """Many frames per call at the sizes that do not take a single-pass kernel (below 2048, above 16384): two calls,
+    the average warming up inside the first."""
+    import cutesdr_amd as ca
+    C, frames, fs, ave = 2, 40, 2e6, 5
+    b = ca.FftBatch(C)
+    b.set_params(n, False, 0.0, fs); b.set_ave(ave)
+    refs = []
+    for c in range(C):
+        r = oracle.CFft(); r.SetFFTParams(n, False, 0.0, fs); r.SetFFTAve(ave); refs.append(r)
+    for call in range(2):
+        x = np.stack([tones_plus_noise(400 + c + 5 * call, frames * n, fs, [150e3 * (c + 1), -300e3]) for c in range(C)])
+        b.put_display(x)
+        for c in range(C):
+            for k in range(frames):
+                refs[c].PutInDisplayFFT(x[c, k * n:(k + 1) * n])
+            assert b.total_count(c) == frames * (call + 1)
+            assert_spectrum_close(b.ave_buf(c).astype(np.float64), refs[c].ave_buf())
