@@ -119,7 +119,7 @@ def _pack24(x):
     return np.concatenate([np.zeros((b3.shape[0], 4), dtype=np.uint8), b3], axis=1)
 
 
-@pytest.mark.parametrize("blanker", [True, False], ids=["blanker", "no-blanker"])
+@pytest.mark.parametrize("blanker", [10.0, 11.0, 0.0], ids=["blanker-odd-delay", "blanker-even-delay", "no-blanker"])
 @pytest.mark.parametrize("pkt_len", [1028, 1444])
 def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
     """Datagrams -> [blanker ->] down-converter -> FastFIR -> AGC -> demodulator on the device
@@ -129,6 +129,8 @@ def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
     import cutesdr_amd as ca
     from util_signals import fm_carrier, am_carrier, FULL_SCALE
     import test_postchain_gpu as T
+    width = blanker or 10.0                                   # 20 / 22 samples at 2 MS/s: the delayed sample the blanked
+                                                              # down-converter fetches is 11 (odd) / 12 (even) behind
     per = 240 if pkt_len == 1444 else 256
     fs, C = 2e6, 3
     npk = 19968 * 32 // per if per == 256 else 19968 * 30 // per          # whole windows of the chain per call
@@ -145,14 +147,14 @@ def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
     b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
     nb = None
     if blanker:
-        nb = ca.NoiseProcBatch(C); nb.setup(True, 30.0, 10.0, fs)
+        nb = ca.NoiseProcBatch(C); nb.setup(True, 30.0, width, fs)
     refs, rnb = [], []
     for c, (name, f) in enumerate((("FM", -100e3), ("AM", -101e3), ("CWU", -102e3))):
         m, kw = T.MODES[name]
         b.set_demod(c, m, T.info(ca, **kw))
         r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, T.info(oracle, **kw)); r.SetDemodFreq(f)
         refs.append(r)
-        q = oracle.CNoiseProc(); q.SetupBlanker(blanker, 30.0, 10.0, fs); rnb.append(q)
+        q = oracle.CNoiseProc(); q.SetupBlanker(bool(blanker), 30.0, width, fs); rnb.append(q)
     b.commit()
     b.set_freq(0, -100e3); b.set_freq(1, -101e3); b.set_freq(2, -102e3)
     first = [0, 0, 0]
