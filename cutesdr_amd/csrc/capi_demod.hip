@@ -1095,6 +1095,39 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     if (rc < 0) return rc;
     return demod_batch_run(b, b->d_blank, b->raw_cap, (int)n, d_out, out_stride, stream, false);
 }
+/* The strict / pipelined pass on fp32 rows with CNoiseProc's blanker in front (what CSdrInterface::ProcessIQData runs in
+ * place before the chain, sdrinterface.cpp:884), FUSED like the datagram form: the blanker kernel leaves one bit per sample,
+ * the down-converter takes the delayed sample from d_in itself and zeroes it under the mask -- no blanked copy of the
+ * input is written or read. */
+int csdr_demod_batch_process_blanked(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                                     struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride, void *stream)
+{
+    if (!b || !d_in || !d_out || !nb || n_per_channel < 0) return fail(CSDR_EINVAL, "bad argument");
+    if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (n_per_channel == 0) return CSDR_OK;
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    for (size_t ki = 0; ki < b->cores.size(); ki++)          // rows shared between receivers would be blanked once per reader
+        for (size_t q = 0; q < b->members[ki].size(); q++)
+            if (b->members[ki][q] >= 0 && b->in_row[b->members[ki][q]] != b->members[ki][q])
+                return fail(CSDR_ESTATE, "process_blanked: every receiver reads its own row (csdr_demod_batch_set_input_rows is off)");
+    const long n = n_per_channel;
+    if (b->pipelined)                                         // (the single-buffered mask, as in process_packets)
+        for (size_t ki = 0; ki < b->cores.size(); ki++)
+            if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
+    const long words = (n + 31) / 32 + 64;
+    if (words > b->mask_cap) {
+        CSDR_HIP(hipDeviceSynchronize());
+        if (b->d_mask) (void)hipFree(b->d_mask);
+        b->d_mask = nullptr; b->mask_cap = 0;
+        CSDR_HIP(hipMalloc((void **)&b->d_mask, (size_t)b->channels * words * sizeof(unsigned)));
+        b->mask_cap = words;
+    }
+    b->blank.mask = b->d_mask; b->blank.mask_stride = b->mask_cap;
+    int rc = csdr__noiseproc_batch_mask(nb, d_in, in_stride, nullptr, 0, 0, (int)n, b->d_mask, b->mask_cap,
+                                        &b->blank.state, &b->blank.hist, stream);
+    if (rc < 0) return rc;
+    return demod_batch_run(b, d_in, in_stride, (int)n, d_out, out_stride, stream, false, nullptr, 0, &b->blank);
+}
 int csdr_demod_batch_group_count(csdr_demod_batch *b, int *rows)
 {
     if (!b) return fail(CSDR_EINVAL, "bad handle");

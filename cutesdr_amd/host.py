@@ -644,6 +644,20 @@ class DemodBatch(_Obj):
         flat = dout.download(np.float32, self.channels * cap).reshape(self.channels, cap)
         return [flat[c, :check(lib().csdr_demod_batch_out_count(self.h, c))].copy() for c in range(self.channels)]
 
+    def process_blanked(self, x, blanker):
+        """x complex [channels, T] -> list of audio rows, CNoiseProc's blanker (a NoiseProcBatch) fused in front"""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        assert x.shape[0] == self.channels
+        T = x.shape[1]
+        cap = T // 8 + self.n + 4096
+        din, dout = DeviceBuffer(x.nbytes, self.device), DeviceBuffer(self.channels * cap * 4, self.device)
+        din.upload(x)
+        check(lib().csdr_demod_batch_process_blanked(self.h, C.c_void_p(din.ptr), T, T, blanker.h, C.c_void_p(dout.ptr), cap,
+                                                     None), "csdr_demod_batch_process_blanked")
+        sync(self.device)
+        flat = dout.download(np.float32, self.channels * cap).reshape(self.channels, cap)
+        return [flat[c, :check(lib().csdr_demod_batch_out_count(self.h, c))].copy() for c in range(self.channels)]
+
     def process(self, x, stereo=False):
         """x complex [channels, T] -> list of audio rows (float32 mono, or complex64 with stereo=True)"""
         x = np.ascontiguousarray(x, dtype=np.complex64)

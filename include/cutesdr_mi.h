@@ -345,6 +345,14 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
                                      struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride,
                                      void *stream);
 
+/* csdr_demod_batch_process with CNoiseProc's blanker in front (interface/sdrinterface.cpp:884 runs it in place before
+ * the chain), fused: the blanker pass leaves one bit per sample and the down-converter zeroes the delayed sample under
+ * it in its own load -- no blanked copy of d_in exists.  nb: as many channels as b; every receiver reads its own row
+ * (not with csdr_demod_batch_set_input_rows).  The two-pass equivalent: csdr_noiseproc_batch_process into a buffer of
+ * the caller's, then csdr_demod_batch_process on that. */
+int csdr_demod_batch_process_blanked(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
+                                     struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride, void *stream);
+
 /* ----------------------------------------------------------------------------------------
  * CFft -- display spectrum and plain transforms (dsp/fft.h:24-85).  FFT sizes 512..65536 as in
  * the reference (clamped to that range, fft.cpp:140-145); a size that is not a power of two

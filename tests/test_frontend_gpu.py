@@ -175,6 +175,44 @@ def test_packets_to_audio_whole_front_end(oracle, pkt_len, blanker):
             first[c] += len(want) // 1024
 
 
+@pytest.mark.parametrize("width", [10.0, 11.0], ids=["odd-delay", "even-delay"])
+def test_float_rows_with_fused_blanker(oracle, width):
+    """csdr_demod_batch_process_blanked: fp32 rows, the blanker's mask pass and the down-converter that zeroes the
+    delayed sample under it -- against the oracle's blanker followed by its chain, FM / AM / CW receivers (three plan
+    groups), two calls, every burst under the chain rule."""
+    import cutesdr_amd as ca
+    from util_signals import fm_carrier, am_carrier, tones_plus_noise
+    import test_postchain_gpu as T
+    fs, C = 2e6, 3
+    n = 19968 * 30
+    sig = [fm_carrier(2 * n, fs, 100e3, dbfs=-20.0), am_carrier(2 * n, fs, 101e3, dbfs=-20.0, channel=1),
+           tones_plus_noise(12, 2 * n, fs, [102e3, 102e3 + 300.0])]
+    rng = np.random.default_rng(6)
+    for x in sig:
+        x[rng.random(2 * n) < 5e-5] += 30000.0
+    xs = np.stack([x.astype(np.complex64) for x in sig])
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    nb = ca.NoiseProcBatch(C); nb.setup(True, 30.0, width, fs)
+    refs, rnb = [], []
+    for c, (name, f) in enumerate((("FM", -100e3), ("AM", -101e3), ("CWU", -102e3))):
+        m, kw = T.MODES[name]
+        b.set_demod(c, m, T.info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, T.info(oracle, **kw)); r.SetDemodFreq(f)
+        refs.append(r)
+        q = oracle.CNoiseProc(); q.SetupBlanker(True, 30.0, width, fs); rnb.append(q)
+    b.commit()
+    b.set_freq(0, -100e3); b.set_freq(1, -101e3); b.set_freq(2, -102e3)
+    first = [0, 0, 0]
+    for call in range(2):
+        part = xs[:, call * n:(call + 1) * n]
+        got = b.process_blanked(part, nb)
+        for c in range(C):
+            want = refs[c].process_append(rnb[c].ProcessBlanker(part[c].astype(np.complex128)))
+            assert len(got[c]) == len(want) and len(want) % 1024 == 0 and len(want) > 0, c
+            T.check_chain_bursts(T.burst_errors(got[c], want), ("FM", "AM", "CWU")[c], first[c], (c, call), fm_late=1)
+            first[c] += len(want) // 1024
+
+
 @pytest.mark.parametrize("fs,width", [(2e6, 20.0), (2000200.0, 21.0)], ids=["odd-lags", "even-lags"])
 @pytest.mark.parametrize("pkt_len", [1028, 1444])
 def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len, fs, width):
