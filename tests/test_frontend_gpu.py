@@ -431,3 +431,48 @@ def test_pipelined_packets_with_blanker_give_the_strict_mode_words():
         for c in range(Cn):
             assert len(outs[0][k][c]) > 0
             assert np.array_equal(outs[0][k][c].view(np.uint32), outs[1][k][c].view(np.uint32)), (k, c)
+
+
+def test_blanked_down_converter_runtime_plan_gives_the_compiled_plans_words():
+    """The down-converter that applies the blanker's mask exists as a compiled-plan kernel per decimator sequence and as
+    the run-time-plan kernel a sequence outside the table takes: the fused chain from fp32 rows and from 24-bit
+    datagrams must give the same audio words through either (csdr__downconv_force_dynamic), FM / AM / CW receivers."""
+    import ctypes as C_
+    import cutesdr_amd as ca
+    from util_signals import fm_carrier, am_carrier, tones_plus_noise
+    import test_postchain_gpu as T
+    L = ca.lib()
+    L.csdr__downconv_force_dynamic.restype = C_.c_int
+    L.csdr__downconv_force_dynamic.argtypes = [C_.c_int]
+    fs, C = 2e6, 3
+    npk = 19968 * 30 // 240
+    n = npk * 240
+    sig = [fm_carrier(n, fs, 100e3, dbfs=-20.0), am_carrier(n, fs, 101e3, dbfs=-20.0, channel=1),
+           tones_plus_noise(12, n, fs, [102e3, 102e3 + 300.0])]
+    rng = np.random.default_rng(8)
+    for x in sig:
+        x[rng.random(n) < 5e-5] += 30000.0
+    raw = np.stack([_pack24(x) for x in sig])
+    xs = np.stack([x.astype(np.complex64) for x in sig])
+    outs = []
+    try:
+        for dyn in (0, 1):
+            L.csdr__downconv_force_dynamic(dyn)
+            res = []
+            for form in ("rows", "packets"):
+                b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+                for c, name in enumerate(("FM", "AM", "CWU")):
+                    m, kw = T.MODES[name]
+                    b.set_demod(c, m, T.info(ca, **kw))
+                b.commit()
+                for c in range(C):
+                    b.set_freq(c, -100e3 - 1000.0 * c)
+                nb = ca.NoiseProcBatch(C); nb.setup(True, 30.0, 10.0, fs)
+                res.append(b.process_blanked(xs, nb) if form == "rows" else b.process_packets(raw, 1444, nb))
+            outs.append(res)
+    finally:
+        L.csdr__downconv_force_dynamic(0)
+    for f in range(2):
+        for c in range(C):
+            assert len(outs[0][f][c]) == len(outs[1][f][c]) > 0
+            assert np.array_equal(outs[0][f][c], outs[1][f][c]), (f, c, np.abs(outs[0][f][c] - outs[1][f][c]).max())
