@@ -476,3 +476,57 @@ def test_blanked_down_converter_runtime_plan_gives_the_compiled_plans_words():
         for c in range(C):
             assert len(outs[0][f][c]) == len(outs[1][f][c]) > 0
             assert np.array_equal(outs[0][f][c], outs[1][f][c]), (f, c, np.abs(outs[0][f][c] - outs[1][f][c]).max())
+
+
+def test_pipelined_blanked_rows_give_the_strict_mode_words():
+    """csdr_demod_batch_process_blanked in pipelined mode (the mask buffer is single-buffered and the blanker's history
+    halves alternate: call k+1's blanker must order itself behind call k's down-converters): four calls back to back
+    without host synchronisation, every audio word equal to the strict mode's."""
+    import ctypes as C_
+    import cutesdr_amd as ca
+    from util_signals import fm_carrier, am_carrier
+    import test_postchain_gpu as T
+    L = ca.lib()
+    fs, Cn, calls = 2e6, 6, 4
+    n = 19968 * 8
+    names = ["FM", "AM", "USB"]
+    rng = np.random.default_rng(23)
+    xs = []
+    for c in range(Cn):
+        x = (fm_carrier if c % 3 == 0 else am_carrier)(calls * n, fs, 100e3 + 900.0 * c, dbfs=-20.0, channel=c)
+        x[rng.random(calls * n) < 5e-5] += 30000.0
+        xs.append(x.astype(np.complex64))
+    xs = np.stack(xs)
+    outs = []
+    for pipelined in (False, True):
+        b = ca.DemodBatch(Cn, 2048); b.set_input_rate(fs)
+        for c in range(Cn):
+            m, kw = T.MODES[names[c % 3]]
+            b.set_demod(c, m, T.info(ca, **kw))
+        b.commit()
+        for c in range(Cn):
+            b.set_freq(c, -(100e3 + 900.0 * c))
+        nb = ca.NoiseProcBatch(Cn); nb.setup(True, 30.0, 10.0, fs)
+        if pipelined:
+            b.set_pipelined(True)
+        cap = n // 8
+        dins = []
+        for k in range(calls):
+            part = np.ascontiguousarray(xs[:, k * n:(k + 1) * n])
+            d = ca.DeviceBuffer(part.nbytes); d.upload(part); dins.append(d)
+        dout = ca.DeviceBuffer(4 * Cn * cap * calls)
+        ca.sync()
+        counts = []
+        for k in range(calls):
+            rc = L.csdr_demod_batch_process_blanked(b.h, C_.c_void_p(dins[k].ptr), n, n, nb.h,
+                                                    C_.c_void_p(dout.ptr + 4 * Cn * cap * k), cap, None)
+            assert rc == 0
+            counts.append([b.out_count(c) for c in range(Cn)])
+        b.flush()
+        ca.sync()
+        y = dout.download(np.float32, Cn * cap * calls).reshape(calls, Cn, cap)
+        outs.append([[y[k, c, :counts[k][c]].copy() for c in range(Cn)] for k in range(calls)])
+    for k in range(calls):
+        for c in range(Cn):
+            assert len(outs[0][k][c]) > 0
+            assert np.array_equal(outs[0][k][c].view(np.uint32), outs[1][k][c].view(np.uint32)), (k, c)
