@@ -485,7 +485,7 @@ def to_c128(x_dev_row):
     return a[:, 0] + 1j * a[:, 1]
 
 
-def spectrum_c1(torch, ca, ctx, x, with_cpu):
+def spectrum_c1(torch, ca, ctx, x, with_cpu, check=True):
     """BASELINE config C1's transform (dsp/fft.cpp:267-288: 4096 points, Hann, ave 1) on every channel of the
     resident buffer x [C, T, 2]: 512 frames per channel and launch.  SURVEY 8(d) prices a bin at 8 B in + 4 B out;
     the kernel keeps the running sums in registers and writes only the LAST frame's bels, so both fractions are
@@ -520,11 +520,24 @@ def spectrum_c1(torch, ca, ctx, x, with_cpu):
                 f.PutInDisplayFFT(xs[i:i + N])
         v, n = cpu_rate(once, len(xs), 2.0)
         out["cpu_baseline"] = cpu_obj(v, n, "CFft::PutInDisplayFFT, 4096-pt frames of channel 0 (BASELINE configs[0])")
+    if check:                                             # no averaging: the display holds the call's LAST frame
+        import numpy as np
+        from oracle import oracle as orc
+        torch.cuda.synchronize()
+        c = C // 3
+        r = orc.CFft(); r.SetFFTParams(N, False, 0.0, C4_FS); r.SetFFTAve(1)
+        r.PutInDisplayFFT(to_c128(x[c, (frames - 1) * N:frames * N]))
+        want = np.asarray(r.ave_buf())
+        got = fb.ave_buf(c).astype(np.float64)
+        near = want > want.max() - 6.0
+        err = float(np.abs(got - want)[near].max())
+        out["parity_checked"] = {"channel": c, "bins_within_60dB_of_peak": int(near.sum()), "max_err_bels": err, "tolerance_bels": 0.001,
+                                 "ok": bool(err <= 0.001)}
     del fb
     return out
 
 
-def input_rate_kernels(torch, ca, ctx, x, with_cpu):
+def input_rate_kernels(torch, ca, ctx, x, with_cpu, check=True):
     """The two input-rate kernels of the path alone on the resident buffer x [C, T, 2]: K2, the down-converter (one plan
     group of all C receivers: 2 MSPS, FM bandwidth -> chain 11,11,15,19,31, 62.5 kS/s; 8 B in + 8 B out / 32 per
     sample) and K6, the noise blanker (8 B in + 8 B out per sample), each with the oracle on one host core."""
@@ -544,6 +557,26 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
                           "raw_input_MSamples_per_s": round(C * T / ms / 1e3, 1),
                           "roofline": roofline_obj(alg / ms / 1e6, ms, "csdr::downconv_kernel<DcPlanT<11,11,15,19,31>>", alg, None),
                           "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
+    if check:                                             # a FRESH object, one call on the timed buffer, receiver C/3 vs the oracle
+        import numpy as np
+        from oracle import oracle as orc
+        c = C // 3
+        dc2 = ca.DownConvertBatch(C, device=ctx.local)
+        dc2.set_data_rate(C4_FS, 15000.0)
+        for k in range(C):
+            dc2.set_frequency(-100e3 - 500.0 * k, channel=k)
+        dc2.process_ptr(x.data_ptr(), T, T, y.data_ptr(), T // 16, st)
+        torch.cuda.synchronize()
+        got = y[c, :T // 32].cpu().numpy().astype(np.float64)
+        r = orc.CDownConvert(); r.SetDataRate(C4_FS, 15000.0); r.SetFrequency(-100e3 - 500.0 * c)
+        xc = to_c128(x[c])                                # (the reference's call pattern: m_InBufLimit windows)
+        want = np.concatenate([np.asarray(r.ProcessData(xc[i:i + 19968])) for i in range(0, len(xc), 19968)])
+        m = min(len(want), T // 32)
+        err = float(np.abs((got[:m, 0] + 1j * got[:m, 1]) - want[:m]).max() / 32767.0) if m else float("inf")
+        out["downconv_k2"]["parity_checked"] = {"receiver": c, "samples": int(T), "outputs_compared": int(m),
+                                                "max_err_over_full_scale": err, "tolerance": 1e-5,
+                                                "ok": bool(m >= T // 32 - 1 and err <= 1e-5)}
+        del dc2
     del y, dc
     nb = ca.NoiseProcBatch(C, device=ctx.local)
     nb.setup(True, 50.0, 2.0, C4_FS)
@@ -554,6 +587,24 @@ def input_rate_kernels(torch, ca, ctx, x, with_cpu):
                          "MSamples_per_s": round(C * T / ms / 1e3, 1),
                          "roofline": roofline_obj(C * T * 16.0 / ms / 1e6, ms, "csdr::noiseblank_kernel", C * T * 16.0, None),
                          "frac_of_hbm_peak": round(C * T * 16.0 / ms / 1e6 / HBM_PEAK_GBS, 4), "cpu_baseline": None}
+    if check:                                             # fresh object, two calls (history across them), sample-exact
+        import numpy as np
+        from oracle import oracle as orc
+        c = C // 3
+        nb2 = ca.NoiseProcBatch(C, device=ctx.local)
+        nb2.setup(True, 50.0, 2.0, C4_FS)
+        q = orc.CNoiseProc(); q.SetupBlanker(True, 50.0, 2.0, C4_FS)
+        xc = to_c128(x[c])
+        same, blanked = True, 0
+        for _ in range(2):
+            nb2.process_ptr(x.data_ptr(), T, T, xb.data_ptr(), T, st)
+            torch.cuda.synchronize()
+            got = xb[c].cpu().numpy()
+            want = np.asarray(q.ProcessBlanker(xc)).astype(np.complex64)
+            same = same and bool(np.array_equal(got[:, 0] + 1j * got[:, 1], want))
+            blanked += int((want == 0).sum())
+        out["blanker_k6"]["parity_checked"] = {"receiver": c, "samples": int(2 * T), "samples_blanked": blanked, "sample_exact": same, "ok": same}
+        del nb2
     del xb, nb
     if with_cpu:
         from oracle import oracle as orc
@@ -1181,8 +1232,8 @@ def run_rank(args):
             if ctx.rank == 0:
                 extra["chain_c4"] = s
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
-                extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu)
-                extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu))
+                extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check)
+                extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check))
                 extra["packets_chain"] = packets_chain(torch, ca, ctx, c4)
             del c4
             torch.cuda.empty_cache()
