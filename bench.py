@@ -443,7 +443,7 @@ def gpu_ms(torch, fn, warm, reps):
 FULL_SCALE = 32767.0
 
 
-def chain_burst_check(got, want, mode, hop=1024):
+def chain_burst_check(got, want, mode, hop=1024, fm_late=0):
     """The chain rule the parity tests apply burst by burst (tests/test_postchain_gpu.py: check_chain_bursts; a burst =
     one FastFIR hop of audio: 1024 samples behind the 2048-point filter, 8192 behind the 16384-point one), on the common prefix of the product's audio and the oracle's.  FM: 1e-3 of
     full scale from the 4th burst, 3e-5 from the 7th (its first bursts demodulate the filter's start-up, DESIGN
@@ -455,7 +455,7 @@ def chain_burst_check(got, want, mode, hop=1024):
     e = np.abs(np.asarray(got[:n], dtype=np.float64) - np.asarray(want[:n], dtype=np.float64)).reshape(-1, hop).max(axis=1) / FULL_SCALE
     idx = np.arange(len(e))
     if mode == "FM":
-        early, steady, t_early, t_steady = e[(idx >= 3) & (idx < 6)], e[idx >= 6], 1e-3, 3e-5
+        early, steady, t_early, t_steady = e[(idx >= 3 + fm_late) & (idx < 6 + fm_late)], e[idx >= 6 + fm_late], 1e-3, 3e-5
     else:
         early, steady, t_early, t_steady = e[idx < 2], e[idx >= 2], 5e-4, 2e-5
     ok = bool((early <= t_early).all() and (steady <= t_steady).all())
@@ -654,7 +654,7 @@ def datagrams_of(torch, x, npk):
     return pk
 
 
-def packets_chain(torch, ca, ctx, c4):
+def packets_chain(torch, ca, ctx, c4, check=True):
     """The C4 share fed with the radio's own 24-bit datagrams (interface/netiobase.cpp:479-527: 6 B per sample instead
     of 8) -- no unpack pass, the down-converter decodes them in its loads -- and the same with CNoiseProc's blanker in
     front (interface/sdrinterface.cpp:884), FUSED: the blanker kernel leaves one bit per sample, the down-converter takes
@@ -684,6 +684,10 @@ def packets_chain(torch, ca, ctx, c4):
     out["mask_kernel"] = {"config": "the blanker pass of that chain alone: %d receivers x %d datagrams in, one bit per sample out" % (C, npk),
                           "ms_per_launch": round(ms, 4),
                           "roofline": roofline_obj(alg / ms / 1e6, ms, "csdr::noiseblank_kernel<true, true>", alg, None)}
+    if check:
+        out["parity_checked"] = {"datagrams": c4.parity_check(packets=(pk, npk)),
+                                 "datagrams_with_blanker": c4.parity_check(packets=(pk, npk), blanker=True)}
+        out["parity_checked"]["ok"] = bool(out["parity_checked"]["datagrams"]["ok"] and out["parity_checked"]["datagrams_with_blanker"]["ok"])
     del nb, pk, mask
     return out
 
@@ -1089,16 +1093,28 @@ class C4Workload:
         self.b = self.make_batch(pipelined)
         self.mode = want
 
-    def parity_check(self, receivers=(0, 1, 2)):
+    def parity_check(self, receivers=(0, 1, 2), packets=None, blanker=False):
         """The buffer that was just timed through a FRESH batch object of all the receivers, one call of 2^21 samples
         (not a multiple of m_InBufLimit = 19968), receivers 0-2 (AM, FM, USB) against the oracle's CDemodulator on the
         same samples -- the chain rule of the parity tests, burst by burst, on the common prefix (the oracle holds back
-        its last partial window)."""
+        its last partial window).  packets = (datagram tensor, datagrams per call): the same through
+        csdr_demod_batch_process_packets, with CNoiseProc's blanker in front on both sides when blanker is set (the FM
+        bounds then start one burst later: impulses into an empty delay line)."""
         from oracle import oracle as orc
+        import numpy as np
         torch = self.torch
         b = self.make_batch(False)
         aud = torch.zeros_like(self.aud)
-        b.process_ptr(self.x.data_ptr(), self.T, self.T, aud.data_ptr(), self.cap, self.stream)
+        if packets is None:
+            b.process_ptr(self.x.data_ptr(), self.T, self.T, aud.data_ptr(), self.cap, self.stream)
+        else:
+            pk, npk = packets
+            nb = self.ca.NoiseProcBatch(self.C, device=self.ctx.local) if blanker else None
+            if nb is not None:
+                nb.setup(True, 50.0, 2.0, C4_FS)
+            rc = self.ca.lib().csdr_demod_batch_process_packets(b.h, pk.data_ptr(), npk, 1444, nb.h if nb is not None else None,
+                                                              aud.data_ptr(), self.cap, self.stream)
+            assert rc == 0, self.ca._capi.last_error()
         torch.cuda.synchronize()
         base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
                     FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
@@ -1112,9 +1128,16 @@ class C4Workload:
             r = orc.CDemodulator(2048)
             r.SetInputSampleRate(C4_FS); r.SetDemod(m, orc.DemodInfo(**dict(base, **kw)))
             r.SetDemodFreq(-(100e3 + 500.0 * ((lo + c) % 1024)))
-            want = r.process_append(to_c128(self.x[c]))
+            if packets is None:
+                xin = to_c128(self.x[c])
+            else:
+                xin = np.asarray(orc.unpack_packets(packets[0][c].cpu().numpy(), 1444), dtype=np.complex128)
+                if blanker:
+                    q = orc.CNoiseProc(); q.SetupBlanker(True, 50.0, 2.0, C4_FS)
+                    xin = np.asarray(q.ProcessBlanker(xin))
+            want = r.process_append(xin)
             got = aud[c, :b.out_count(c)].cpu().numpy()
-            chk = dict(chain_burst_check(got, want, name), receiver=c, mode=name)
+            chk = dict(chain_burst_check(got, want, name, fm_late=1 if blanker else 0), receiver=c, mode=name)
             ok = ok and chk["ok"]
             res.append(chk)
         del b, aud
@@ -1234,7 +1257,7 @@ def run_rank(args):
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
                 extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check)
                 extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check))
-                extra["packets_chain"] = packets_chain(torch, ca, ctx, c4)
+                extra["packets_chain"] = packets_chain(torch, ca, ctx, c4, check=not args.no_check)
             del c4
             torch.cuda.empty_cache()
             if ctx.world == 1:
