@@ -17,7 +17,8 @@ def impulsive(seed, n, fs, rate=2e-4):
     return x.astype(np.complex64).astype(np.complex128)     # fp32-representable: both sides see the same values
 
 
-@pytest.mark.parametrize("fs,thresh,width", [(2e6, 50.0, 2.0), (2e6, 20.0, 100.0), (500e3, 80.0, 3000.0), (6e6, 35.0, 10.0)])
+@pytest.mark.parametrize("fs,thresh,width", [(2e6, 50.0, 2.0), (2e6, 20.0, 100.0), (500e3, 80.0, 3000.0), (6e6, 35.0, 10.0),
+                                             (2e6, 40.0, 2040.0)])   # (4080 samples of blanking: two tiles of warm-up per segment)
 def test_blanker_matches_oracle_across_calls(oracle, fs, thresh, width):
     import cutesdr_amd as ca
     g, r = ca.CNoiseProc(), oracle.CNoiseProc()
@@ -30,7 +31,7 @@ def test_blanker_matches_oracle_across_calls(oracle, fs, thresh, width):
         got, want = g.ProcessBlanker(x[a:b]), r.ProcessBlanker(x[a:b])
         assert np.array_equal(got, want), (a, b, np.nonzero(got != want)[0][:5])
         blanked += int((want == 0).sum())
-    assert 0 < blanked < 375000                               # the case actually blanks, and not everything
+    assert 0 < blanked < len(x)                               # the case actually blanks, and not everything
 
 
 def test_blanker_off_passes_data_and_setup_quirk(oracle):
@@ -254,8 +255,8 @@ def test_blanker_reading_datagrams_is_sample_exact(oracle, pkt_len, fs, width):
             assert np.array_equal(got[c], want.astype(np.complex64)), (npk, c)
 
 
-@pytest.mark.parametrize("fs,width", [(2e6, 20.0), (2000200.0, 21.0), (500e3, 100.0), (6e6, 10.0)],
-                         ids=["ring-odd-lag", "ring-even-lag", "window-below-a-tile", "window-beyond-the-ring"])
+@pytest.mark.parametrize("fs,width", [(2e6, 20.0), (2000200.0, 21.0), (500e3, 100.0), (6e6, 10.0), (2e6, 2040.0)],
+                         ids=["ring-odd-lag", "ring-even-lag", "window-below-a-tile", "window-beyond-the-ring", "ring-widest-blank"])
 @pytest.mark.parametrize("src", ["rows", 1028, 1444])
 def test_blank_mask_is_bit_exact(oracle, src, fs, width):
     """The blanker's MASK form (what csdr_demod_batch_process_packets runs in front of the fused down-converter): one
@@ -319,7 +320,7 @@ def test_blank_mask_is_bit_exact(oracle, src, fs, width):
             assert np.array_equal(got, want), (npk, c, np.nonzero(got != want)[0][:5])
             blanked += int(bits.sum())
         k0 += npk
-    assert 0 < blanked < tot                                   # the case blanks, and not everything
+    assert 0 < blanked < Cn * tot                              # the case blanks, and not everything
 
 
 @pytest.mark.parametrize("seed", range(8))
