@@ -490,3 +490,51 @@ def test_calls_of_the_bench_length_not_a_multiple_of_the_window(oracle, pipeline
         assert 0 <= len(g) - len(w) <= 2 * 1024, (name, len(g), len(w))    # the oracle: whole windows only
         assert len(w) >= 62 * 1024
         check_chain_bursts(burst_errors(g[:len(w)], w), name if name == "FM" else "other", 0, (name, "2^21-sample calls"))
+
+
+@pytest.mark.parametrize("squelch", [35, 60, 90])
+def test_fm_squelch_open_closed_and_opening_in_the_batch_chain(oracle, squelch):
+    """FM receivers with the squelch set (fmdemod.cpp:113-152): a carrier throughout (open), noise only (closed: zeros),
+    a carrier that starts a third into the stream and stops at two thirds (closed, opening, closing again) -- the batch
+    chain (whose squelch half runs burst-parallel behind the walk) against the oracle: the SAME bursts are zero on both
+    sides, and the audible ones follow the chain rule counted from where the audio starts."""
+    import cutesdr_amd as ca
+    fs, C = 2e6, 3
+    n = 19968 * 36
+    t = np.arange(n) / fs
+    x = np.stack([fm_carrier(n, fs, 100e3 + 1000.0 * c, dbfs=-25.0, channel=c) for c in range(C)])
+    rng = np.random.default_rng(31)
+    noise = 32767.0 * 10 ** (-70 / 20.0) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x[1] = noise
+    gate = (t > t[-1] / 3) & (t < 2 * t[-1] / 3)
+    x[2] = np.where(gate, x[2], noise)
+    x = x.astype(np.complex64)
+    m, kw = MODES["FM"]
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    refs = []
+    for c in range(C):
+        b.set_demod(c, m, info(ca, SquelchValue=squelch, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, SquelchValue=squelch, **kw))
+        r.SetDemodFreq(-(100e3 + 1000.0 * c)); refs.append(r)
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -(100e3 + 1000.0 * c))
+    zeros = [[], [], []]
+    half = n // 2
+    for part in (x[:, :half], x[:, half:]):
+        got = b.process(part)
+        for c in range(C):
+            want = refs[c].process_append(part[c].astype(np.complex128))
+            assert len(got[c]) == len(want) > 0
+            g = got[c].reshape(-1, 1024); w = np.asarray(want).reshape(-1, 1024)
+            zg, zw = ~g.any(axis=1), ~w.any(axis=1)
+            assert np.array_equal(zg, zw), (squelch, c, np.nonzero(zg != zw)[0][:5])       # the same squelch decisions
+            zeros[c].extend(zw.tolist())
+            errs = np.abs(g - w).max(axis=1)
+            aud = np.nonzero(~zw)[0]
+            if len(aud) > 8:                                                            # steady audio: from the 7th audible burst
+                assert (errs[aud[7:]] <= 1e-3 * FULL_SCALE).all(), (squelch, c, errs[aud[:12]] / FULL_SCALE)
+    z0, z1, z2 = (np.array(z) for z in zeros)
+    assert not z0[4:].any()                          # the carrier keeps the squelch open
+    assert z1[4:].all()                              # noise alone keeps it closed
+    assert z2[4:].any() and not z2.all()             # the gated carrier: both states seen
