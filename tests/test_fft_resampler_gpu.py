@@ -298,3 +298,31 @@ def test_fft_batch_many_frames_multi_kernel_sizes(oracle, n):
                 refs[c].PutInDisplayFFT(x[c, k * n:(k + 1) * n])
             assert b.total_count(c) == frames * (call + 1)
             assert_spectrum_close(b.ave_buf(c).astype(np.float64), refs[c].ave_buf())
+
+
+@pytest.mark.parametrize("dbc", [-6.0, 12.5])
+def test_display_spectrum_with_db_compensation(oracle, dbc):
+    """SetFFTParams' dBCompensation (fft.cpp:186-188: it moves K_B and K_C, the offset and the floor inside the log) --
+    every other test passes 0: the averaged bels and the screen mapping with it set, drop-in and batch form."""
+    import cutesdr_amd as ca
+    n, fs = 4096, 2e6
+    f, r = ca.CFft(), oracle.CFft()
+    b = ca.FftBatch(2)
+    for o in (f, r):
+        o.SetFFTParams(n, False, dbc, fs); o.SetFFTAve(3)
+    b.set_params(n, False, dbc, fs); b.set_ave(3)
+    frames = 6
+    x = tones_plus_noise(77, frames * n, fs, [250e3, -410e3])
+    for k in range(frames):
+        assert f.PutInDisplayFFT(x[k * n:(k + 1) * n]) == r.PutInDisplayFFT(x[k * n:(k + 1) * n])
+    b.put_display(np.stack([x, x[::-1].copy()]))
+    want = r.ave_buf()
+    assert_spectrum_close(f.ave_buf().astype(np.float64), want)
+    assert_spectrum_close(b.ave_buf(0).astype(np.float64), want)
+    zero = oracle.CFft(); zero.SetFFTParams(n, False, 0.0, fs); zero.SetFFTAve(3)
+    for k in range(frames):
+        zero.PutInDisplayFFT(x[k * n:(k + 1) * n])
+    assert abs((want.max() - zero.ave_buf().max()) - dbc / 10.0) < 0.05      # the compensation is there: bels move by dbc / 10
+    ovg, pg = f.GetScreenIntegerFFTData(400, 600, 0.0, -140.0, -800000, 800000)
+    ovr, pr = r.GetScreenIntegerFFTData(400, 600, 0.0, -140.0, -800000, 800000)
+    assert ovg == ovr and np.abs(pg - pr).max() <= 1
