@@ -538,3 +538,58 @@ def test_fm_squelch_open_closed_and_opening_in_the_batch_chain(oracle, squelch):
     assert not z0[4:].any()                          # the carrier keeps the squelch open
     assert z1[4:].all()                              # noise alone keeps it closed
     assert z2[4:].any() and not z2.all()             # the gated carrier: both states seen
+
+
+def test_retune_between_calls_in_the_batch_chain(oracle):
+    """csdr_demod_batch_set_freq between calls (CDemodulator::SetDemodFreq -> CDownConvert::SetFrequency,
+    downconvert.cpp:98-106: the oscillator keeps its phasor, only the increment changes): AM, FM and USB receivers whose
+    streams hold two carriers each move from the first to the second after the first call; the audio behind the retune
+    follows the oracle's, burst by burst -- the filters, AGC and loops of both sides go through the same transient."""
+    import cutesdr_amd as ca
+    fs, C = 2e6, 3
+    names = ["AM", "FM", "USB"]
+    n = 19968 * 16
+    f1 = [100e3, 101e3, 102e3]
+    f2 = [-300e3, -301e3, -302e3]
+    xs = []
+    for c, name in enumerate(names):
+        if name == "FM":
+            x = fm_carrier(2 * n, fs, f1[c], dbfs=-20.0, channel=c) + fm_carrier(2 * n, fs, f2[c], fmod=700.0, dbfs=-26.0, noise_dbfs=-200.0, channel=c + 10)
+        elif name == "AM":
+            x = am_carrier(2 * n, fs, f1[c], dbfs=-20.0, channel=c) + am_carrier(2 * n, fs, f2[c], fmod=600.0, dbfs=-26.0, noise_dbfs=-200.0, channel=c + 10)
+        else:
+            x = tones_plus_noise(9, 2 * n, fs, [f1[c] + 1200.0, f1[c] + 2340.0, f2[c] + 900.0, f2[c] + 1710.0])
+        xs.append(x.astype(np.complex64))
+    xs = np.stack(xs)
+    b = ca.DemodBatch(C, 2048); b.set_input_rate(fs)
+    refs = []
+    for c, name in enumerate(names):
+        m, kw = MODES[name]
+        b.set_demod(c, m, info(ca, **kw))
+        r = oracle.CDemodulator(2048); r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-f1[c])
+        refs.append(r)
+    b.commit()
+    for c in range(C):
+        b.set_freq(c, -f1[c])
+    first = [0] * C
+    for call, part in enumerate((xs[:, :n], xs[:, n:])):
+        if call == 1:
+            for c in range(C):
+                b.set_freq(c, -f2[c]); refs[c].SetDemodFreq(-f2[c])
+        got = b.process(part)
+        for c, name in enumerate(names):
+            want = refs[c].process_append(part[c].astype(np.complex128))
+            assert len(got[c]) == len(want) > 0
+            errs = burst_errors(got[c], want)
+            if call == 0:
+                check_chain_bursts(errs, name, first[c], (c, name, "before the retune"))
+            else:
+                # behind the retune both sides ring down and pull in again from the SAME states, through the AGC's recovery
+                # (the new carrier is 6 dB weaker: the gain ramps for ~10 bursts and carries the rounding differences with
+                # it -- AM 8e-5 of full scale in the third burst) and, for FM, the loop's re-acquisition: the start-up bounds
+                # for eight bursts, the steady ones from there
+                early = (1e-3 if name == "FM" else 5e-4) * FULL_SCALE
+                assert (errs[:8] <= early).all(), (c, name, errs[:10] / FULL_SCALE)
+                assert (errs[8:] <= (3e-5 if name == "FM" else 2e-5) * FULL_SCALE).all(), (c, name, errs[:16] / FULL_SCALE)
+                assert np.abs(want[4096:]).max() > 100.0                    # there is audio on the new carrier
+            first[c] += len(want) // 1024
