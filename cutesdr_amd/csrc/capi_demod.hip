@@ -1043,6 +1043,20 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
 int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
                                     float *d_out_iq, long long out_stride, void *stream)
 { return demod_batch_run(b, d_in, in_stride, n_per_channel, d_out_iq, out_stride, stream, true); }
+// the blanker's mask rows of a call of n samples per channel (fused form): [channels][mask_cap] words, grown when needed
+static int batch_mask_rows(csdr_demod_batch *b, long n)
+{
+    const long words = (n + 31) / 32 + 64;
+    if (words > b->mask_cap) {
+        CSDR_HIP(hipDeviceSynchronize());
+        if (b->d_mask) (void)hipFree(b->d_mask);
+        b->d_mask = nullptr; b->mask_cap = 0;
+        CSDR_HIP(hipMalloc((void **)&b->d_mask, (size_t)b->channels * words * sizeof(unsigned)));
+        b->mask_cap = words;
+    }
+    b->blank.mask = b->d_mask; b->blank.mask_stride = b->mask_cap;
+    return CSDR_OK;
+}
 int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets, int npackets, int pkt_len,
                                      struct csdr_noiseproc_batch *nb, float *d_out, long long out_stride,
                                      void *stream)
@@ -1069,15 +1083,7 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     // the blanker ("fuses naturally into the NCO kernel's load").  CSDR_BLANK_FUSED=0: the two-pass form.
     static const bool fused = !(getenv("CSDR_BLANK_FUSED") && atoi(getenv("CSDR_BLANK_FUSED")) == 0);
     if (fused) {
-        const long words = (n + 31) / 32 + 64;
-        if (words > b->mask_cap) {
-            CSDR_HIP(hipDeviceSynchronize());
-            if (b->d_mask) (void)hipFree(b->d_mask);
-            b->d_mask = nullptr; b->mask_cap = 0;
-            CSDR_HIP(hipMalloc((void **)&b->d_mask, (size_t)b->channels * words * sizeof(unsigned)));
-            b->mask_cap = words;
-        }
-        b->blank.mask = b->d_mask; b->blank.mask_stride = b->mask_cap;
+        { const int rcm = batch_mask_rows(b, n); if (rcm) return rcm; }
         int rc = csdr__noiseproc_batch_mask(nb, nullptr, 0, d_packets, npackets, pkt_len, (int)n, b->d_mask, b->mask_cap,
                                             &b->blank.state, &b->blank.hist, stream);
         if (rc < 0) return rc;
@@ -1114,15 +1120,7 @@ int csdr_demod_batch_process_blanked(csdr_demod_batch *b, const float *d_in, lon
     if (b->pipelined)                                         // (the single-buffered mask, as in process_packets)
         for (size_t ki = 0; ki < b->cores.size(); ki++)
             if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
-    const long words = (n + 31) / 32 + 64;
-    if (words > b->mask_cap) {
-        CSDR_HIP(hipDeviceSynchronize());
-        if (b->d_mask) (void)hipFree(b->d_mask);
-        b->d_mask = nullptr; b->mask_cap = 0;
-        CSDR_HIP(hipMalloc((void **)&b->d_mask, (size_t)b->channels * words * sizeof(unsigned)));
-        b->mask_cap = words;
-    }
-    b->blank.mask = b->d_mask; b->blank.mask_stride = b->mask_cap;
+    { const int rcm = batch_mask_rows(b, n); if (rcm) return rcm; }
     int rc = csdr__noiseproc_batch_mask(nb, d_in, in_stride, nullptr, 0, 0, (int)n, b->d_mask, b->mask_cap,
                                         &b->blank.state, &b->blank.hist, stream);
     if (rc < 0) return rc;
