@@ -163,10 +163,11 @@ void noiseblank_kernel(NbArgs a)
         // decoded where they are consumed so that the fetch does not wait for itself
         unsigned pw[6 * NB_PER];
         bool praw = false;                                  // uniform: what the last fetch left in pw
+        bool praw16 = false;                                // ... raw 16-bit datagram words (ring form)
         auto put = [&](int slot, int k, f2 v) { pw[2 * NB_PER * slot + 2 * k] = __float_as_uint(v.x); pw[2 * NB_PER * slot + 2 * k + 1] = __float_as_uint(v.y); };
         auto fetch = [&](long b0) {
             const bool inside = (ring || b0 - M1 >= 0) && (mask_mode || b0 - D1 >= 0) && b0 + NB_TILE <= seg_b;
-            praw = false;
+            praw = false; praw16 = false;
             if (pk && pkt_len == 1444 && inside) {
                 // 24-bit datagrams: a sample pair (even index) is 12 bytes at a 4-byte aligned offset and never straddles a
                 // datagram; a thread's four samples of a stream are two pairs (even start) or parts of three (odd start)
@@ -189,6 +190,18 @@ void noiseblank_kernel(NbArgs a)
                     for (int p = 0; p <= NB_NP; p++) pair_words(ed + 2u * p, pw + 6 * NB_NP + 3 + 3 * p);
                 }
                 praw = true;
+                return;
+            }
+            // 16-bit datagrams, ring form (no second or third stream to fetch): a sample is one word, 256 to a datagram, a
+            // thread's samples contiguous inside one -- plain word loads, decoded where they are consumed (the per-sample
+            // path below cost the 16-bit chain a third more in this kernel: 1.43 against 1.07 ms)
+            if (RING && mask_mode && pk && pkt_len == 1028 && inside) {
+                static_assert(256 % NbTile<true, true>::PER == 0, "a thread's samples lie inside one 16-bit datagram");
+                const unsigned i0 = (unsigned)(b0 + (long)t * NB_PER);
+                const unsigned *wp = reinterpret_cast<const unsigned *>(pk + ((i0 >> 8) * 1028u + 4u + 4u * (i0 & 255u)));
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) pw[k] = wp[k];
+                praw16 = true;
                 return;
             }
             // a tile whose three streams lie inside this call's float rows (all but the first tiles of a call and a
@@ -218,7 +231,11 @@ void noiseblank_kernel(NbArgs a)
         };
         // the prefetched tile as samples: new, leaving, delayed
         auto take = [&](f2 *x, f2 *xo, f2 *xdl) {
-            if (praw) {
+            if (praw16) {
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++)
+                    x[k] = f2{(float)(short)(pw[k] & 0xffffu), (float)(short)(pw[k] >> 16)};      // (I low half, Q high half: wire_format.hpp)
+            } else if (praw) {
                 auto pair = [&](const unsigned *w, f2 &a, f2 &b) {
                     const wf4 v = wire_pair_decode(wf4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), 0.f}, 1444);
                     a = f2{v.x, v.y}; b = f2{v.z, v.w};
