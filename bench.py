@@ -684,6 +684,20 @@ def packets_chain(torch, ca, ctx, c4, check=True):
     out["mask_kernel"] = {"config": "the blanker pass of that chain alone: %d receivers x %d datagrams in, one bit per sample out" % (C, npk),
                           "ms_per_launch": round(ms, 4),
                           "roofline": roofline_obj(alg / ms / 1e6, ms, "csdr::noiseblank_kernel<true, true>", alg, None)}
+    # the 16-bit wire format (256 samples + 4 header bytes per datagram): the same chain with the blanker
+    npk16 = (T // 256) // 8 * 8
+    pk16 = torch.zeros((C, npk16, 1028), device=x.device, dtype=torch.uint8)
+    for c0 in range(0, C, 32):
+        v = torch.round(x[c0:c0 + 32, :npk16 * 256].reshape(-1, npk16, 512)).clamp(-32768, 32767).to(torch.int32)
+        pk16[c0:c0 + 32, :, 4:] = torch.stack([v & 255, (v >> 8) & 255], dim=-1).to(torch.uint8).reshape(-1, npk16, 1024)
+        del v
+    nb16 = ca.NoiseProcBatch(C, device=ctx.local)
+    nb16.setup(True, 50.0, 2.0, C4_FS)
+    def run16():
+        rc = ca.lib().csdr_demod_batch_process_packets(c4.b.h, pk16.data_ptr(), npk16, 1028, nb16.h, c4.aud.data_ptr(), c4.cap, c4.stream)
+        assert rc == 0, ca._capi.last_error()
+    out["packets16_blanker_chain_ms"] = round(gpu_ms(torch, run16, 8, 20), 4)
+    del nb16, pk16
     if check:
         out["parity_checked"] = {"datagrams": c4.parity_check(packets=(pk, npk)),
                                  "datagrams_with_blanker": c4.parity_check(packets=(pk, npk), blanker=True)}
