@@ -178,8 +178,17 @@ void noiseblank_kernel(NbArgs a)
                     dst[0] = wp[0]; dst[1] = wp[1]; dst[2] = wp[2];
                 };
                 const unsigned eo = (i0 - (unsigned)M1) & ~1u, ed = (i0 - (unsigned)D1) & ~1u;
+                if constexpr (RING && MASK) {
+                    // (a thread's samples start at a multiple of NB_PER, which divides 240: they lie in ONE datagram, 6 bytes
+                    // apart -- one division instead of one per pair)
+                    const unsigned q = i0 / 240u, j = i0 - q * 240u;
+                    const unsigned *wp = reinterpret_cast<const unsigned *>(pk + (q * 1444u + 4u + 6u * j));
 #pragma unroll
-                for (int p = 0; p < NB_NP; p++) pair_words(i0 + 2u * p, pw + 3 * p);
+                    for (int k = 0; k < 3 * NB_NP; k++) pw[k] = wp[k];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < NB_NP; p++) pair_words(i0 + 2u * p, pw + 3 * p);
+                }
                 if (!ring) {
 #pragma unroll
                     for (int p = 0; p < NB_NP; p++) pair_words(eo + 2u * p, pw + 3 * NB_NP + 3 * p);
