@@ -22,6 +22,7 @@ struct csdr_demod_shard {
     std::vector<float *> d_block; std::vector<size_t> block_cap;    // shared-stream mode: the wide-band block on each device
     std::vector<float *> d_sm;                           // 2 x count floats per shard: S-meter averages, peaks
     std::vector<int> input_row; int nrows = 0;           // shared-stream mode: receiver -> row of the block
+    std::vector<csdr_noiseproc_batch *> nb;              // per shard: CNoiseProc's blanker of its receivers (csdr_demod_shard_set_blanker)
     bool committed = false;
     ~csdr_demod_shard()
     {
@@ -29,6 +30,7 @@ struct csdr_demod_shard {
             (void)hipSetDevice(device[s]);
             if (stream[s]) { (void)hipStreamSynchronize(stream[s]); }
             if (b[s]) csdr_demod_batch_destroy(b[s]);
+            if (s < nb.size() && nb[s]) csdr_noiseproc_batch_destroy(nb[s]);
             if (d_block[s]) (void)hipFree(d_block[s]);
             if (d_sm[s]) (void)hipFree(d_sm[s]);
             if (stream[s]) (void)hipStreamDestroy(stream[s]);
@@ -132,6 +134,52 @@ int csdr_demod_shard_process(csdr_demod_shard *S, const float *const *d_in, long
     for (size_t s = 0; s < S->b.size(); s++) {
         const int rc = csdr_demod_batch_process(S->b[s], d_in[s], in_stride, n_per_channel, d_out[s], out_stride,
                                                 streams ? streams[s] : (void *)S->stream[s]);
+        if (rc < 0 && !err) err = rc;
+    }
+    return err;
+}
+/* CNoiseProc::SetupBlanker (noiseproc.cpp:78-119) for every receiver of every shard: the blanker that
+ * csdr_demod_shard_process_packets / _process_blanked run fused in front of the chain (on = 0: none). */
+int csdr_demod_shard_set_blanker(csdr_demod_shard *S, int on, double threshold, double width_us, double sample_rate)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    S->nb.resize(S->b.size(), nullptr);
+    for (size_t s = 0; s < S->b.size(); s++) {
+        if (!S->nb[s]) {
+            S->nb[s] = csdr_noiseproc_batch_create(S->device[s], S->count[s]);
+            if (!S->nb[s]) return CSDR_EHIP;
+        }
+        const int rc = csdr_noiseproc_batch_setup(S->nb[s], -1, on, threshold, width_us, sample_rate);
+        if (rc) return rc;
+    }
+    return CSDR_OK;
+}
+/* csdr_demod_batch_process_packets on every shard: d_packets[s] = shard s's receivers' datagrams on ITS device
+ * ([count_s][npackets][pkt_len] bytes), d_out[s] its audio rows.  With a blanker set (csdr_demod_shard_set_blanker) it
+ * runs fused in front, as in the one-device call. */
+int csdr_demod_shard_process_packets(csdr_demod_shard *S, const void *const *d_packets, int npackets, int pkt_len,
+                                     float *const *d_out, long long out_stride, void *const *streams)
+{
+    if (!S || !d_packets || !d_out) return fail(CSDR_EINVAL, "bad argument");
+    int err = 0;
+    for (size_t s = 0; s < S->b.size(); s++) {
+        const int rc = csdr_demod_batch_process_packets(S->b[s], d_packets[s], npackets, pkt_len,
+                                                        s < S->nb.size() ? S->nb[s] : nullptr, d_out[s], out_stride,
+                                                        streams ? streams[s] : (void *)S->stream[s]);
+        if (rc < 0 && !err) err = rc;
+    }
+    return err;
+}
+/* csdr_demod_shard_process with the blanker of csdr_demod_shard_set_blanker fused in front (fp32 rows) */
+int csdr_demod_shard_process_blanked(csdr_demod_shard *S, const float *const *d_in, long long in_stride, int n_per_channel,
+                                     float *const *d_out, long long out_stride, void *const *streams)
+{
+    if (!S || !d_in || !d_out) return fail(CSDR_EINVAL, "bad argument");
+    if (S->nb.size() != S->b.size()) return fail(CSDR_ESTATE, "csdr_demod_shard_set_blanker first");
+    int err = 0;
+    for (size_t s = 0; s < S->b.size(); s++) {
+        const int rc = csdr_demod_batch_process_blanked(S->b[s], d_in[s], in_stride, n_per_channel, S->nb[s], d_out[s], out_stride,
+                                                        streams ? streams[s] : (void *)S->stream[s]);
         if (rc < 0 && !err) err = rc;
     }
     return err;

@@ -754,6 +754,43 @@ class ShardedDemodBatch(_Obj):
             b.free()
         return self._collect(outs, cap)
 
+    def set_blanker(self, On, Threshold, Width, SampleRate):
+        check(lib().csdr_demod_shard_set_blanker(self.h, int(On), Threshold, Width, SampleRate), "shard_set_blanker")
+
+    def process_blanked(self, x):
+        """process() with the blanker of set_blanker fused in front"""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        T = x.shape[1]
+        cap = T + self.n
+        ins = []
+        for (f, c, d) in self.ranges:
+            b = DeviceBuffer(8 * c * T, d); b.upload(np.ascontiguousarray(x[f:f + c])); ins.append(b)
+        outs = self._outs(cap)
+        pin = (C.c_void_p * len(ins))(*[b.ptr for b in ins]); pout = (C.c_void_p * len(outs))(*[b.ptr for b in outs])
+        check(lib().csdr_demod_shard_process_blanked(self.h, pin, T, T, pout, cap, None), "csdr_demod_shard_process_blanked")
+        self.sync()
+        for b in ins:
+            b.free()
+        return self._collect(outs, cap)
+
+    def process_packets(self, raw, pkt_len):
+        """raw uint8 [channels, npackets, pkt_len] (host): every shard's receivers' datagrams go to its device"""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        assert raw.shape[0] == self.channels and raw.shape[2] == pkt_len
+        npk = raw.shape[1]
+        T = npk * (240 if pkt_len == 1444 else 256)
+        cap = T // 8 + self.n + 4096
+        ins = []
+        for (f, c, d) in self.ranges:
+            b = DeviceBuffer(c * npk * pkt_len, d); b.upload(np.ascontiguousarray(raw[f:f + c])); ins.append(b)
+        outs = self._outs(cap)
+        pin = (C.c_void_p * len(ins))(*[b.ptr for b in ins]); pout = (C.c_void_p * len(outs))(*[b.ptr for b in outs])
+        check(lib().csdr_demod_shard_process_packets(self.h, pin, npk, pkt_len, pout, cap, None), "csdr_demod_shard_process_packets")
+        self.sync()
+        for b in ins:
+            b.free()
+        return self._collect(outs, cap)
+
     def process_shared(self, block, src_device=0):
         """block complex [nrows, T] (host) -> uploaded once to src_device, broadcast by the object"""
         block = np.ascontiguousarray(block, dtype=np.complex64)

@@ -327,6 +327,16 @@ int csdr_demod_shard_out_count(csdr_demod_shard *s, int channel);
 int csdr_demod_shard_set_input_rows(csdr_demod_shard *s, const int *input_row, int nrows);
 int csdr_demod_shard_process_shared(csdr_demod_shard *s, const float *d_block, int src_device, void *src_stream,
                                     long long in_stride, int n_per_channel, float *const *d_out, long long out_stride);
+/* The datagram and blanker forms of the one-device batch on every shard.  set_blanker = CNoiseProc::SetupBlanker for all
+ * receivers (noiseproc.cpp:78-119; the shard object owns one csdr_noiseproc_batch per device); process_packets takes
+ * d_packets[s] = shard s's receivers' datagrams on ITS device ([count_s][npackets][pkt_len] bytes, as
+ * csdr_demod_batch_process_packets) and runs the blanker fused in front when one is set; process_blanked is
+ * csdr_demod_shard_process with that blanker in front of fp32 rows. */
+int csdr_demod_shard_set_blanker(csdr_demod_shard *s, int on, double threshold, double width_us, double sample_rate);
+int csdr_demod_shard_process_packets(csdr_demod_shard *s, const void *const *d_packets, int npackets, int pkt_len,
+                                     float *const *d_out, long long out_stride, void *const *streams);
+int csdr_demod_shard_process_blanked(csdr_demod_shard *s, const float *const *d_in, long long in_stride, int n_per_channel,
+                                     float *const *d_out, long long out_stride, void *const *streams);
 /* waits for everything issued on the shards' own streams (pipelined mode: flushes first) */
 int csdr_demod_shard_sync(csdr_demod_shard *s);
 /* CSMeter::GetAve / GetPeak of every receiver into HOST arrays indexed by global channel (either may be NULL; reading

@@ -103,3 +103,50 @@ def test_shared_block_is_broadcast_to_every_shard(oracle):
             assert len(got[c]) == len(want)
             check_chain_bursts(burst_errors(got[c], want), name if name == "FM" else "other", 0, (devices, c, name))
         del sh
+
+
+@pytest.mark.parametrize("form", ["packets16", "packets24", "packets24-no-blanker", "rows"])
+def test_shards_with_the_blanker_equal_one_wide_batch(form):
+    """The datagram and blanker forms behind the shard object (csdr_demod_shard_set_blanker / _process_packets /
+    _process_blanked): for every device set, word for word what one batch of all the receivers with one blanker
+    gives through csdr_demod_batch_process_packets / _process_blanked, two calls."""
+    import cutesdr_amd as ca
+    from test_frontend_gpu import _pack16, _pack24
+    fs = 2e6
+    names = ["FM", "AM", "USB", "FM", "CWU", "AM", "USB", "FM"]
+    C = len(names)
+    pkt_len = 1028 if form == "packets16" else 1444
+    per = 256 if pkt_len == 1028 else 240
+    npk = (19968 * 8 // per) // 8 * 8                          # whole multiples of the largest decimation (CW: 128)
+    n = npk * per
+    rng = np.random.default_rng(12)
+    x = np.stack([make_input(m if m != "CWU" else "USB", 2 * n, fs) * np.exp(2j * np.pi * 800.0 * c * np.arange(2 * n) / fs)
+                  for c, m in enumerate(names)])
+    for c in range(C):
+        x[c, rng.random(2 * n) < 5e-5] += 30000.0
+    blank = form != "packets24-no-blanker"
+    wide = ca.DemodBatch(C, 2048); _configure(wide, ca, names, fs)
+    nb = ca.NoiseProcBatch(C); nb.setup(True, 30.0, 10.0, fs)
+    want = []
+    for call in range(2):
+        part = x[:, call * n:(call + 1) * n]
+        if form == "rows":
+            want.append(wide.process_blanked(part.astype(np.complex64), nb))
+        else:
+            raw = np.stack([(_pack16 if pkt_len == 1028 else _pack24)(part[c]) for c in range(C)])
+            want.append(wide.process_packets(raw, pkt_len, nb if blank else None))
+    for devs in _device_sets():
+        sh = ca.ShardedDemodBatch(devs, C, 2048); _configure(sh, ca, names, fs)
+        if blank:
+            sh.set_blanker(True, 30.0, 10.0, fs)
+        for call in range(2):
+            part = x[:, call * n:(call + 1) * n]
+            if form == "rows":
+                got = sh.process_blanked(part.astype(np.complex64))
+            else:
+                raw = np.stack([(_pack16 if pkt_len == 1028 else _pack24)(part[c]) for c in range(C)])
+                got = sh.process_packets(raw, pkt_len)
+            for c in range(C):
+                assert len(got[c]) == len(want[call][c]), (devs, call, c)
+                assert np.array_equal(got[c].view(np.uint32), want[call][c].view(np.uint32)), (devs, call, c, names[c])
+        assert any(len(w) > 0 for w in want[1])
