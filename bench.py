@@ -226,9 +226,6 @@ def profiled_traffic():
     return None
 
 
-K2_ALONE_GRID = 4096 * 64          # 256 receivers x 16 segments, one wave each (capi_downconv.hip's segment rule: one round)
-
-
 def live_traffic(timeout_s=240):
     """HBM bytes per launch MEASURED IN THIS RUN for the headline kernel and for the secondary objects: two child runs
     of this script (`--pmc-child`: a few launches of every workload) under `rocprofv3 --pmc`, FETCH_SIZE and
@@ -259,6 +256,7 @@ def live_traffic(timeout_s=240):
             if not counts:
                 return None
             acc = {"k1": [], "k2": [], "k3": 0.0, "k6": [], "k6m": [], "chain": 0.0}
+            dcs = []                                      # every down-converter dispatch: (dispatch id, value)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row["Kernel_Name"]
@@ -267,8 +265,8 @@ def live_traffic(timeout_s=240):
                     v = float(row["Counter_Value"])
                     if "fastfir_os2_kernel<14>" in name:
                         acc["k1"].append(v)
-                    elif "downconv_kernel" in name and int(row.get("Grid_Size", 0)) == K2_ALONE_GRID:
-                        acc["k2"].append(v)
+                    elif "downconv_kernel" in name:
+                        dcs.append((int(row["Dispatch_Id"]), v))
                     elif "spectrum" in name:
                         acc["k3"] += v
                     elif "noiseblank_kernel<true" in name:
@@ -277,10 +275,18 @@ def live_traffic(timeout_s=240):
                         acc["k6"].append(v)
                     else:
                         acc["chain"] += v
-            if len(acc["k1"]) < 3:
-                return None
+            # the child runs "K2 alone" BEFORE its chain steps and says how many launches that was: the first counts["k2"]
+            # down-converter dispatches are those, whatever grid the library's segment rule gave them (the grid size
+            # depends on the channel count, the workgroup budget and CSDR_DC_WGS); the rest belong to the chain steps
+            dcs.sort()
+            acc["k2"] = [v for _, v in dcs[:counts["k2"]]]
+            acc["chain"] += sum(v for _, v in dcs[counts["k2"]:])
+            if len(acc["k1"]) != counts["k1"] or len(acc["k2"]) != counts["k2"] or not acc["k6"] or not acc["k6m"] or \
+                    len(dcs) <= counts["k2"]:
+                return None                               # a phase is missing or split differently: no figure rather than a wrong one
             mean = lambda v: sum(v) / len(v) if v else None
-            per[counter] = {"k1": mean(acc["k1"]), "k2": mean(acc["k2"]), "k6": mean(acc["k6"]), "k6m": mean(acc["k6m"]),
+            per[counter] = {"k1": mean(acc["k1"]), "k2": mean(acc["k2"]), "k6": sum(acc["k6"]) / counts["k6"],
+                            "k6m": sum(acc["k6m"]) / counts["k6m"],
                             "k3": acc["k3"] / counts["k3"] if counts.get("k3") else None,
                             "chain": acc["chain"] / counts["chain"] if counts.get("chain") else None}
         res = {}
@@ -1231,9 +1237,13 @@ def run_stub(args):
         w.step()
     dist_barrier(ctx)
     elapsed = dist_max(ctx, time.perf_counter() - t0)
+    ranges = [[lo, hi]]
+    if ctx.world > 1:                                  # every rank's channel range, for the tests of the sharding rule
+        ranges = [None] * ctx.world
+        ctx.dist.all_gather_object(ranges, [lo, hi])
     if ctx.rank == 0:
         line = result_line(ctx, w.C, w.T, args.steps, args.warmup, elapsed, elapsed / args.steps * 1e3,
-                           extra={"stub": True, "rank0_channels": [lo, hi]})
+                           extra={"stub": True, "rank0_channels": [lo, hi], "rank_channels": ranges})
         print(json.dumps(line), flush=True)
     dist_finish(ctx)
 

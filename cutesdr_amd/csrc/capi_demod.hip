@@ -51,6 +51,7 @@ extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, c
 extern "C" int csdr__noiseproc_batch_mask(struct csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const void *d_packets,
                                           int npackets, int pkt_len, int n_per_channel, unsigned *d_mask, long long mask_stride,
                                           const void **d_state, const float **d_hist, void *stream);
+extern "C" int csdr__noiseproc_batch_shape(struct csdr_noiseproc_batch *b, int *channels, int *device);
 extern "C" int csdr__downconvert_batch_copy_channel(csdr_downconvert_batch *dst, int dc, csdr_downconvert_batch *src, int sc);
 extern "C" int csdr__fastfir_batch_copy_row(csdr_fastfir_batch *dst, int dr, csdr_fastfir_batch *src, int sr);
 extern "C" int csdr__noiseproc_batch_process_packets(struct csdr_noiseproc_batch *b, const void *d_packets, int npackets,
@@ -325,6 +326,8 @@ struct ChanCfg {
     int pending = -1;                   // batch form: mode requested before commit
     DemodInfo info{};
     double out_rate = 48000.0, want_bw = 48000.0, cw_off = 0.0;
+    double demod_rate = 48000.0;        // m_SampleRate of the demodulator OBJECT: the output rate at the time the mode was
+                                        // set (amdemod.cpp:50, fmdemod.cpp:62); an input-rate change does not touch it
 };
 
 // CDemodulator::SetDemod (dsp/demodulator.cpp:107-157) for row r of core k
@@ -341,10 +344,11 @@ int apply_set_demod(ChainCore &k, int r, ChanCfg &c, double in_rate, int mode, c
         if ((rc = k.pc.pull(r))) return rc;
         PcChannel &h = k.pc.h[r];
         h.mode = mode;
+        c.demod_rate = c.out_rate;
         switch (mode) {                 // new demodulator object = fresh state
-        case PC_MODE_AM:  am_init(h.am, k.pc.fir_am[r], c.out_rate); break;
-        case PC_MODE_SAM: sam_init(h.sam, k.pc.fir_sam[r], c.out_rate); break;
-        case PC_MODE_FM:  fm_init(h.fm, k.pc.fir_fm[r], c.out_rate); break;
+        case PC_MODE_AM:  am_init(h.am, k.pc.fir_am[r], c.demod_rate); break;
+        case PC_MODE_SAM: sam_init(h.sam, k.pc.fir_sam[r], c.demod_rate); break;
+        case PC_MODE_FM:  fm_init(h.fm, k.pc.fir_fm[r], c.demod_rate); break;
         default: break;
         }
         if ((rc = k.pc.push(r))) return rc;
@@ -362,9 +366,9 @@ int apply_set_demod(ChainCore &k, int r, ChanCfg &c, double in_rate, int mode, c
         PcChannel &h = k.pc.h[r];
         if (mode == PC_MODE_FM) {
             fm_set_squelch(h.fm, info.SquelchValue);
-            fm_set_bw(h.fm, k.pc.fir_fm[r], c.out_rate, (double)info.HiCut);     // fmdemod.cpp:160-164
+            fm_set_bw(h.fm, k.pc.fir_fm[r], c.demod_rate, (double)info.HiCut);   // fmdemod.cpp:160-164 (the object's own rate)
         } else {
-            am_bandwidth(h.am, k.pc.fir_am[r], c.out_rate, (info.HiCut - info.LowCut) / 2.0);
+            am_bandwidth(h.am, k.pc.fir_am[r], c.demod_rate, (info.HiCut - info.LowCut) / 2.0);   // amdemod.cpp:56-60
         }
         if ((rc = k.pc.push(r))) return rc;
     }
@@ -533,19 +537,24 @@ static void batch_drop_core(csdr_demod_batch *b, int ki)
  * muted rows only is dropped.  Transactional: the new row is complete before anything of the batch changes, and any
  * failure leaves the batch as it was.  A receiver already alone in its group changes in place, exactly like the
  * single-channel object. */
-static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const DemodInfo &di, int new_stages)
+template <class Apply>                                // apply(core, row, cfg): what makes the receiver's chain the new one
+static int batch_move_row(csdr_demod_batch *b, int channel, int new_stages, Apply apply)
 {
     CSDR_HIP(hipDeviceSynchronize());                  // control plane: nothing of this batch in flight from here on
     const int ka = b->core_of[channel], r = b->row_of[channel];
     ChainCore &A = *b->cores[ka];
-    if (A.rows == 1) return apply_set_demod(A, 0, b->cfg[channel], b->in_rate, mode, di);
+    if (A.rows == 1) return apply(A, 0, b->cfg[channel]);
     // ---- where to: a muted row of a group with the new decimation and the same staging fill, else a new group
     int kb = -1, rb = -1;
     for (size_t ki = 0; ki < b->cores.size() && kb < 0; ki++) {
         ChainCore &B = *b->cores[ki];
         if ((int)ki == ka || B.pending != A.pending || B.rows < 2) continue;
-        if (csdr_downconvert_batch_out_count(B.dc, 0, 1 << 12) != (1 << 12) >> new_stages) continue;
-        for (size_t q = 0; q < b->members[ki].size(); q++) if (b->members[ki][q] < 0) { kb = (int)ki; rb = (int)q; break; }
+        // (the muted row's own chain is its group's: a muted row follows its group through every rate change, while row 0
+        // may be a receiver that is itself about to leave)
+        for (size_t q = 0; q < b->members[ki].size(); q++)
+            if (b->members[ki][q] < 0 && csdr_downconvert_batch_out_count(B.dc, (int)q, 1 << 12) == (1 << 12) >> new_stages) {
+                kb = (int)ki; rb = (int)q; break;
+            }
     }
     ChainCore *S = nullptr;
     int *dr = nullptr, *dor = nullptr;
@@ -570,7 +579,7 @@ static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const 
         float *dst = (T.stage_cur ? T.d_stage2 : T.d_stage) + (size_t)tr * T.cap * 2;
         hip(hipMemcpy(dst, cur, (size_t)A.pending * 8, hipMemcpyDeviceToDevice));
     }
-    if (rc == CSDR_OK) rc = apply_set_demod(T, tr, cfg, b->in_rate, mode, di);
+    if (rc == CSDR_OK) rc = apply(T, tr, cfg);
     const int muted = -1;
     int *t_in = kb < 0 ? dr : b->d_rows[kb] + rb, *t_out = kb < 0 ? dor : b->d_out_rows[kb] + rb;
     if (rc == CSDR_OK) hip(hipMemcpy(t_in, &b->in_row[channel], sizeof(int), hipMemcpyHostToDevice));
@@ -605,6 +614,27 @@ static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const 
     batch_order(b);
     return CSDR_OK;
 }
+static int batch_move_channel(csdr_demod_batch *b, int channel, int mode, const DemodInfo &di, int new_stages)
+{
+    const double in_rate = b->in_rate;
+    return batch_move_row(b, channel, new_stages, [&](ChainCore &k, int row, ChanCfg &cfg) {
+        return apply_set_demod(k, row, cfg, in_rate, mode, di);
+    });
+}
+
+// CDemodulator::SetInputSampleRate (dsp/demodulator.cpp:92-99) for row r of core k: the down-converter is rebuilt for
+// the new input rate (CDownConvert::SetDataRate, downconvert.cpp:114-173: new stage list from zeroed histories, the
+// oscillator keeps phase and amplitude, the CW offset is added once more, :169), m_OutputRate follows -- and nothing else:
+// filter taps and overlap, AGC constants and rings and the demodulator object stay as they are until the next SetDemod
+// (which, for the same mode, keeps the demodulator built for the OLD output rate: ChanCfg::demod_rate).  The S-meter is
+// handed m_OutputRate with every pass (demodulator.cpp:183), so its time constants follow at once.
+static int apply_input_rate(ChainCore &k, int r, ChanCfg &c, double rate)
+{
+    const double out = csdr_downconvert_batch_set_data_rate(k.dc, r, rate, c.want_bw);
+    if (out < 0) return CSDR_EHIP;
+    c.out_rate = out;
+    return k.pc.smeter_rate_set(r, out);
+}
 
 extern "C" {
 
@@ -632,6 +662,11 @@ int csdr_demod_set_input_rate(csdr_demod *d, double rate)
         const double r = csdr_downconvert_batch_set_data_rate(d->k.dc, 0, rate, d->c.want_bw);
         if (r < 0) return CSDR_EHIP;
         d->c.out_rate = r;
+        // Everything else stays as it is until the next SetDemod: filter taps, AGC constants and rings, m_InBufLimit and
+        // the demodulator object (built for the OLD output rate; a same-mode SetDemod does not rebuild it,
+        // demodulator.cpp:111-137).  Only the S-meter follows at once: it is handed m_OutputRate with every pass (:183)
+        int rc = d->k.pc.smeter_rate_set(0, r);
+        if (rc) return rc;
     }
     return CSDR_OK;
 }
@@ -678,7 +713,10 @@ static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out,
         if (take < 1) take = 1;
         if (take > n - i) take = n - i;
         if (d->win_busy[d->cur]) { CSDR_HIP(hipEventSynchronize(d->ev_win[d->cur])); d->win_busy[d->cur] = false; }
-        int rc = w.reserve(2 * ((size_t)d->pos + take));
+        // (a whole window at once: grown step by step, a window filled in 256-sample calls was reallocated -- pinned
+        // malloc, copy, free -- some ten times during its first fill, on the per-datagram path)
+        const size_t fill = (size_t)d->pos + take;
+        int rc = w.reserve(2 * (fill > (size_t)d->limit ? fill : (size_t)d->limit));
         if (rc) return rc;
         cvt_to_f32(w.p + 2 * (size_t)d->pos, in_iq + 2 * (size_t)i, 2 * (size_t)take);
         d->pos += take; i += take;
@@ -756,13 +794,65 @@ csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_
     return b;
 }
 void csdr_demod_batch_destroy(csdr_demod_batch *b) { delete b; }
+/* CDemodulator::SetInputSampleRate (dsp/demodulator.cpp:92-99) for every receiver of the batch, at any time -- the host
+ * calls it on every bandwidth switch of the radio (interface/sdrinterface.cpp:753-754).  Before the commit it only
+ * records the rate.  On a committed batch every receiver's down-converter is rebuilt for the new rate with what the
+ * reference keeps (apply_input_rate above); receivers stay in their rows as long as the rows of a plan group still share
+ * one decimation (they do whenever they share one bandwidth limit, which is how the commit groups them); a receiver whose
+ * new chain has another number of stages than its group's leaves for a matching muted row or a group of its own, exactly
+ * as after a mode change (batch_move_row).  Control plane: synchronises the device; a failure in the planning phase
+ * leaves the batch as it was. */
 int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate)
 {
     if (!b) return fail(CSDR_EINVAL, "bad handle");
-    if (!b->cores.empty() && rate != b->in_rate)
-        return fail(CSDR_ESTATE, "set the input rate before configuring channels");
+    if (b->cores.empty() || rate == b->in_rate) { b->in_rate = rate; return CSDR_OK; }
+    if (!(rate > 0.0)) return fail(CSDR_EINVAL, "input rate %g", rate);
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());                  // control plane: nothing of this batch in flight from here on
+    // ---- plan (nothing changes yet): every receiver's new stage count, every group's (its first live row's)
+    std::vector<int> stages(b->channels, -1);
+    for (int c = 0; c < b->channels; c++) {
+        if (b->core_of[c] < 0) continue;
+        const DcPlan p = dc_make_plan(rate, b->cfg[c].want_bw);
+        if (p.nstages < 0 || p.nstages > DC_MAX_STAGES) return fail(CSDR_EINVAL, "no decimator chain for rate %g", rate);
+        stages[c] = p.nstages;
+    }
+    std::vector<int> group_stages(b->cores.size(), -1);
+    std::vector<double> group_bw(b->cores.size(), 0.0);
+    for (size_t ki = 0; ki < b->cores.size(); ki++)
+        for (int c : b->members[ki])
+            if (c >= 0) { group_stages[ki] = stages[c]; group_bw[ki] = b->cfg[c].want_bw; break; }
+    // ---- the rows that keep their group: in place (a muted row follows its group, it only has to decimate alike)
+    std::vector<int> movers;
+    for (size_t ki = 0; ki < b->cores.size(); ki++) {
+        ChainCore &k = *b->cores[ki];
+        for (size_t q = 0; q < b->members[ki].size(); q++) {
+            const int c = b->members[ki][q];
+            if (c >= 0 && stages[c] != group_stages[ki]) { movers.push_back(c); continue; }
+            if (c >= 0) { const int rc = apply_input_rate(k, (int)q, b->cfg[c], rate); if (rc) return rc; }
+            else if (group_stages[ki] >= 0 && csdr_downconvert_batch_set_data_rate(k.dc, (int)q, rate, group_bw[ki]) < 0) return CSDR_EHIP;
+        }
+    }
     b->in_rate = rate;
-    return CSDR_OK;
+    // ---- the others move, with all their state, like a receiver whose new mode decimates differently; the row each
+    // leaves behind is muted and takes its old group's new chain
+    int err = CSDR_OK;
+    std::map<ChainCore *, double> bw_of;               // (group indices shift when a move empties a group)
+    for (size_t ki = 0; ki < b->cores.size(); ki++) bw_of[b->cores[ki]] = group_bw[ki];
+    for (int c : movers) {
+        const int ka = b->core_of[c], r = b->row_of[c];
+        ChainCore *A = b->cores[ka];
+        const bool alone = A->rows == 1;
+        const double bw = bw_of[A];
+        const int rc = batch_move_row(b, c, stages[c], [&](ChainCore &k, int row, ChanCfg &cfg) { return apply_input_rate(k, row, cfg, rate); });
+        if (rc) { if (!err) err = rc; continue; }
+        // (batch_move_row may have dropped group ka -- then A is gone; it drops a group only when every row is muted)
+        bool still = false;
+        for (auto *k : b->cores) still = still || k == A;
+        if (!alone && still && csdr_downconvert_batch_set_data_rate(A->dc, r, rate, bw) < 0 && !err) err = CSDR_EHIP;
+    }
+    batch_order(b);
+    return err;
 }
 /* Configure every channel, then call csdr_demod_batch_commit() once: channels that decimate by
  * the same chain are grouped and run together. */
@@ -897,6 +987,19 @@ int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream)
             b->prev_post[ki] = -1;
         }
     }
+    return CSDR_OK;
+}
+/* internal (csdr_demod_shard_process_shared): orders `stream` behind the batch's reads of the INPUT of its previous
+ * call.  Strict mode: nothing to do (a process call joins the caller's stream itself).  Pipelined mode: the previous
+ * call's down-converters run on the batch's own streams and the caller's stream joins them only inside the NEXT process
+ * call -- too late for a caller that refills the input buffer on that stream first. */
+int csdr__demod_batch_wait_input_free(csdr_demod_batch *b, void *stream)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (!b->pipelined) return CSDR_OK;
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    for (size_t ki = 0; ki < b->cores.size() && ki < b->prev_join.size(); ki++)
+        if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, b->joins[ki], 0)); b->prev_join[ki] = 0; }
     return CSDR_OK;
 }
 int csdr_demod_batch_set_freq(csdr_demod_batch *b, int channel, double freq)
@@ -1043,6 +1146,18 @@ int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long i
 int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
                                     float *d_out_iq, long long out_stride, void *stream)
 { return demod_batch_run(b, d_in, in_stride, n_per_channel, d_out_iq, out_stride, stream, true); }
+// the caller's blanker must be as wide as the chain and on its device: the mask has one row per receiver, and the
+// down-converter indexes the blanker's state and history by input row
+static int batch_blanker_fits(csdr_demod_batch *b, struct csdr_noiseproc_batch *nb)
+{
+    int ch = 0, dev = -1;
+    const int rc = csdr__noiseproc_batch_shape(nb, &ch, &dev);
+    if (rc) return rc;
+    if (ch != b->channels || dev != b->device)
+        return fail(CSDR_EINVAL, "blanker of %d channels on device %d given to a chain of %d on device %d", ch, dev,
+                    b->channels, b->device);
+    return CSDR_OK;
+}
 // the blanker's mask rows of a call of n samples per channel (fused form): [channels][mask_cap] words, grown when needed
 static int batch_mask_rows(csdr_demod_batch *b, long n)
 {
@@ -1070,6 +1185,7 @@ int csdr_demod_batch_process_packets(csdr_demod_batch *b, const void *d_packets,
     if (n > 0x7fffffffL) return fail(CSDR_EINVAL, "%d datagrams are more samples than one call can take", npackets);
     if (!nb)        // the down-converter decodes the datagrams in its own loads: no unpacked copy, no extra pass
         return demod_batch_run(b, nullptr, 0, (int)n, d_out, out_stride, stream, false, d_packets, pkt_len);
+    { const int rcs = batch_blanker_fits(b, nb); if (rcs) return rcs; }
     // With the blanker.  The internal buffers below (mask / blanked samples) are single-buffered, and the blanker's
     // history halves alternate per call: in pipelined mode the down-converters of the PREVIOUS call (on the batch's own
     // streams) may still be reading them, and the caller's stream -- on which the blanker of this call runs -- has not
@@ -1116,6 +1232,7 @@ int csdr_demod_batch_process_blanked(csdr_demod_batch *b, const float *d_in, lon
         for (size_t q = 0; q < b->members[ki].size(); q++)
             if (b->members[ki][q] >= 0 && b->in_row[b->members[ki][q]] != b->members[ki][q])
                 return fail(CSDR_ESTATE, "process_blanked: every receiver reads its own row (csdr_demod_batch_set_input_rows is off)");
+    { const int rcs = batch_blanker_fits(b, nb); if (rcs) return rcs; }
     const long n = n_per_channel;
     if (b->pipelined)                                         // (the single-buffered mask, as in process_packets)
         for (size_t ki = 0; ki < b->cores.size(); ki++)

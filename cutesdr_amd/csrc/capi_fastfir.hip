@@ -383,11 +383,16 @@ int csdr_fastfir_process(csdr_fastfir *f, int n, const double *in_iq, double *ou
     const int avail = f->pending + n;
     const int nproc = (avail / L) * L;
     if (nproc == 0) { f->pending = avail; return 0; }
-    if ((rc = ensure_cap(f, (size_t)nproc))) return rc;
-    if ((rc = f->pin_out.reserve(2 * (size_t)nproc))) return rc;
+    // (an error below keeps the call's samples: they are appended to the pending ones, and a later call retries the hops)
+    if ((rc = ensure_cap(f, (size_t)nproc))) { f->pending = avail; return rc; }
+    if ((rc = f->pin_out.reserve(2 * (size_t)nproc))) { f->pending = avail; return rc; }
     CSDR_HIP(hipMemcpyAsync(f->d_in, f->pin_in.p, (size_t)nproc * 8, hipMemcpyHostToDevice, f->s));
     rc = csdr_fastfir_batch_process(f->b, f->d_in, nproc, nproc, f->d_out, nproc, (void *)f->s, 0);
-    if (rc) return rc;
+    if (rc) {                                             // the copy above may still be reading the pinned buffer
+        (void)hipStreamSynchronize(f->s);
+        f->pending = avail;
+        return rc;
+    }
     CSDR_HIP(hipMemcpyAsync(f->pin_out.p, f->d_out, (size_t)nproc * 8, hipMemcpyDeviceToHost, f->s));
     CSDR_HIP(hipStreamSynchronize(f->s));
     cvt_to_f64(out_iq, f->pin_out.p, 2 * (size_t)nproc);

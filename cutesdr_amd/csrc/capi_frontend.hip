@@ -109,6 +109,15 @@ int csdr__noiseproc_batch_process_packets(csdr_noiseproc_batch *b, const void *d
     return nb_run(b, nullptr, 0, WireIn{(const unsigned char *)d_packets, (long)npackets * pkt_len, pkt_len, per},
                   npackets * per, d_out, out_stride, stream);
 }
+/* internal: the shape of a blanker object (csdr_demod_batch_process_packets / _process_blanked check that it is theirs:
+ * the mask rows, and the state / history the down-converter indexes by input row, are sized by the CHAIN's width) */
+int csdr__noiseproc_batch_shape(csdr_noiseproc_batch *b, int *channels, int *device)
+{
+    if (!b) return fail(CSDR_EINVAL, "bad handle");
+    if (channels) *channels = b->channels;
+    if (device) *device = b->device;
+    return CSDR_OK;
+}
 /* internal (csdr_demod_batch_process_packets / _process with a blanker): MASK MODE -- the blanker decides, the
  * down-converter applies.  One pass over the call's samples (float rows, or datagrams when d_packets is given) leaves one
  * bit per sample in d_mask ([channels][mask_stride] words; set = blanked) and advances the blanker's state and

@@ -10,6 +10,7 @@
 // bench.py --gpus N keeps its one-process-per-GPU form (torch.distributed over RCCL): this object is for a host that
 // drives a whole node from one process, like the reference's single CSdrInterface.
 #include "capi_common.hpp"
+#include <map>
 #include <vector>
 
 using namespace csdr;
@@ -22,8 +23,11 @@ struct csdr_demod_shard {
     std::vector<float *> d_block; std::vector<size_t> block_cap;    // shared-stream mode: the wide-band block on each device
     std::vector<float *> d_sm;                           // 2 x count floats per shard: S-meter averages, peaks
     std::vector<int> input_row; int nrows = 0;           // shared-stream mode: receiver -> row of the block
-    std::vector<csdr_noiseproc_batch *> nb;              // per shard: CNoiseProc's blanker of its receivers (csdr_demod_shard_set_blanker)
-    bool committed = false;
+    std::vector<csdr_noiseproc_batch *> nb;              // per shard: CNoiseProc's blanker of its receivers (csdr_demod_shard_set_blanker):
+                                                         // empty (none) or one per shard, never partly built
+    std::vector<hipEvent_t> ev_block;                    // per shard: process_shared's reads of the caller's block are done
+    std::map<int, hipEvent_t> ev_ready;                  // per source device: the caller's block is complete (process_shared)
+    bool committed = false, pipelined = false;
     ~csdr_demod_shard()
     {
         for (size_t s = 0; s < b.size(); s++) {
@@ -33,8 +37,10 @@ struct csdr_demod_shard {
             if (s < nb.size() && nb[s]) csdr_noiseproc_batch_destroy(nb[s]);
             if (d_block[s]) (void)hipFree(d_block[s]);
             if (d_sm[s]) (void)hipFree(d_sm[s]);
+            if (s < ev_block.size() && ev_block[s]) (void)hipEventDestroy(ev_block[s]);
             if (stream[s]) (void)hipStreamDestroy(stream[s]);
         }
+        for (auto &e : ev_ready) { (void)hipSetDevice(e.first); (void)hipEventDestroy(e.second); }
     }
     int shard_of(int channel) const
     {
@@ -121,6 +127,7 @@ int csdr_demod_shard_set_pipelined(csdr_demod_shard *S, int on)
 {
     if (!S) return fail(CSDR_EINVAL, "bad handle");
     for (auto *b : S->b) { const int rc = csdr_demod_batch_set_pipelined(b, on); if (rc) return rc; }
+    S->pipelined = on != 0;
     return CSDR_OK;
 }
 /* One pass of every shard: d_in[s] = shard s's rows [count_s][in_stride] complex fp32 resident on ITS device,
@@ -143,15 +150,22 @@ int csdr_demod_shard_process(csdr_demod_shard *S, const float *const *d_in, long
 int csdr_demod_shard_set_blanker(csdr_demod_shard *S, int on, double threshold, double width_us, double sample_rate)
 {
     if (!S) return fail(CSDR_EINVAL, "bad handle");
-    S->nb.resize(S->b.size(), nullptr);
-    for (size_t s = 0; s < S->b.size(); s++) {
-        if (!S->nb[s]) {
-            S->nb[s] = csdr_noiseproc_batch_create(S->device[s], S->count[s]);
-            if (!S->nb[s]) return CSDR_EHIP;
+    // every shard's blanker or none: built aside and published only when all of them exist and are set up
+    std::vector<csdr_noiseproc_batch *> nb = S->nb;
+    const bool fresh = nb.empty();
+    int rc = CSDR_OK;
+    if (fresh)
+        for (size_t s = 0; s < S->b.size() && rc == CSDR_OK; s++) {
+            nb.push_back(csdr_noiseproc_batch_create(S->device[s], S->count[s]));
+            if (!nb.back()) { nb.pop_back(); rc = CSDR_EHIP; }       // (the error text is csdr_noiseproc_batch_create's)
         }
-        const int rc = csdr_noiseproc_batch_setup(S->nb[s], -1, on, threshold, width_us, sample_rate);
-        if (rc) return rc;
+    for (size_t s = 0; s < nb.size() && rc == CSDR_OK; s++)
+        rc = csdr_noiseproc_batch_setup(nb[s], -1, on, threshold, width_us, sample_rate);
+    if (rc != CSDR_OK) {
+        if (fresh) for (auto *p : nb) csdr_noiseproc_batch_destroy(p);
+        return rc;             // (existing blankers: SetupBlanker of the shards before the failing one has been applied)
     }
+    S->nb = nb;
     return CSDR_OK;
 }
 /* csdr_demod_batch_process_packets on every shard: d_packets[s] = shard s's receivers' datagrams on ITS device
@@ -161,10 +175,11 @@ int csdr_demod_shard_process_packets(csdr_demod_shard *S, const void *const *d_p
                                      float *const *d_out, long long out_stride, void *const *streams)
 {
     if (!S || !d_packets || !d_out) return fail(CSDR_EINVAL, "bad argument");
+    if (!S->nb.empty() && S->nb.size() != S->b.size()) return fail(CSDR_ESTATE, "blanker set up for %zu of %zu shards", S->nb.size(), S->b.size());
     int err = 0;
     for (size_t s = 0; s < S->b.size(); s++) {
         const int rc = csdr_demod_batch_process_packets(S->b[s], d_packets[s], npackets, pkt_len,
-                                                        s < S->nb.size() ? S->nb[s] : nullptr, d_out[s], out_stride,
+                                                        S->nb.empty() ? nullptr : S->nb[s], d_out[s], out_stride,
                                                         streams ? streams[s] : (void *)S->stream[s]);
         if (rc < 0 && !err) err = rc;
     }
@@ -206,7 +221,15 @@ int csdr_demod_shard_set_input_rows(csdr_demod_shard *S, const int *input_row, i
 }
 /* One pass in shared-stream mode: d_block [nrows][in_stride] complex fp32 resident on device `src_device`, handed over
  * ONCE; the object copies it to every other shard's device (hipMemcpyPeerAsync on that shard's stream, behind
- * `src_stream`'s work so far) and runs every shard on its copy.  The one broadcast SURVEY 8e names. */
+ * `src_stream`'s work so far) and runs every shard on its copy.  The one broadcast SURVEY 8e names.
+ * The caller's block is FREE AGAIN IN src_stream's ORDER when the call returns: src_stream is made to wait for every read
+ * of d_block this call enqueues -- the peer copies, and the shards that sit on src_device: strict mode reads the block
+ * in place (the whole pass is then in front of src_stream's next work), pipelined mode takes a device-to-device copy
+ * first, because there the down-converters of call k still run while call k+1 is being issued.  The per-shard copies
+ * d_block[s] are single buffers: before refilling one, the shard's stream waits until the previous call's
+ * down-converters have consumed it (csdr__demod_batch_wait_input_free) -- round-4 ADVICE: without that, pipelined call
+ * k+1's copy could overwrite what call k was still reading. */
+extern "C" int csdr__demod_batch_wait_input_free(csdr_demod_batch *b, void *stream);
 int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, int src_device, void *src_stream,
                                     long long in_stride, int n_per_channel, float *const *d_out, long long out_stride)
 {
@@ -214,15 +237,22 @@ int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, i
     if (in_stride < n_per_channel) return fail(CSDR_EINVAL, "input stride < n");
     const size_t bytes = (size_t)S->nrows * (size_t)in_stride * 8;
     if (!device_ok(src_device)) return CSDR_EHIP;
-    hipEvent_t ready = nullptr;
-    CSDR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    hipEvent_t &ready = S->ev_ready[src_device];
+    if (!ready) CSDR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
     CSDR_HIP(hipEventRecord(ready, (hipStream_t)src_stream));
+    S->ev_block.resize(S->b.size(), nullptr);
+    std::vector<char> recorded(S->b.size(), 0);
     int err = 0;
     for (size_t s = 0; s < S->b.size(); s++) {
         if (!device_ok(S->device[s])) { err = CSDR_EHIP; break; }
+        if (!S->ev_block[s]) CSDR_HIP(hipEventCreateWithFlags(&S->ev_block[s], hipEventDisableTiming));
         const float *in = d_block;
+        const bool copy = S->device[s] != src_device || S->pipelined;
         hipError_t e = hipStreamWaitEvent(S->stream[s], ready, 0);
-        if (e == hipSuccess && S->device[s] != src_device) {
+        if (e == hipSuccess && copy) {
+            // the previous call's readers of d_block[s] first (pipelined mode; a no-op in strict mode)
+            const int rcw = csdr__demod_batch_wait_input_free(S->b[s], (void *)S->stream[s]);
+            if (rcw) { err = rcw; break; }
             if (bytes > S->block_cap[s]) {
                 (void)hipStreamSynchronize(S->stream[s]);
                 if (S->d_block[s]) (void)hipFree(S->d_block[s]);
@@ -230,15 +260,25 @@ int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, i
                 e = hipMalloc((void **)&S->d_block[s], bytes);
                 if (e == hipSuccess) S->block_cap[s] = bytes;
             }
-            if (e == hipSuccess) e = hipMemcpyPeerAsync(S->d_block[s], S->device[s], d_block, src_device, bytes, S->stream[s]);
+            if (e == hipSuccess)
+                e = S->device[s] != src_device
+                        ? hipMemcpyPeerAsync(S->d_block[s], S->device[s], d_block, src_device, bytes, S->stream[s])
+                        : hipMemcpyAsync(S->d_block[s], d_block, bytes, hipMemcpyDeviceToDevice, S->stream[s]);
+            if (e == hipSuccess) e = hipEventRecord(S->ev_block[s], S->stream[s]);     // the caller's block has been read
             in = S->d_block[s];
         }
         if (e != hipSuccess) { err = fail(CSDR_EHIP, "broadcast to device %d: %s", S->device[s], hipGetErrorString(e)); break; }
         const int rc = csdr_demod_batch_process(S->b[s], in, in_stride, n_per_channel, d_out[s], out_stride, (void *)S->stream[s]);
         if (rc < 0 && !err) err = rc;
+        // in place (strict mode, same device): the pass itself is the reader; it has joined the shard's stream
+        if (!copy && hipEventRecord(S->ev_block[s], S->stream[s]) != hipSuccess && !err) err = fail(CSDR_EHIP, "hipEventRecord");
+        recorded[s] = 1;
     }
+    // (src_stream may be the NULL stream, which is the CURRENT device's: back to the source device first)
     (void)hipSetDevice(src_device);
-    (void)hipEventDestroy(ready);
+    for (size_t s = 0; s < S->b.size(); s++)
+        if (recorded[s] && hipStreamWaitEvent((hipStream_t)src_stream, S->ev_block[s], 0) != hipSuccess && !err)
+            err = fail(CSDR_EHIP, "hipStreamWaitEvent");
     return err;
 }
 /* waits for everything issued on the shards' own streams */

@@ -791,6 +791,13 @@ class ShardedDemodBatch(_Obj):
             b.free()
         return self._collect(outs, cap)
 
+    def process_shared_ptr(self, d_block, src_device, T, in_stride, outs, cap, src_stream=None):
+        """the raw call: block [nrows][in_stride] resident on src_device, one output buffer per shard; asynchronous"""
+        pout = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
+        check(lib().csdr_demod_shard_process_shared(self.h, C.c_void_p(d_block), src_device,
+                                                    C.c_void_p(src_stream) if src_stream else None, in_stride, T, pout, cap),
+              "csdr_demod_shard_process_shared")
+
     def process_shared(self, block, src_device=0):
         """block complex [nrows, T] (host) -> uploaded once to src_device, broadcast by the object"""
         block = np.ascontiguousarray(block, dtype=np.complex64)

@@ -245,6 +245,14 @@ int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, do
 typedef struct csdr_demod_batch csdr_demod_batch;
 csdr_demod_batch *csdr_demod_batch_create(int device, int channels, int fastfir_n);
 void csdr_demod_batch_destroy(csdr_demod_batch *b);
+/* CDemodulator::SetInputSampleRate (dsp/demodulator.cpp:92-99) of every receiver.  Before commit(): recorded.  After
+ * commit(): applied at once, at any time, as the host does on every bandwidth switch of the radio
+ * (interface/sdrinterface.cpp:753-754): every down-converter is rebuilt for the new rate (new stage list from zeroed
+ * histories; oscillator phase and amplitude kept; the CW offset added once more, downconvert.cpp:169), the output rate
+ * and the S-meter's time constants follow, and -- like the reference -- filter taps and overlap, AGC constants and rings
+ * and the demodulator objects stay as they are until the receiver's next SetDemod, which for an unchanged mode keeps the
+ * demodulator built for the old output rate.  Receivers keep their rows while a plan group still shares one decimation;
+ * one whose new chain decimates differently from its group's moves as after a mode change.  Synchronises the device. */
 int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate);
 /* CDemodulator::SetDemod (dsp/demodulator.cpp:107-157) of one receiver.  Before commit(): recorded.  After commit():
  * applied at once, like the reference between two ProcessData calls -- also a mode whose maximum bandwidth (hence
@@ -312,7 +320,7 @@ csdr_demod_shard *csdr_demod_shard_create(const int *devices, int nshards, int c
 void csdr_demod_shard_destroy(csdr_demod_shard *s);
 int csdr_demod_shard_count(csdr_demod_shard *s);
 int csdr_demod_shard_range(csdr_demod_shard *s, int shard, int *first, int *count, int *device);
-int csdr_demod_shard_set_input_rate(csdr_demod_shard *s, double rate);
+int csdr_demod_shard_set_input_rate(csdr_demod_shard *s, double rate);   /* every shard's batch; before or after commit */
 int csdr_demod_shard_set_demod(csdr_demod_shard *s, int channel, int mode, const csdr_demod_info *info);
 int csdr_demod_shard_commit(csdr_demod_shard *s);
 int csdr_demod_shard_set_freq(csdr_demod_shard *s, int channel, double freq);

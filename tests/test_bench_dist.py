@@ -63,6 +63,24 @@ def test_under_torch_distributed_run():
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2
 
 
+def test_eight_ranks_the_shape_of_the_scaling_run():
+    """What the driver's 8-GPU run looks like to bench.py, rehearsed with eight gloo ranks on the CPU:
+    started the driver's way (torch.distributed.run, 8 processes), eight CONTIGUOUS channel ranges of 256, ONE JSON line
+    from rank 0, whole-job value = 8 x the per-rank work over the slowest rank's time."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["rank_channels"] == [[256 * k, 256 * (k + 1)] for k in range(8)]
+    assert abs(line["value"] - 8 * 256 * 4096 * 3 / (line["ms_per_step"] * 3e-3) / 1e6) / line["value"] < 1e-3
+    assert "x8" in line["config"]["parallelism"]
+
+
 def test_two_rank_gloo_aggregation(tmp_path):
     script = tmp_path / "run.py"
     script.write_text(

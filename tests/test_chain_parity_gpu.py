@@ -230,6 +230,70 @@ def test_c4_shard_256_mixed_receivers_distinct_streams(oracle):
     assert dsm.max() <= 0.02, (int(np.argmax(dsm)), dsm.max())
 
 
+def test_c4_full_width_2048_receivers_in_8_shards(oracle):
+    """BASELINE config C4 at its FULL width -- 2048 receivers, 683 AM / 683 FM / 682 USB by turns (bench.py's C4 mix,
+    c4_stream), eight shards of 256 -- behind ONE csdr_demod_shard object; on the one-GPU box the eight shards share
+    device 0 (several shards may name one device), on a node each gets its own.  Sixteen m_InBufLimit windows per receiver.
+    (i) 96 receivers, twelve from every shard and every mode among them, against their own oracle CDemodulator under
+    the chain rule, their S-meters within 0.02 dB; (ii) ALL 2048 receivers and S-meters word for word against eight
+    256-wide csdr_demod_batch objects fed the same rows (the per-GPU share test_c4_shard_256... checks against the
+    oracle receiver by receiver)."""
+    import cutesdr_amd as ca
+    C, S, fs, T = 2048, 8, 2e6, 16 * 19968
+    names = ["AM", "FM", "USB"]
+    ndev = ca._capi.lib().csdr_device_count()
+    devices = list(range(S)) if ndev >= S else [0] * S
+    sh = ca.ShardedDemodBatch(devices, C, 2048)
+    assert [r[:2] for r in sh.ranges] == [(256 * k, 256) for k in range(S)]
+    sh.set_input_rate(fs)
+    for c in range(C):
+        m, kw = MODES[names[c % 3]]
+        sh.set_demod(c, m, info(ca, **kw))
+    sh.commit()
+    for c in range(C):
+        sh.set_freq(c, -(100e3 + 500.0 * (c % 256)))
+    x = np.empty((C, T), dtype=np.complex64)
+
+    def gen(c):                                                # (carriers repeat per shard, noise and kind do not)
+        x[c] = c4_stream(c, T, fs).astype(np.complex64) * np.exp(-2j * np.pi * 500.0 * (c - c % 256) * np.arange(T) / fs)
+    with cf.ThreadPoolExecutor(16) as ex:
+        list(ex.map(gen, range(C)))
+    got = sh.process(x)
+    sm = sh.smeter_all()
+    assert len(got) == C and all(len(g) == (T // 32 if c % 3 else T // 64) // 1024 * 1024 for c, g in enumerate(got))
+
+    picks = [256 * k + j for k in range(S) for j in (0, 1, 2, 85, 86, 87, 127, 128, 129, 253, 254, 255)]
+
+    def check(c):
+        name = names[c % 3]
+        m, kw = MODES[name]
+        r = oracle.CDemodulator(2048)
+        r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-(100e3 + 500.0 * (c % 256)))
+        want = r.process_append(x[c].astype(np.complex128))
+        assert len(want) == len(got[c]) and len(want) >= T // 64 - 1024, (c, len(want), len(got[c]))
+        check_chain_bursts(burst_errors(got[c], want), name, what=(c, name))
+        return abs(float(sm[c]) - r.GetSMeterAve())
+
+    with cf.ThreadPoolExecutor(16) as ex:
+        dsm = np.array(list(ex.map(check, picks)))
+    assert dsm.max() <= 0.02, (picks[int(np.argmax(dsm))], dsm.max())
+    del sh
+    for k in range(S):                                         # word for word: one 256-wide batch per shard's range
+        b = ca.DemodBatch(256, 2048, device=devices[k])
+        b.set_input_rate(fs)
+        for j in range(256):
+            m, kw = MODES[names[(256 * k + j) % 3]]
+            b.set_demod(j, m, info(ca, **kw))
+        b.commit()
+        for j in range(256):
+            b.set_freq(j, -(100e3 + 500.0 * j))
+        one = b.process(x[256 * k:256 * (k + 1)])
+        for j in range(256):
+            assert np.array_equal(one[j].view(np.uint32), got[256 * k + j].view(np.uint32)), (k, j)
+        assert np.array_equal(b.smeter_all(), sm[256 * k:256 * (k + 1)]), k
+        del b
+
+
 def test_pipelined_mode_gives_the_strict_mode_results():
     """csdr_demod_batch_set_pipelined: the post-chain of call k overlaps the down-converter of call k+1 on
     internal streams; four calls issued back to back without any host synchronisation, one flush at the end --

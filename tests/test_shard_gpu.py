@@ -105,6 +105,68 @@ def test_shared_block_is_broadcast_to_every_shard(oracle):
         del sh
 
 
+def test_shared_block_reused_by_back_to_back_pipelined_calls():
+    """in pipelined mode the down-converters of call k still run on the batch's own streams while
+    call k+1 is being issued, so a second csdr_demod_shard_process_shared that refilled the per-shard copy of the block --
+    or a caller that refilled ITS block -- raced with them.  The contract now: when the call returns the caller's block is
+    free again in src_stream's order.  Three calls back to back, NO host synchronisation in between, the caller's ONE
+    block buffer overwritten with the next block right after each call (a plain copy on the source stream): every word
+    equals what a strict-mode object gives with a synchronisation after every call."""
+    import cutesdr_amd as ca
+    fs, lim = 2e6, 19968
+    names = ["FM", "AM", "USB", "FM", "AM", "USB", "FM", "AM", "USB", "SAM", "FM", "USB"]
+    C, S, n, calls = len(names), 2, lim * 24, 3
+    t = np.arange(n)
+    blocks = []
+    for k in range(calls):
+        blk = np.zeros((S, n), dtype=np.complex128)
+        for c, m in enumerate(names):
+            blk[c % S] += 0.25 * make_input(m, n, fs)[::-1 if k == 1 else 1] * np.exp(2j * np.pi * (40e3 * (c // S) + 3e3 * k) * t / fs)
+        blocks.append(blk.astype(np.complex64))
+    rows = np.array([c % S for c in range(C)], dtype=np.int32)
+
+    def build(devices, pipelined):
+        sh = ca.ShardedDemodBatch(devices, C, 2048)
+        sh.set_input_rate(fs)
+        for c, name in enumerate(names):
+            m, kw = MODES[name]
+            sh.set_demod(c, m, info(ca, **kw))
+        sh.commit()
+        for c in range(C):
+            sh.set_freq(c, -(100e3 + 40e3 * (c // S)))
+        sh.set_input_rows(rows, S)
+        if pipelined:
+            sh.set_pipelined(True)
+        return sh
+
+    for devices in _device_sets():
+        if C // len(devices) < S:
+            continue
+        strict = build(devices, False)
+        want = [strict.process_shared(blocks[k], src_device=devices[-1]) for k in range(calls)]
+        del strict
+        sh = build(devices, True)
+        src = devices[-1]
+        cap = n + 2048
+        dblk = ca.DeviceBuffer(blocks[0].nbytes, src)
+        outs = [sh._outs(cap) for _ in range(calls)]
+        counts = []
+        for k in range(calls):                                 # upload (null stream of src), call, next upload at once
+            dblk.upload(blocks[k])
+            sh.process_shared_ptr(dblk.ptr, src, n, n, outs[k], cap)
+            counts.append([sh.out_count(c) for c in range(C)])
+        sh.sync()
+        for k in range(calls):
+            for (f, cnt, d), o in zip(sh.ranges, outs[k]):
+                y = o.download(np.float32, cnt * cap).reshape(cnt, cap)
+                for i in range(cnt):
+                    c = f + i
+                    assert counts[k][c] == len(want[k][c]), (devices, k, c)
+                    assert np.array_equal(y[i, :counts[k][c]].view(np.uint32), want[k][c].view(np.uint32)), (devices, k, c, names[c])
+        assert any(len(w) for w in want[2])
+        del sh
+
+
 @pytest.mark.parametrize("form", ["packets16", "packets24", "packets24-no-blanker", "rows"])
 def test_shards_with_the_blanker_equal_one_wide_batch(form):
     """The datagram and blanker forms behind the shard object (csdr_demod_shard_set_blanker / _process_packets /
