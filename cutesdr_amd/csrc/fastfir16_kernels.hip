@@ -191,183 +191,7 @@ int fastfir16_bin_of(int slot)
     return (t3 >> 3) + 16 * (t3 & 7) + 128 * kc;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// N = 4096 the same way (round 4): 256 threads x 16 points, N = 16 x 16 x 16.  The generic kernel ran this size as 128
-// threads x 32 points, two waves per workgroup at 272 registers (2.2 TB/s at 256 channels x 2^19).  Same three passes as
-// above with B = 16 points in the middle one, so that F2 / I2 take ONE column of sixteen per thread (thread (ka, c))
-// instead of a column pair of eight, and the pass twiddle W_256^{c kb} needs the quadrant of W_N (N = 4096: W_N^1024 = j).
-//   n = 256 a + 16 b + c     k = ka + 16 kb + 256 kc        LDS cell of (ka, x, c): 304 ka + 18 x + c
-// F2 -> F3 -> I2 stay inside the wave that owns ka (four per wave); H slot kc * 256 + t3 for thread t3 = 16 ka + kb.
-// ---------------------------------------------------------------------------------------------------------------------
-namespace {
-constexpr int F4K_N = 4096, F4K_T = 256, F4K_L = 2048;
-// A ka plane is 16 rows of 18 cells + 16 cells of padding: 288 cells are 576 words, a multiple of the 64 banks, and the
-// four ka of a wave in F2 / I2 (same column, same row) would meet in one bank -- with the pad a ka step is 32 banks
-// (PMC: 38 % of this kernel's LDS cycles were bank conflicts before)
-constexpr int F4K_KA = 18 * 16 + 16;
-constexpr int F4K_LDS_DATA = F4K_KA * 16;
-constexpr int F4K_LDS_BYTES = (F4K_LDS_DATA + 256) * 8;  // + the 16 x 16 twiddles of F2 / I2
-}  // namespace
-
-// every sample is read once and written once: non-temporal policy on the streams (K1 measured -1.2 % for the same)
-#ifdef CSDR_F4K_NO_NT
-#define F4K_LD(p) (*(p))
-#define F4K_ST(v, p) (*(p) = (v))
-#else
-#define F4K_LD(p) __builtin_nontemporal_load(p)
-#define F4K_ST(v, p) __builtin_nontemporal_store(v, p)
-#endif
-__global__ __launch_bounds__(F4K_T)
-void fastfir4k_kernel(FastFirArgs a)
-{
-    constexpr int T = F4K_T, L = F4K_L;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-    v2f *twB = lds + F4K_LDS_DATA;                        // twB[16 kb + c] = W_256^{c kb}
-    const int t = threadIdx.x;
-
-    int wg = blockIdx.x, ch, run;
-    if ((a.channels & 7) == 0) {                          // the runs of a channel (one H) on one XCD's L2
-        const int xcd = wg & 7, slot = wg >> 3;
-        ch = (slot / a.runs) * 8 + xcd;
-        run = slot % a.runs;
-    } else {
-        ch = wg / a.runs;
-        run = wg % a.runs;
-    }
-    const int b0 = run * a.blocks_per_run;
-    int b1 = b0 + a.blocks_per_run;
-    if (b1 > a.nblocks) b1 = a.nblocks;
-    if (ch >= a.channels || b0 >= b1) return;             // uniform per workgroup
-
-    const v2f *tw1 = reinterpret_cast<const v2f *>(a.tw1);    // W_N^n, n < 1024
-    {
-        const int m = 16 * (t & 15) * (t >> 4);           // W_256^{c kb} = W_N^{16 c kb}; W_N^1024 = +j (positive exponent)
-        v2f v = tw1[m & 1023];
-        const int q = (m >> 10) & 3;
-        if (q == 1) v = v2f{-v.y, v.x};
-        else if (q == 2) v = -v;
-        else if (q == 3) v = v2f{v.y, -v.x};
-        twB[t] = v;
-    }
-    v2f pw[16];                                           // W_N^{t ka}: resident
-    twiddle_powers<16>(tw1[t], pw);
-
-    const v2f *in = reinterpret_cast<const v2f *>(a.in) + (long)ch * a.in_stride;
-    v2f *out = reinterpret_cast<v2f *>(a.out) + (long)ch * a.out_stride;
-    const v2f *hist = reinterpret_cast<const v2f *>(a.hist) + (long)ch * L;
-    const v2f *H = reinterpret_cast<const v2f *>(a.h) + (long)ch * a.h_stride * 2;   // h_stride counts float4
-
-    v2f carry[8], nxt[8];                                 // rows a of the old / the new half: sample 256 a + t
-    {
-        const v2f *src = b0 == 0 ? hist : in + (long)(b0 - 1) * L;
-#pragma unroll
-        for (int q = 0; q < 8; q++) carry[q] = src[T * q + t];
-#pragma unroll
-        for (int q = 0; q < 8; q++) nxt[q] = F4K_LD(&in[(long)b0 * L + T * q + t]);
-    }
-    const int ka2 = t >> 4, c2 = t & 15;                  // F2 / I2: column c of ka; F3: thread t = 16 ka + kb owns row t
-    __syncthreads();                                      // twB
-
-    for (int b = b0; b < b1; b++) {
-        v2f x[16];
-#pragma unroll
-        for (int q = 0; q < 8; q++) { x[q] = carry[q]; x[8 + q] = nxt[q]; carry[q] = nxt[q]; }
-        if (b + 1 < b1) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) nxt[q] = F4K_LD(&in[(long)(b + 1) * L + T * q + t]);
-        }
-        // ---------------- F1: DIF over a, twiddle, column c of row b of every ka ----------------
-        dft_dif<16, +1>(x);
-        static_for<0, 16>([&](auto Rr) {
-            constexpr int r = Rr.value, ka = bitrev<16>(r);
-            if constexpr (ka != 0) x[r] = cmul(x[r], pw[ka]);
-            // (no barrier in front: these are the cells this thread itself read in I1 of the previous block)
-            lds[F4K_KA * ka + row18(t >> 4, t & 15)] = x[r];
-        });
-        __syncthreads();
-        // ---------------- F2: DIF over b for this column, twiddle, in place ----------------
-        {
-            v2f *cell = lds + F4K_KA * ka2 + c2;          // (ka, b, c) at cell + 18 b
-#pragma unroll
-            for (int q = 0; q < 16; q++) x[q] = cell[18 * q];
-            dft_dif<16, +1>(x);
-            static_for<0, 16>([&](auto Rr) {
-                constexpr int r = Rr.value, kb = bitrev<16>(r);
-                if constexpr (kb != 0) x[r] = cmul(x[r], twB[16 * kb + c2]);
-                cell[18 * kb] = x[r];
-            });
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---------------- F3 + H + I3: row t, registers only ----------------
-        {
-            v2f hv[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) hv[q] = H[T * q + t];        // slot kc * 256 + t (L2)
-            v2f *row = lds + F4K_KA * ka2 + 18 * c2;      // row (ka, kb) = (t >> 4, t & 15)
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const v4f v = *reinterpret_cast<const v4f *>(row + 2 * q);
-                x[2 * q] = v2f{v.x, v.y}; x[2 * q + 1] = v2f{v.z, v.w};
-            }
-            dft_dif<16, +1>(x);
-            static_for<0, 16>([&](auto Rr) { x[Rr.value] = cmul(x[Rr.value], hv[bitrev<16>(Rr.value)]); });
-            dft_dit<16, -1>(x);
-            static_for<0, 16>([&](auto Cc) {
-                constexpr int c = Cc.value;
-                // W_256^{c kb}, kb = t & 15: the table is symmetric, and read as [c][kb] the sixteen kb of a wave are
-                // sixteen neighbouring cells ([kb][c] is a stride of 32 banks: eight lanes to a bank)
-                if constexpr (c != 0) x[c] = cmul_conj(x[c], twB[16 * c + c2]);
-            });
-#pragma unroll
-            for (int q = 0; q < 8; q++)                   // two cells per store, like the loads: no two rows of a pass in one bank
-                *reinterpret_cast<v4f *>(row + 2 * q) = v4f{x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y};
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---------------- I2: DIT back over kb for this column, in place ----------------
-        {
-            v2f *cell = lds + F4K_KA * ka2 + c2;
-            static_for<0, 16>([&](auto Rr) {
-                constexpr int r = Rr.value, kb = bitrev<16>(r);
-                x[r] = cell[18 * kb];
-            });
-            dft_dit<16, -1>(x);
-#pragma unroll
-            for (int q = 0; q < 16; q++) cell[18 * q] = x[q];
-        }
-        __syncthreads();
-        // ---------------- I1: conjugate twiddle, DIT back over ka, the valid half out ----------------
-        static_for<0, 16>([&](auto Rr) {
-            constexpr int r = Rr.value, ka = bitrev<16>(r);
-            x[r] = lds[F4K_KA * ka + row18(t >> 4, t & 15)];
-            if constexpr (ka != 0) x[r] = cmul_conj(x[r], pw[ka]);
-        });
-        dft_dit<16, -1>(x);
-#pragma unroll
-        for (int q = 0; q < 8; q++) F4K_ST(x[8 + q], &out[(long)b * L + T * q + t]);
-    }
-    if (b1 == a.nblocks) {
-        v2f *hn = reinterpret_cast<v2f *>(a.hist_next) + (long)ch * L;
-#pragma unroll
-        for (int q = 0; q < 8; q++) hn[T * q + t] = carry[q];
-    }
-}
-
-hipError_t fastfir4k_launch(const FastFirArgs &a, hipStream_t stream)
-{
-    hipLaunchKernelGGL(fastfir4k_kernel, dim3(a.channels * a.runs), dim3(F4K_T), F4K_LDS_BYTES, stream, a);
-    return hipGetLastError();
-}
-// natural-order spectrum bin of H slot i (= kc * 256 + t3, thread t3 = 16 ka + kb): k = ka + 16 kb + 256 kc
-int fastfir4k_bin_of(int slot)
-{
-    const int kc = slot >> 8, t3 = slot & 255;
-    return (t3 >> 4) + 16 * (t3 & 15) + 256 * kc;
-}
-
+// (N = 4096 had a kernel of this shape here in round 4 -- 256 threads x 16 points, 0.378 of the roofline; since round 5 the
+// pipelined build of fastfir2_kernels.hip takes that size, two blocks per workgroup: 13 % faster.)
 
 }  // namespace csdr

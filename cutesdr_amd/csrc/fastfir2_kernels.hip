@@ -1,4 +1,7 @@
-// fastfir2_kernels.hip -- batched overlap-save FFT FIR for gfx950, software-pipelined build (K1).
+// fastfir2_kernels.hip -- batched overlap-save FFT FIR for gfx950, software-pipelined build (K1): N = 16384 (the
+// headline configuration), and since round 5 N = 8192 and 4096 -- the same passes with an outer pass of radix 8 / 4 over
+// four / eight columns per thread (the instruction stream of the 16384-point instantiation is unchanged, checked in the
+// ISA), 4096 points as two blocks side by side per workgroup (K1Cfg below).
 //
 // Same algorithm, LDS image, spectrum order and HBM traffic as fastfir_os_kernel
 // (fastfir_kernels.hip; reference dsp/fastfir.cpp:268-321, dsp/fft.cpp:416-426): passes
@@ -38,6 +41,9 @@ namespace csdr {
 #ifndef K1_HREG
 #define K1_HREG 8           // float4 of this thread's share of H that stay in registers for the whole run (0..8 fit)
 #endif
+#ifndef K1_HREG4K
+#define K1_HREG4K 4         // ... at N = 4096, whose outer pass (eight columns of four points) keeps more values live
+#endif
 
 // Diagnostic build only (-DCSDR_K1_STAMPS, tools/k1_stamps.py): cycle shares of the passes of one block,
 // summed per wave in scalar registers and written to a.dbg after the loop.  No stamp executes otherwise.
@@ -69,20 +75,39 @@ namespace csdr {
 __device__ __forceinline__ void keep_alive(v4f v) { asm volatile("" ::"v"(v)); }
 #endif
 
+// N = 4096 runs TWO blocks side by side in one workgroup: a block of 4096 points is 128 threads and 43 KB of LDS, three
+// workgroups -- six waves -- per CU, against the eight (two per SIMD) the schedule below is made for.  Two "virtual
+// workgroups" of 128 threads, each with its own LDS image and its own run of blocks, sharing the twiddle table and the
+// (then merely coincident) barriers: 256 threads, 78 KB, two per CU, eight waves -- the shape of the 8192-point launch.
 template <int LOG2N>
-__global__ __launch_bounds__(FastFirCfg<LOG2N>::T)
+struct K1Cfg {
+    using Base = FastFirCfg<LOG2N>;
+    static constexpr int VW = LOG2N == 12 ? 2 : 1;                          // virtual workgroups per workgroup
+    static constexpr int TV = Base::T;                                      // threads of one block
+    static constexpr int T = VW * TV;
+    static constexpr int LDS_BYTES = (VW * Base::LDS_DATA + 1024) * 8;
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(K1Cfg<LOG2N>::T) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fastfir_os2_kernel(FastFirArgs a)
 {
     using Cfg = FastFirCfg<LOG2N>;
     constexpr int N = Cfg::N, T = Cfg::T, R0 = Cfg::R0, G = Cfg::G, L = N / 2;
     constexpr int HALF = R0 / 2;
-    static_assert(R0 == 16 && G == 2, "the grouped outer pass is written for N = 16384");
+    constexpr int VW = K1Cfg<LOG2N>::VW;
+    constexpr int HREG = LOG2N == 12 ? K1_HREG4K : K1_HREG;   // resident float4 of H
+    static_assert(R0 == 16 || R0 == 8 || R0 == 4, "the grouped outer pass is written for N = 16384, 8192 and 4096");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-    v2f *tw2 = lds + Cfg::LDS_DATA;           // tw2[k1*32 + n2] = W_1024^{n2*k1}
+    const int t = VW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T, vw = VW == 1 ? 0 : (int)threadIdx.x / T;
+    v2f *lds = reinterpret_cast<v2f *>(smem_raw) + vw * Cfg::LDS_DATA;
+    v2f *tw2 = reinterpret_cast<v2f *>(smem_raw) + VW * Cfg::LDS_DATA;     // tw2[k1*32 + n2] = W_1024^{n2*k1}
+    if constexpr (VW > 1) {                   // (a virtual workgroup that has nothing to do leaves below: the table is whole first)
+        for (int i = threadIdx.x; i < 1024; i += VW * T) tw2[i] = a.tw2[i];
+        __syncthreads();
+    }
 
-    const int t = threadIdx.x;
-    int wg = blockIdx.x, ch, run;
+    int wg = blockIdx.x * VW + vw, ch, run;
     if ((a.channels & 7) == 0) {
         int xcd = wg & 7, slot = wg >> 3;
         ch = (slot / a.runs) * 8 + xcd;
@@ -94,29 +119,37 @@ void fastfir_os2_kernel(FastFirArgs a)
     const int b0 = run * a.blocks_per_run;
     int b1 = b0 + a.blocks_per_run;
     if (b1 > a.nblocks) b1 = a.nblocks;
-    if (ch >= a.channels || b0 >= b1) return;          // uniform per workgroup
+    if (ch >= a.channels || b0 >= b1) return;          // uniform per (virtual) workgroup
 
-    for (int i = t; i < 1024; i += T) tw2[i] = a.tw2[i];
+    if constexpr (VW == 1)
+        for (int i = t; i < 1024; i += T) tw2[i] = a.tw2[i];
 
     const rsrc_t r_in = make_rsrc(a.in + (long)ch * a.in_stride, (unsigned)a.nblocks * L * 8u);
     const rsrc_t r_hist = make_rsrc(a.hist + (long)ch * L, L * 8u);
     const rsrc_t r_out = make_rsrc(a.out + (long)ch * a.out_stride, (unsigned)a.nblocks * L * 8u);
     const rsrc_t r_h = make_rsrc(a.h + (long)ch * a.h_stride, N * 8u);
-    const int voff = t * (G * 8);
+    // A thread's G columns of the outer pass are G / 2 PAIRS, pair pp = columns PSTEP pp + 2t, + 1 (PSTEP = 2 T: every
+    // load, store and 16-byte LDS access of a wave covers 64 adjacent pairs -- with G adjacent columns per thread the
+    // four 16-byte accesses of the 4096-point kernel each touched a quarter of every line: 1.8 ms instead of 0.8)
+    constexpr int PSTEP = 2 * T, PSTEP_LDS = PSTEP + 2 * (PSTEP / 32), PSTEP_B = PSTEP * 8;
+    const int voff = t * 16;
+    // one hop-half of samples: rows n1 = 0..HALF-1 of 1024 samples, this thread's G / 2 column pairs
     auto load_half = [&](rsrc_t r, int soff, v2f (&dst)[16]) {
 #pragma unroll
-        for (int n1 = 0; n1 < HALF; n1++) {
-            v4f v = buf_load16_aux<K1_LDAUX>(r, voff, soff + n1 * 8192);
-            dst[n1] = v2f{v.x, v.y};
-            dst[HALF + n1] = v2f{v.z, v.w};
-        }
+        for (int n1 = 0; n1 < HALF; n1++)
+#pragma unroll
+            for (int pp = 0; pp < G / 2; pp++) {
+                v4f v = buf_load16_aux<K1_LDAUX>(r, voff + pp * PSTEP_B, soff + n1 * 8192);
+                dst[(2 * pp) * HALF + n1] = v2f{v.x, v.y};
+                dst[(2 * pp + 1) * HALF + n1] = v2f{v.z, v.w};
+            }
     };
 
     // outer-pass twiddles W_N^{n2 k0}, n2 = 2t+e, k0 = 1..15: pw[e][k0].  Rebuilt at the top of every
     // I3 and kept for F1 of the next block only: live across the whole loop they would not fit beside H
     v2f w1[G];
 #pragma unroll
-    for (int e = 0; e < G; e++) w1[e] = a.tw1[G * t + e];
+    for (int e = 0; e < G; e++) w1[e] = a.tw1[PSTEP * (e / 2) + 2 * t + (e & 1)];
     v2f pw[G][R0];
 #pragma unroll
     for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);
@@ -126,7 +159,7 @@ void fastfir_os2_kernel(FastFirArgs a)
     // L2 costs about as much energy as four packed instructions -- the rest is fetched from L2 for every block
     v4f hv[16];
 #pragma unroll
-    for (int j = 0; j < K1_HREG; j++) hv[j] = buf_load16(r_h, t * 16, j * (T * 16));
+    for (int j = 0; j < HREG; j++) hv[j] = buf_load16(r_h, t * 16, j * (T * 16));
 #ifdef K1_ABLATE
     v4f habl = {1.0f, 0.0f, 1.0f, 0.0f};
     asm volatile("" : "+v"(habl));
@@ -134,7 +167,7 @@ void fastfir_os2_kernel(FastFirArgs a)
     asm volatile("" : "+v"(twabl));
 #endif
     v2f x[32];           // phase B: the 32 points of this thread
-    // The two halves of a block's input, [n1] = column 2t row n1, [8 + n1] = column 2t+1 row n1.  The new
+    // The two halves of a block's input, [e * HALF + n1] = column PSTEP (e / 2) + 2t + (e & 1), row n1.  The new
     // half of one block is the old half of the next: the block loop is unrolled by two and the buffers
     // swap roles, so nothing is copied; the samples after next are fetched into the old half's registers
     // as soon as the first butterfly stage has read them.
@@ -148,7 +181,7 @@ void fastfir_os2_kernel(FastFirArgs a)
     v2f *const col = lds + lds_pad(1024 * sb) + sn;         // F2 / I2: point n1 at col[34 * n1]
     const v2f *const twc = tw2 + sn;                        // twiddle k1 at twc[32 * k1]
     v2f *const rowp = lds + 34 * t;                         // F3: this thread's 32 consecutive points
-    v2f *const outer = lds + lds_pad(G * t);                // F1 / I3: row k0 at outer[lds_pad(1024) * k0]
+    v2f *const outer = lds + lds_pad(2 * t);                // F1 / I3: row k0, pair pp at outer[OUTER_ROW k0 + PSTEP_LDS pp]
     constexpr int OUTER_ROW = 1024 + 2 * (1024 / 32);       // padded elements between rows of the outer pass
 
 #ifdef K1_CYC          // diagnostic build (tools/k1_cycles.py): shader cycles and real time of the whole block loop
@@ -166,13 +199,16 @@ void fastfir_os2_kernel(FastFirArgs a)
         CSDR_SB();
         CSDR_PRIO(1);
         {
-            v2f y0[R0], y1[R0];
+            v2f y[G][R0];
             static_for<0, HALF>([&](auto N1) {
-                constexpr int n1 = N1.value, po = bitrev<R0>(n1), pn = bitrev<R0>(HALF + n1);
-                y0[po] = oldh[n1];        y0[pn] = newh[n1];
-                y1[po] = oldh[HALF + n1]; y1[pn] = newh[HALF + n1];
+                static_for<0, G>([&](auto E) {
+                    constexpr int e = E.value, n1 = N1.value, po = bitrev<R0>(n1), pn = bitrev<R0>(HALF + n1);
+                    y[e][po] = oldh[e * HALF + n1]; y[e][pn] = newh[e * HALF + n1];
+                });
             });
-            static_for<0, R0 / 4>([&](auto Gg) { dit_head4<Gg.value, R0, +1>(y0); dit_head4<Gg.value, R0, +1>(y1); });
+            static_for<0, (R0 >= 8 ? R0 / 4 : 1)>([&](auto Gg) {
+                static_for<0, G>([&](auto E) { dit_head4<Gg.value, R0, +1>(y[E.value]); });
+            });
             CSDR_SB();
             // block b+1's new half: into the registers of the old half, which the butterflies above have read
             // (unconditional, so that the block stays one straight line of code: after the last block of the
@@ -180,32 +216,67 @@ void fastfir_os2_kernel(FastFirArgs a)
             load_half(r_in, (b + 1 < a.nblocks ? b + 1 : a.nblocks - 1) * (L * 8), oldh);
             CSDR_SB();
             CSDR_PRIO(0);
-            v4f wv[R0];
-            static_for<0, R0 / 4 + 1>([&](auto Ii) {
-                constexpr int i = Ii.value;                // tail group i finishes rows k0 = i, i+4, i+8, i+12
-                if constexpr (i < R0 / 4) {
-                    dit_tail<i, R0, +1>(y0);
-                    dit_tail<i, R0, +1>(y1);
-                    static_for<0, 4>([&](auto P) {
-                        constexpr int k0 = i + 4 * P.value;
-                        if constexpr (k0 != 0) {
-                            y0[k0] = cmul(y0[k0], pw[0][k0]);
-                            y1[k0] = cmul(y1[k0], pw[1][k0]);
-                        }
-                        wv[k0] = store_operand(y0[k0], y1[k0]);
-                    });
-                }
-                if constexpr (i > 0) {                 // rows of the previous group: written while this one computes
-                    CSDR_STORE_GROUP_BEGIN();
-                    static_for<0, 4>([&](auto P) {
-                        constexpr int k0 = (i - 1) + 4 * P.value;
-                        *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0) = wv[k0];
-                    });
-                    CSDR_STORE_GROUP_END();
-                } else {
-                    CSDR_SB();
-                }
-            });
+            v4f wv[16];                                    // (R0 rows) x (G / 2 column pairs): row k0, pair pp at [k0 * (G / 2) + pp]
+            if constexpr (R0 == 16) {
+                static_for<0, R0 / 4 + 1>([&](auto Ii) {
+                    constexpr int i = Ii.value;                // tail group i finishes rows k0 = i, i+4, i+8, i+12
+                    if constexpr (i < R0 / 4) {
+                        dit_tail<i, R0, +1>(y[0]);
+                        dit_tail<i, R0, +1>(y[1]);
+                        static_for<0, 4>([&](auto P) {
+                            constexpr int k0 = i + 4 * P.value;
+                            if constexpr (k0 != 0) {
+                                y[0][k0] = cmul(y[0][k0], pw[0][k0]);
+                                y[1][k0] = cmul(y[1][k0], pw[1][k0]);
+                            }
+                            wv[k0] = store_operand(y[0][k0], y[1][k0]);
+                        });
+                    }
+                    if constexpr (i > 0) {                 // rows of the previous group: written while this one computes
+                        CSDR_STORE_GROUP_BEGIN();
+                        static_for<0, 4>([&](auto P) {
+                            constexpr int k0 = (i - 1) + 4 * P.value;
+                            *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0) = wv[k0];
+                        });
+                        CSDR_STORE_GROUP_END();
+                    } else {
+                        CSDR_SB();
+                    }
+                });
+            } else {
+                // N = 8192: the last stage (8) in four groups, group i finishes rows k0 = i, i + 4 of the G = 4 columns;
+                // N = 4096: the head group was the whole radix-4 transform, group i is row k0 = i of the G = 8 columns.
+                // Either way four float4 per group, stored one group behind, as above.
+                constexpr int NG = 4, RPG = R0 / NG;           // rows per group
+                static_for<0, NG + 1>([&](auto Ii) {
+                    constexpr int i = Ii.value;
+                    if constexpr (i < NG) {
+                        if constexpr (R0 == 8)
+                            static_for<0, G>([&](auto E) { bfly_dit<4 * i, +1>(y[E.value][i], y[E.value][i + 4]); });
+                        static_for<0, RPG>([&](auto P) {
+                            constexpr int k0 = i + NG * P.value;
+                            static_for<0, G>([&](auto E) {
+                                if constexpr (k0 != 0) y[E.value][k0] = cmul(y[E.value][k0], pw[E.value][k0]);
+                            });
+                            static_for<0, G / 2>([&](auto PP) {
+                                wv[k0 * (G / 2) + PP.value] = store_operand(y[2 * PP.value][k0], y[2 * PP.value + 1][k0]);
+                            });
+                        });
+                    }
+                    if constexpr (i > 0) {
+                        CSDR_STORE_GROUP_BEGIN();
+                        static_for<0, RPG>([&](auto P) {
+                            constexpr int k0 = (i - 1) + NG * P.value;
+                            static_for<0, G / 2>([&](auto PP) {
+                                *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0 + PSTEP_LDS * PP.value) = wv[k0 * (G / 2) + PP.value];
+                            });
+                        });
+                        CSDR_STORE_GROUP_END();
+                    } else {
+                        CSDR_SB();
+                    }
+                });
+            }
         }
         CSDR_STAMP(0);                                 // F1 (and the loop-carried moves)
 #ifdef ABL_BAR
@@ -259,8 +330,8 @@ void fastfir_os2_kernel(FastFirArgs a)
 #ifdef ABL_H
                     hv[2 * i] = habl; hv[2 * i + 1] = habl;
 #else
-                    if constexpr (2 * i >= K1_HREG) hv[2 * i] = buf_load16(r_h, t * 16, (2 * i) * (T * 16));
-                    if constexpr (2 * i + 1 >= K1_HREG) hv[2 * i + 1] = buf_load16(r_h, t * 16, (2 * i + 1) * (T * 16));
+                    if constexpr (2 * i >= HREG) hv[2 * i] = buf_load16(r_h, t * 16, (2 * i) * (T * 16));
+                    if constexpr (2 * i + 1 >= HREG) hv[2 * i + 1] = buf_load16(r_h, t * 16, (2 * i + 1) * (T * 16));
 #endif
                     dit_tail<i, 32, +1>(x);
                     static_for<0, 4>([&](auto P) {
@@ -400,48 +471,78 @@ void fastfir_os2_kernel(FastFirArgs a)
         // ================= I3: conj twiddle, radix-16 DIT inverse, store the valid half =================
         CSDR_PRIO(3);
         {
-            v2f y0[R0], y1[R0];
+            v2f y[G][R0];
             static_for<0, R0>([&](auto Rr) {
                 constexpr int r = Rr.value, k0 = bitrev<R0>(r);
-                const v4f v = *reinterpret_cast<const v4f *>(outer + OUTER_ROW * k0);
-                y0[r] = v2f{v.x, v.y};
-                y1[r] = v2f{v.z, v.w};
+                static_for<0, G / 2>([&](auto PP) {
+                    const v4f v = *reinterpret_cast<const v4f *>(outer + OUTER_ROW * k0 + PSTEP_LDS * PP.value);
+                    y[2 * PP.value][r] = v2f{v.x, v.y};
+                    y[2 * PP.value + 1][r] = v2f{v.z, v.w};
+                });
             });
 #pragma unroll
             for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);     // while the reads are in flight
             CSDR_SB();
-            static_for<0, R0 / 4>([&](auto Gg) {
+            static_for<0, (R0 >= 8 ? R0 / 4 : 1)>([&](auto Gg) {
                 constexpr int g = Gg.value;
-                dit_head4_conjtw<g, R0, -1, g == 0>(y0, pw[0][bitrev<R0>(4 * g)], pw[0][bitrev<R0>(4 * g + 1)],
-                                                    pw[0][bitrev<R0>(4 * g + 2)], pw[0][bitrev<R0>(4 * g + 3)]);
-                dit_head4_conjtw<g, R0, -1, g == 0>(y1, pw[1][bitrev<R0>(4 * g)], pw[1][bitrev<R0>(4 * g + 1)],
-                                                    pw[1][bitrev<R0>(4 * g + 2)], pw[1][bitrev<R0>(4 * g + 3)]);
+                static_for<0, G>([&](auto E) {
+                    constexpr int e = E.value;
+                    dit_head4_conjtw<g, R0, -1, g == 0>(y[e], pw[e][bitrev<R0>(4 * g)], pw[e][bitrev<R0>(4 * g + 1)],
+                                                        pw[e][bitrev<R0>(4 * g + 2)], pw[e][bitrev<R0>(4 * g + 3)]);
+                });
                 if constexpr ((g & 1) == 1) CSDR_SB();
             });
-            // sample 1024*n1 + 2t + e, n1 >= 8  ->  output offset 1024*(n1-8) + 2t + e
+            // sample 1024*n1 + column, n1 >= HALF  ->  output offset 1024*(n1-HALF) + column
             CSDR_PRIO(2);
-            v4f sv[8];
-            static_for<0, R0 / 4 + 1>([&](auto I) {
-                constexpr int i = I.value;
-                if constexpr (i < R0 / 4) {
-                    dit_tail_upper<i, R0, -1>(y0);      // only rows 8..15 of the inverse transform are kept
-                    dit_tail_upper<i, R0, -1>(y1);
-                    sv[2 * i] = store_operand(y0[i + 8], y1[i + 8]);
-                    sv[2 * i + 1] = store_operand(y0[i + 12], y1[i + 12]);
-                }
-                if constexpr (i > 0) {
-                    CSDR_STORE_GROUP_BEGIN();
+            v4f sv[8];                                     // (HALF rows) x (G / 2 column pairs)
+            if constexpr (R0 == 16) {
+                static_for<0, R0 / 4 + 1>([&](auto I) {
+                    constexpr int i = I.value;
+                    if constexpr (i < R0 / 4) {
+                        dit_tail_upper<i, R0, -1>(y[0]);      // only rows 8..15 of the inverse transform are kept
+                        dit_tail_upper<i, R0, -1>(y[1]);
+                        sv[2 * i] = store_operand(y[0][i + 8], y[1][i + 8]);
+                        sv[2 * i + 1] = store_operand(y[0][i + 12], y[1][i + 12]);
+                    }
+                    if constexpr (i > 0) {
+                        CSDR_STORE_GROUP_BEGIN();
 #ifdef ABL_GST
-                    keep_alive(sv[2 * (i - 1)]); keep_alive(sv[2 * (i - 1) + 1]);
+                        keep_alive(sv[2 * (i - 1)]); keep_alive(sv[2 * (i - 1) + 1]);
 #else
-                    buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1) * 8192, sv[2 * (i - 1)]);
-                    buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1 + 4) * 8192, sv[2 * (i - 1) + 1]);
+                        buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1) * 8192, sv[2 * (i - 1)]);
+                        buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1 + 4) * 8192, sv[2 * (i - 1) + 1]);
 #endif
-                    CSDR_STORE_GROUP_END();
-                } else {
-                    CSDR_SB();
-                }
-            });
+                        CSDR_STORE_GROUP_END();
+                    } else {
+                        CSDR_SB();
+                    }
+                });
+            } else {
+                // only the upper half of the inverse transform is kept (fastfir.cpp:291-300).  N = 8192: the last stage's
+                // difference outputs, rows 4..7, group i = row 4 + i; N = 4096: rows 2, 3 of the head group's radix-4
+                // transform, group i = row 2 + i
+                constexpr int NG = HALF;
+                static_for<0, NG + 1>([&](auto I) {
+                    constexpr int i = I.value;
+                    if constexpr (i < NG) {
+                        if constexpr (R0 == 8)
+                            static_for<0, G>([&](auto E) { bfly_dit_lower<4 * i, -1>(y[E.value][i], y[E.value][i + 4]); });
+                        static_for<0, G / 2>([&](auto PP) {
+                            sv[i * (G / 2) + PP.value] = store_operand(y[2 * PP.value][HALF + i], y[2 * PP.value + 1][HALF + i]);
+                        });
+                    }
+                    if constexpr (i > 0) {
+                        CSDR_STORE_GROUP_BEGIN();
+                        static_for<0, G / 2>([&](auto PP) {
+                            buf_store16_aux<K1_STAUX>(r_out, voff + PP.value * PSTEP_B, b * (L * 8) + (i - 1) * 8192,
+                                                      sv[(i - 1) * (G / 2) + PP.value]);
+                        });
+                        CSDR_STORE_GROUP_END();
+                    } else {
+                        CSDR_SB();
+                    }
+                });
+            }
         }
         CSDR_STAMP(6);                                 // I3
     };
@@ -477,33 +578,51 @@ void fastfir_os2_kernel(FastFirArgs a)
         v4f sv[8];
 #pragma unroll
         for (int n1 = 0; n1 < HALF; n1++)      // the last new half: in hp after a pair of blocks, in hq after a single one
-            sv[n1] = odd_tail ? store_operand(hq[n1], hq[HALF + n1]) : store_operand(hp[n1], hp[HALF + n1]);
+#pragma unroll
+            for (int pp = 0; pp < G / 2; pp++)
+                sv[n1 * (G / 2) + pp] = odd_tail ? store_operand(hq[(2 * pp) * HALF + n1], hq[(2 * pp + 1) * HALF + n1])
+                                                 : store_operand(hp[(2 * pp) * HALF + n1], hp[(2 * pp + 1) * HALF + n1]);
         CSDR_STORE_GROUP_BEGIN();
 #pragma unroll
-        for (int n1 = 0; n1 < HALF; n1++) buf_store16(r_hn, voff, n1 * 8192, sv[n1]);
+        for (int n1 = 0; n1 < HALF; n1++)
+#pragma unroll
+            for (int pp = 0; pp < G / 2; pp++) buf_store16(r_hn, voff + pp * PSTEP_B, n1 * 8192, sv[n1 * (G / 2) + pp]);
         CSDR_STORE_GROUP_END();
     }
 }
 
-hipError_t fastfir2_launch(const FastFirArgs &a, hipStream_t stream)
+template <int LOG2N>
+static hipError_t launch2_one(const FastFirArgs &a, hipStream_t stream)
 {
-    using Cfg = FastFirCfg<14>;
+    using Cfg = K1Cfg<LOG2N>;
     // per launch: the attribute belongs to the current device, and a process may drive several
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<14>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<LOG2N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fastfir_os2_kernel<14>), dim3(a.channels * a.runs), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((fastfir_os2_kernel<LOG2N>), dim3((a.channels * a.runs + Cfg::VW - 1) / Cfg::VW), dim3(Cfg::T),
+                       Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();
+}
+
+hipError_t fastfir2_launch(int log2n, const FastFirArgs &a, hipStream_t stream)
+{
+    switch (log2n) {
+    case 12: return launch2_one<12>(a, stream);
+    case 13: return launch2_one<13>(a, stream);
+    case 14: return launch2_one<14>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // Host mirror of the kernel's index algebra: thread t of pass F3 owns k0 = t >> 5 (sub-transform) and k1 = t & 31
 // (its row), and consumes H in the order its tail groups finish bins: float4 j = 2 i + h of thread t, half e,
-// multiplies k2 = i + 8 h + 16 e; natural bin k = k0 + 16 (k1 + 32 k2).
-int fastfir2_bin_of(int t, int j, int e)
+// multiplies k2 = i + 8 h + 16 e; natural bin k = k0 + R0 (k1 + 32 k2), R0 = N / 1024 sub-transforms.
+int fastfir2_bin_of(int log2n, int t, int j, int e)
 {
+    const int R0 = (1 << log2n) / 1024;
     const int i = j >> 1, h = j & 1;
     const int k2 = i + 8 * h + 16 * e;
-    return (t >> 5) + 16 * ((t & 31) + 32 * k2);
+    return (t >> 5) + R0 * ((t & 31) + 32 * k2);
 }
 
 }  // namespace csdr
