@@ -821,7 +821,7 @@ def host_form(ca, with_cpu, check=True):
     dt = (time.perf_counter() - t0) / reps
     res = {"config": "drop-in CDemodulator, host doubles in / out: 2 MSPS FM, %d-sample calls (the reference's call pattern), 2^22 samples per measurement" % call,
            "raw_input_MSamples_per_s": round(n / dt / 1e6, 1), "x_real_time": round(n / dt / fs, 1),
-           "staging": "pinned windows used in turn, async H2D + chain on the object's stream, one wait per pass that returns audio",
+           "staging": "pinned windows used in turn, read by the down-converter itself over PCIe (zero copy, round 5), audio written by the post-chain into a pinned buffer; one wait per pass that returns audio",
            "cpu_baseline": None}
     if with_cpu or check:
         from oracle import oracle as orc

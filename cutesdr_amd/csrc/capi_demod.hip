@@ -387,6 +387,11 @@ struct csdr_demod {
     // device and through the chain (asynchronous, on the object's stream), the caller's next samples are converted
     // into window w^1.  The host waits for the GPU only when a pass is due to RETURN samples (a whole hop of audio),
     // as the reference's call pattern demands; passes that only fill the filter return at once.
+    // ZERO COPY (round 5): the pinned windows are mapped into the device's address space and the down-converter reads
+    // them over PCIe in its own loads, the post-chain writes the audio into the pinned output buffer -- no copy engine, no
+    // cross-engine dependency between a copy and the kernel behind it (9 us of copy + 10 us until the kernel started, per
+    // pass, and a 4 us copy kernel on the way back).  CSDR_HOST_ZEROCOPY=0 restores the copies (d_in / d_out).
+    bool zero_copy = true;
     PinnedBuf win[2], pin_out;
     int cur = 0;
     bool win_busy[2] = {false, false};
@@ -648,6 +653,7 @@ csdr_demod *csdr_demod_create(int device, int fastfir_n)
     if (!ok) { fail(CSDR_EHIP, "stream / event creation failed"); delete d; return nullptr; }
     csdr_downconvert_batch_set_cw_offset(d->k.dc, 0, 0.0);      // ctor: SetDemodFreq(0.0)
     csdr_downconvert_batch_set_frequency(d->k.dc, 0, 0.0);
+    d->zero_copy = !(getenv("CSDR_HOST_ZEROCOPY") && atoi(getenv("CSDR_HOST_ZEROCOPY")) == 0);
     return d;
 }
 void csdr_demod_destroy(csdr_demod *d) { delete d; }
@@ -716,40 +722,61 @@ static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out,
         // (a whole window at once: grown step by step, a window filled in 256-sample calls was reallocated -- pinned
         // malloc, copy, free -- some ten times during its first fill, on the per-datagram path)
         const size_t fill = (size_t)d->pos + take;
-        int rc = w.reserve(2 * (fill > (size_t)d->limit ? fill : (size_t)d->limit));
+        const size_t want = 2 * (fill > (size_t)d->limit ? fill : (size_t)d->limit);
+        if (want > w.cap && d->zero_copy) CSDR_HIP(hipStreamSynchronize(d->s));   // nothing may still be reading the old buffer
+        int rc = w.reserve(want);
         if (rc) return rc;
         cvt_to_f32(w.p + 2 * (size_t)d->pos, in_iq + 2 * (size_t)i, 2 * (size_t)take);
         d->pos += take; i += take;
         if (d->pos < d->limit) break;                     // the call's samples are in; the window is not full yet
         const int len = d->pos;
         d->pos = 0;
-        if ((size_t)len > d->cap_in) {
-            CSDR_HIP(hipStreamSynchronize(d->s));
-            if (d->d_in) (void)hipFree(d->d_in);
-            d->d_in = nullptr; d->cap_in = 0;
-            CSDR_HIP(hipMalloc((void **)&d->d_in, (size_t)len * 8));
-            d->cap_in = len;
-        }
         const size_t need_out = (size_t)len + d->k.L;
-        if (need_out > d->cap_out) {
-            CSDR_HIP(hipStreamSynchronize(d->s));
-            if (d->d_out) (void)hipFree(d->d_out);
-            d->d_out = nullptr; d->cap_out = 0;
-            CSDR_HIP(hipMalloc((void **)&d->d_out, need_out * 8));
-            d->cap_out = need_out;
+        const float *chain_in = nullptr;
+        float *chain_out = nullptr;
+        size_t out_stride = 0;
+        if (d->zero_copy) {
+            if (2 * need_out > d->pin_out.cap) {
+                CSDR_HIP(hipStreamSynchronize(d->s));
+                if ((rc = d->pin_out.reserve(2 * need_out))) return rc;
+            }
+            void *pi = nullptr, *po = nullptr;
+            CSDR_HIP(hipHostGetDevicePointer(&pi, w.p, 0));
+            CSDR_HIP(hipHostGetDevicePointer(&po, d->pin_out.p, 0));
+            chain_in = (const float *)pi; chain_out = (float *)po; out_stride = d->pin_out.cap / 2;
+        } else {
+            if ((size_t)len > d->cap_in) {
+                CSDR_HIP(hipStreamSynchronize(d->s));
+                if (d->d_in) (void)hipFree(d->d_in);
+                d->d_in = nullptr; d->cap_in = 0;
+                CSDR_HIP(hipMalloc((void **)&d->d_in, (size_t)len * 8));
+                d->cap_in = len;
+            }
+            if (need_out > d->cap_out) {
+                CSDR_HIP(hipStreamSynchronize(d->s));
+                if (d->d_out) (void)hipFree(d->d_out);
+                d->d_out = nullptr; d->cap_out = 0;
+                CSDR_HIP(hipMalloc((void **)&d->d_out, need_out * 8));
+                d->cap_out = need_out;
+            }
+            // window -> device -> chain, all on the object's stream (d_in is reused in stream order)
+            CSDR_HIP(hipMemcpyAsync(d->d_in, w.p, (size_t)len * 8, hipMemcpyHostToDevice, d->s));
+            chain_in = d->d_in; chain_out = d->d_out; out_stride = d->cap_out;
         }
-        // window -> device -> chain, all on the object's stream (d_in is reused in stream order)
-        CSDR_HIP(hipMemcpyAsync(d->d_in, w.p, (size_t)len * 8, hipMemcpyHostToDevice, d->s));
-        CSDR_HIP(hipEventRecord(d->ev_win[d->cur], d->s));
-        d->win_busy[d->cur] = true;
+        const int wcur = d->cur;
         d->cur ^= 1;
-        const int k = d->k.step(d->d_in, len, nullptr, len, d->d_out, (long)d->cap_out, nullptr, stereo, d->s);
+        const int k = d->k.step(chain_in, len, nullptr, len, chain_out, (long)out_stride, nullptr, stereo, d->s);
+        // the window is free again when the down-converter (zero copy) / the copy has read it: the whole pass, here
+        CSDR_HIP(hipEventRecord(d->ev_win[wcur], d->s));
+        d->win_busy[wcur] = true;
         if (k < 0) return k;
         if (k > 0) {                                      // a pass that returns samples: the one wait of this call
             const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
-            if ((rc = d->pin_out.reserve(nf))) return rc;
-            CSDR_HIP(hipMemcpyAsync(d->pin_out.p, d->d_out, nf * 4, hipMemcpyDeviceToHost, d->s));
-            CSDR_HIP(hipStreamSynchronize(d->s));
+            if (!d->zero_copy) {
+                if ((rc = d->pin_out.reserve(nf))) return rc;
+                CSDR_HIP(hipMemcpyAsync(d->pin_out.p, d->d_out, nf * 4, hipMemcpyDeviceToHost, d->s));
+            }
+            CSDR_HIP(hipStreamSynchronize(d->s));             // (polling hipStreamQuery first: measured +-0)
             cvt_to_f64(append ? out + (stereo ? 2 : 1) * (size_t)ret : out, d->pin_out.p, nf);
         }
         ret += k;

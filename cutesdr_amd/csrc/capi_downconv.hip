@@ -289,6 +289,8 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         // full: C5's down-converter 117 -> 45 us, the host form's 40 -> 13 us per pass, 188 -> 260 MS/s.)
         long min_seg = (long)DC_TILE_SAMPLES * CSDR_DC_MINSEG_TILES;
         if (min_seg < (long)p.W * CSDR_DC_MINSEG_W) min_seg = (long)p.W * CSDR_DC_MINSEG_W;
+        // (a segment must not be shorter than the warm-up: segment s > 0 reads the W samples in front of it from THIS
+        // call's input -- min_seg < W would read in front of the caller's buffer)
         // ONE full round of the chip's 4096 one-wave slots (256 CUs x 16) -- round 4: every segment pays its warm-up
         // (W samples run through the cascade for nothing: 1024 for the FM plan, 2560 for AM), and with two rounds (8192,
         // rounds 1-3) an 86-receiver group's segments were 43 tiles long: 5-12 % of warm-up.  One round: per-plan launches
