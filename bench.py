@@ -958,8 +958,8 @@ class C3Workload:
                 out["spectrum"][str(size)]["parity_checked"] = {"channel": c, "bins_within_60dB_of_peak": int(near.sum()),
                                                                 "max_err_bels": err, "tolerance_bels": 0.001, "ok": bool(err <= 0.001)}
             del fb
-        out["note"] = ("%d channels x 2^%d samples per launch; fastfir 16384 is the headline; kernels: 2048 fastfir16_kernel, 4096 and "
-                       "8192 fastfir_os2_kernel<12> / <13> (round 5: the headline kernel's pipelined build at those sizes); spectrum 2048 / 4096 / 8192 at sixteen points per thread (2048 and "
+        out["note"] = ("%d channels x 2^%d samples per launch; fastfir 16384 is the headline; kernels: fastfir_os2_kernel<11> / <12> / "
+                       "<13> at 2048 / 4096 / 8192 points (round 5: the headline kernel's pipelined build at every size); spectrum 2048 / 4096 / 8192 at sixteen points per thread (2048 and "
                        "8192: round 4), 16384 generic" % (self.C, self.T.bit_length() - 1))
         return out
 

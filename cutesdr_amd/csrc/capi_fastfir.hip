@@ -28,8 +28,7 @@ struct csdr_fastfir_batch {
     float *d_hist;                    // 2 x [channels][n/2] complex fp32 (ping-pong)
     int hist_cur;                     // which half holds the previous call's tail
     int dbg_stage; float *dbg_out;    // diagnostics only (csdr__dbg_fastfir_stage)
-    int variant;                      // 0: generic kernel (every size); 2: pipelined build (N = 4096, 8192, 16384;
-                                      // fastfir2_kernels.hip); 3: 128 threads x 16 points (N = 2048, fastfir16_kernels.hip)
+    int variant;                      // 0: generic kernel (fastfir_kernels.hip); 2: pipelined build (fastfir2_kernels.hip), every size
     float *d_tw1, *d_tw2;
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
@@ -46,15 +45,11 @@ static void build_perm(csdr_fastfir_batch *b)
             for (int e = 0; e < 2; e++)
                 b->perm[(j * T + t) * 2 + e] = fastfir_bin_of(b->log2n, t, 2 * j + e);
     b->perm2.clear();
-    if (b->n >= 4096) {
+    {
         b->perm2.resize(b->n);
         for (int j = 0; j < 16; j++)
             for (int t = 0; t < T; t++)
                 for (int e = 0; e < 2; e++) b->perm2[(j * T + t) * 2 + e] = fastfir2_bin_of(b->log2n, t, j, e);
-    }
-    if (b->n == 2048) {
-        b->perm2.resize(b->n);
-        for (int i = 0; i < b->n; i++) b->perm2[i] = fastfir16_bin_of(i);
     }
 }
 
@@ -98,7 +93,7 @@ csdr_fastfir_batch *csdr_fastfir_batch_create(int device, int channels, int fft_
         // N = 16384 runs the software-pipelined build; CSDR_FASTFIR_VARIANT=0
         // forces the generic kernel (diagnostics; launches it cannot take fall back to the generic one anyway)
         const char *v = getenv("CSDR_FASTFIR_VARIANT");
-        b->variant = (v && atoi(v) == 0) ? 0 : (fft_size >= 4096 ? 2 : 3);
+        b->variant = (v && atoi(v) == 0) ? 0 : 2;
     }
     b->d_h = b->d_h2 = b->d_hist = b->d_tw1 = b->d_tw2 = nullptr;
     b->flo = -1.0; b->fhi = 1.0; b->off = 1.0; b->fs = 1.0;      // fastfir.cpp:126-129
@@ -245,7 +240,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
         // at this size: the LDS block is N*8.5 bytes), fewest runs on a tie -- longer runs re-read
         // less overlap.  C3 (256 channels, N=16384): one run of 64 blocks per channel.
         // (N = 4096, pipelined build: two workgroups per CU of two blocks each)
-        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : (b->variant == 3 ? 6 : 8)));
+        const long per_cu = b->n >= 16384 ? 1 : (b->n >= 8192 ? 2 : (b->n >= 4096 ? 4 : 8));   // (4096 / 2048: 2 workgroups x 2 / 4 blocks)
         const long slots = (long)b->cus * per_cu;
         long best_runs = 1; double best_eff = -1.0;
         const long max_runs = std::min<long>(a.nblocks, std::max<long>(1, 4 * ((slots + b->channels - 1) / b->channels)));
@@ -260,10 +255,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     a.blocks_per_run = blocks_per_wg;
     a.runs = (a.nblocks + blocks_per_wg - 1) / blocks_per_wg;
     a.dbg_stage = b->dbg_stage; a.dbg = (v2f_h *)b->dbg_out;
-    if (b->variant == 3) {
-        a.h = (const v4f_h *)b->d_h2;         // its own H order
-        CSDR_HIP(fastfir16_launch(a, s));
-    } else if (b->variant >= 2) {
+    if (b->variant >= 2) {
         a.h = (const v4f_h *)b->d_h2;         // its own H order
         CSDR_HIP(fastfir2_launch(b->log2n, a, s));     // any block count (pairs, then a single trailing block)
     }
@@ -298,7 +290,7 @@ int csdr__fastfir_batch_copy_row(csdr_fastfir_batch *dst, int dr, csdr_fastfir_b
 /* test-only hook, not part of the public ABI: choose the kernel build of this object (A/B timing in one process) */
 int csdr__fastfir_set_variant(csdr_fastfir_batch *b, int variant)
 {
-    if (!b || (variant != 0 && variant != 2) || (variant && b->n < 4096)) return CSDR_EINVAL;
+    if (!b || (variant != 0 && variant != 2)) return CSDR_EINVAL;
     b->variant = variant;
     return CSDR_OK;
 }

@@ -1,7 +1,7 @@
 // fastfir2_kernels.hip -- batched overlap-save FFT FIR for gfx950, software-pipelined build (K1): N = 16384 (the
-// headline configuration), and since round 5 N = 8192 and 4096 -- the same passes with an outer pass of radix 8 / 4 over
-// four / eight columns per thread (the instruction stream of the 16384-point instantiation is unchanged, checked in the
-// ISA), 4096 points as two blocks side by side per workgroup (K1Cfg below).
+// headline configuration), and since round 5 N = 8192, 4096 and 2048 -- the same passes with an outer pass of radix 8 / 4 /
+// 2 over four / eight / sixteen columns per thread (the instruction stream of the 16384-point instantiation is unchanged,
+// checked in the ISA), 4096 points as two and 2048 points as four blocks side by side per workgroup (K1Cfg below).
 //
 // Same algorithm, LDS image, spectrum order and HBM traffic as fastfir_os_kernel
 // (fastfir_kernels.hip; reference dsp/fastfir.cpp:268-321, dsp/fft.cpp:416-426): passes
@@ -44,6 +44,9 @@ namespace csdr {
 #ifndef K1_HREG4K
 #define K1_HREG4K 4         // ... at N = 4096, whose outer pass (eight columns of four points) keeps more values live
 #endif
+#ifndef K1_HREG2K
+#define K1_HREG2K 8         // ... at N = 2048 (the sixteen base twiddles are fetched where they are used: 0 / 4 / 8 resident measured 0.710 / 0.697 / 0.689 ms)
+#endif
 
 // Diagnostic build only (-DCSDR_K1_STAMPS, tools/k1_stamps.py): cycle shares of the passes of one block,
 // summed per wave in scalar registers and written to a.dbg after the loop.  No stamp executes otherwise.
@@ -75,6 +78,7 @@ namespace csdr {
 __device__ __forceinline__ void keep_alive(v4f v) { asm volatile("" ::"v"(v)); }
 #endif
 
+// (N = 2048 likewise: FOUR blocks of one wave each, and a block's barriers are wave barriers.)
 // N = 4096 runs TWO blocks side by side in one workgroup: a block of 4096 points is 128 threads and 43 KB of LDS, three
 // workgroups -- six waves -- per CU, against the eight (two per SIMD) the schedule below is made for.  Two "virtual
 // workgroups" of 128 threads, each with its own LDS image and its own run of blocks, sharing the twiddle table and the
@@ -82,7 +86,7 @@ __device__ __forceinline__ void keep_alive(v4f v) { asm volatile("" ::"v"(v)); }
 template <int LOG2N>
 struct K1Cfg {
     using Base = FastFirCfg<LOG2N>;
-    static constexpr int VW = LOG2N == 12 ? 2 : 1;                          // virtual workgroups per workgroup
+    static constexpr int VW = LOG2N == 12 ? 2 : (LOG2N == 11 ? 4 : 1);      // virtual workgroups per workgroup
     static constexpr int TV = Base::T;                                      // threads of one block
     static constexpr int T = VW * TV;
     static constexpr int LDS_BYTES = (VW * Base::LDS_DATA + 1024) * 8;
@@ -96,8 +100,17 @@ void fastfir_os2_kernel(FastFirArgs a)
     constexpr int N = Cfg::N, T = Cfg::T, R0 = Cfg::R0, G = Cfg::G, L = N / 2;
     constexpr int HALF = R0 / 2;
     constexpr int VW = K1Cfg<LOG2N>::VW;
-    constexpr int HREG = LOG2N == 12 ? K1_HREG4K : K1_HREG;   // resident float4 of H
-    static_assert(R0 == 16 || R0 == 8 || R0 == 4, "the grouped outer pass is written for N = 16384, 8192 and 4096");
+    constexpr int HREG = LOG2N == 12 ? K1_HREG4K : (LOG2N == 11 ? K1_HREG2K : K1_HREG);   // resident float4 of H
+    static_assert(R0 == 16 || R0 == 8 || R0 == 4 || R0 == 2, "the grouped outer pass is written for N = 2048 ... 16384");
+    // a block of 2048 points is ONE wave: its two "workgroup" barriers are wave barriers (the four blocks of a workgroup
+    // then run free of each other)
+    auto block_barrier = [] {
+        if constexpr (LOG2N == 11) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = VW == 1 ? (int)threadIdx.x : (int)threadIdx.x % T, vw = VW == 1 ? 0 : (int)threadIdx.x / T;
     v2f *lds = reinterpret_cast<v2f *>(smem_raw) + vw * Cfg::LDS_DATA;
@@ -147,12 +160,19 @@ void fastfir_os2_kernel(FastFirArgs a)
 
     // outer-pass twiddles W_N^{n2 k0}, n2 = 2t+e, k0 = 1..15: pw[e][k0].  Rebuilt at the top of every
     // I3 and kept for F1 of the next block only: live across the whole loop they would not fit beside H
-    v2f w1[G];
+    // (N = 2048: sixteen base twiddles and no powers -- they are fetched where the outer passes use them, 8 KB of table
+    // that stays in the vector cache, instead of thirty-two registers held for the whole run)
+    v2f w1[R0 > 2 ? G : 1];
+    if constexpr (R0 > 2) {
 #pragma unroll
-    for (int e = 0; e < G; e++) w1[e] = a.tw1[PSTEP * (e / 2) + 2 * t + (e & 1)];
+        for (int e = 0; e < G; e++) w1[e] = a.tw1[PSTEP * (e / 2) + 2 * t + (e & 1)];
+    }
+    auto w_pair = [&](int pp) { return *reinterpret_cast<const v4f *>(a.tw1 + PSTEP * pp + 2 * t); };   // R0 == 2
     v2f pw[G][R0];
+    if constexpr (R0 > 2) {
 #pragma unroll
-    for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);
+        for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);
+    }
 
     // H: float4 j of this thread (fastfir2_bin_of) multiplies in F3's tail group j / 2.  The first K1_HREG of the
     // sixteen stay in registers for the whole run -- all the registers the kernel has to spare: a 1 KB fetch from
@@ -206,9 +226,13 @@ void fastfir_os2_kernel(FastFirArgs a)
                     y[e][po] = oldh[e * HALF + n1]; y[e][pn] = newh[e * HALF + n1];
                 });
             });
-            static_for<0, (R0 >= 8 ? R0 / 4 : 1)>([&](auto Gg) {
-                static_for<0, G>([&](auto E) { dit_head4<Gg.value, R0, +1>(y[E.value]); });
-            });
+            if constexpr (R0 == 2) {
+                static_for<0, G>([&](auto E) { bfly_dit<0, +1>(y[E.value][0], y[E.value][1]); });
+            } else {
+                static_for<0, (R0 >= 8 ? R0 / 4 : 1)>([&](auto Gg) {
+                    static_for<0, G>([&](auto E) { dit_head4<Gg.value, R0, +1>(y[E.value]); });
+                });
+            }
             CSDR_SB();
             // block b+1's new half: into the registers of the old half, which the butterflies above have read
             // (unconditional, so that the block stays one straight line of code: after the last block of the
@@ -237,6 +261,33 @@ void fastfir_os2_kernel(FastFirArgs a)
                         static_for<0, 4>([&](auto P) {
                             constexpr int k0 = (i - 1) + 4 * P.value;
                             *reinterpret_cast<v4f *>(outer + OUTER_ROW * k0) = wv[k0];
+                        });
+                        CSDR_STORE_GROUP_END();
+                    } else {
+                        CSDR_SB();
+                    }
+                });
+            } else if constexpr (R0 == 2) {
+                // N = 2048: the one butterfly above was the whole outer transform; group i = rows 0, 1 of the pairs 2i, 2i + 1
+                v4f wq[8];
+                static_for<0, 8>([&](auto PP) { wq[PP.value] = w_pair(PP.value); });
+                static_for<0, 5>([&](auto Ii) {
+                    constexpr int i = Ii.value;
+                    if constexpr (i < 4) {
+                        static_for<0, 2>([&](auto Q) {
+                            constexpr int pp = 2 * i + Q.value;
+                            y[2 * pp][1] = cmul(y[2 * pp][1], v2f{wq[pp].x, wq[pp].y});
+                            y[2 * pp + 1][1] = cmul(y[2 * pp + 1][1], v2f{wq[pp].z, wq[pp].w});
+                            wv[pp] = store_operand(y[2 * pp][0], y[2 * pp + 1][0]);
+                            wv[8 + pp] = store_operand(y[2 * pp][1], y[2 * pp + 1][1]);
+                        });
+                    }
+                    if constexpr (i > 0) {
+                        CSDR_STORE_GROUP_BEGIN();
+                        static_for<0, 2>([&](auto Q) {
+                            constexpr int pp = 2 * (i - 1) + Q.value;
+                            *reinterpret_cast<v4f *>(outer + PSTEP_LDS * pp) = wv[pp];
+                            *reinterpret_cast<v4f *>(outer + OUTER_ROW + PSTEP_LDS * pp) = wv[8 + pp];
                         });
                         CSDR_STORE_GROUP_END();
                     } else {
@@ -282,7 +333,7 @@ void fastfir_os2_kernel(FastFirArgs a)
 #ifdef ABL_BAR
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #else
-        __syncthreads();
+        block_barrier();
 #endif
         CSDR_STAMP(1);                                 // barrier after F1
 
@@ -464,7 +515,7 @@ void fastfir_os2_kernel(FastFirArgs a)
 #ifdef ABL_BAR
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #else
-        __syncthreads();
+        block_barrier();
 #endif
         CSDR_STAMP(5);                                 // barrier after I2
 
@@ -480,18 +531,20 @@ void fastfir_os2_kernel(FastFirArgs a)
                     y[2 * PP.value + 1][r] = v2f{v.z, v.w};
                 });
             });
+            if constexpr (R0 > 2) {
 #pragma unroll
-            for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);     // while the reads are in flight
-            CSDR_SB();
-            static_for<0, (R0 >= 8 ? R0 / 4 : 1)>([&](auto Gg) {
-                constexpr int g = Gg.value;
-                static_for<0, G>([&](auto E) {
-                    constexpr int e = E.value;
-                    dit_head4_conjtw<g, R0, -1, g == 0>(y[e], pw[e][bitrev<R0>(4 * g)], pw[e][bitrev<R0>(4 * g + 1)],
-                                                        pw[e][bitrev<R0>(4 * g + 2)], pw[e][bitrev<R0>(4 * g + 3)]);
+                for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);     // while the reads are in flight
+                CSDR_SB();
+                static_for<0, (R0 >= 8 ? R0 / 4 : 1)>([&](auto Gg) {
+                    constexpr int g = Gg.value;
+                    static_for<0, G>([&](auto E) {
+                        constexpr int e = E.value;
+                        dit_head4_conjtw<g, R0, -1, g == 0>(y[e], pw[e][bitrev<R0>(4 * g)], pw[e][bitrev<R0>(4 * g + 1)],
+                                                            pw[e][bitrev<R0>(4 * g + 2)], pw[e][bitrev<R0>(4 * g + 3)]);
+                    });
+                    if constexpr ((g & 1) == 1) CSDR_SB();
                 });
-                if constexpr ((g & 1) == 1) CSDR_SB();
-            });
+            }
             // sample 1024*n1 + column, n1 >= HALF  ->  output offset 1024*(n1-HALF) + column
             CSDR_PRIO(2);
             v4f sv[8];                                     // (HALF rows) x (G / 2 column pairs)
@@ -512,6 +565,31 @@ void fastfir_os2_kernel(FastFirArgs a)
                         buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1) * 8192, sv[2 * (i - 1)]);
                         buf_store16_aux<K1_STAUX>(r_out, voff, b * (L * 8) + (i - 1 + 4) * 8192, sv[2 * (i - 1) + 1]);
 #endif
+                        CSDR_STORE_GROUP_END();
+                    } else {
+                        CSDR_SB();
+                    }
+                });
+            } else if constexpr (R0 == 2) {
+                // N = 2048: the kept half is the butterfly's difference output, row 1 = y0 - conj(w) y1; group i = pairs 2i, 2i + 1
+                v4f wq[8];
+                static_for<0, 8>([&](auto PP) { wq[PP.value] = w_pair(PP.value); });
+                static_for<0, 5>([&](auto I) {
+                    constexpr int i = I.value;
+                    if constexpr (i < 4) {
+                        static_for<0, 2>([&](auto Q) {
+                            constexpr int pp = 2 * i + Q.value;
+                            const v2f d0 = y[2 * pp][0] - cmul_conj(y[2 * pp][1], v2f{wq[pp].x, wq[pp].y});
+                            const v2f d1 = y[2 * pp + 1][0] - cmul_conj(y[2 * pp + 1][1], v2f{wq[pp].z, wq[pp].w});
+                            sv[pp] = store_operand(d0, d1);
+                        });
+                    }
+                    if constexpr (i > 0) {
+                        CSDR_STORE_GROUP_BEGIN();
+                        static_for<0, 2>([&](auto Q) {
+                            constexpr int pp = 2 * (i - 1) + Q.value;
+                            buf_store16_aux<K1_STAUX>(r_out, voff + pp * PSTEP_B, b * (L * 8), sv[pp]);
+                        });
                         CSDR_STORE_GROUP_END();
                     } else {
                         CSDR_SB();
@@ -607,6 +685,7 @@ static hipError_t launch2_one(const FastFirArgs &a, hipStream_t stream)
 hipError_t fastfir2_launch(int log2n, const FastFirArgs &a, hipStream_t stream)
 {
     switch (log2n) {
+    case 11: return launch2_one<11>(a, stream);
     case 12: return launch2_one<12>(a, stream);
     case 13: return launch2_one<13>(a, stream);
     case 14: return launch2_one<14>(a, stream);

@@ -29,14 +29,10 @@ struct FastFirArgs {
 hipError_t fastfir_launch(int log2n, const FastFirArgs &a, hipStream_t stream);
 int fastfir_bin_of(int log2n, int t, int r);
 
-// software-pipelined build for N = 16384, 8192 and 4096 (fastfir2_kernels.hip): same LDS image as fastfir_launch, its
+// software-pipelined build, N = 2048 ... 16384 (fastfir2_kernels.hip): same LDS image as fastfir_launch, its
 // own H order
 hipError_t fastfir2_launch(int log2n, const FastFirArgs &a, hipStream_t stream);
 // natural-order spectrum bin of H slot (float4 index j*(N/32) + t, half e) of that kernel
 int fastfir2_bin_of(int log2n, int t, int j, int e);
-
-// N = 2048 as 128 threads x 16 points (fastfir16_kernels.hip): H in its own order, slot i <-> bin fastfir16_bin_of(i)
-hipError_t fastfir16_launch(const FastFirArgs &a, hipStream_t stream);
-int fastfir16_bin_of(int slot);
 
 }  // namespace csdr

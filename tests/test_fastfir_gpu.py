@@ -179,16 +179,19 @@ def test_generic_kernel_at_16384_in_child_process():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_pipelined_and_generic_kernels_agree(oracle):
-    """The pipelined build (FMA-form butterflies) and the generic kernel against the oracle and against each
-    other, for even and odd block counts (the pipelined kernel walks pairs of blocks, then a single trailing one)
-    and across two calls (overlap carried)."""
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
+def test_pipelined_and_generic_kernels_agree(oracle, n):
+    """The pipelined build (FMA-form butterflies; round 5: also at 8192 and 4096 points, outer pass of radix 8 / 4 over
+    four / eight columns per thread, 4096 points as two blocks per workgroup) and the generic kernel against the oracle
+    and against each other, for even and odd block counts (the pipelined kernel walks pairs of blocks, then a single
+    trailing one; at 4096 points an odd number of RUNS leaves a workgroup's second half idle) and across two calls
+    (overlap carried)."""
     import ctypes as C
     import cutesdr_amd as ca
     L = ca.lib()
     L.csdr__fastfir_set_variant.restype = C.c_int
     L.csdr__fastfir_set_variant.argtypes = [C.c_void_p, C.c_int]
-    n, Cn = 16384, 3
+    Cn = 3
     rng = np.random.default_rng(5)
     for nb in (1, 2, 5, 8):
         x = (3000.0 * (rng.standard_normal((Cn, nb * n // 2)) + 1j * rng.standard_normal((Cn, nb * n // 2)))).astype(np.complex64)

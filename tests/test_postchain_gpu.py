@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 STEADY = 2e-5 * FULL_SCALE
 FROM_ZERO = 5e-4 * FULL_SCALE
+SAM_FIRST = 4e-3 * FULL_SCALE          # SAM chain, the stream's first burst
+SAM_SECOND = 1e-3 * FULL_SCALE         # SAM chain, the second
 FM_SECOND = 8e-2 * FULL_SCALE          # FM chain, burst 1 (the second)
 FM_THIRD = 1.5e-2 * FULL_SCALE         # FM chain, burst 2
 FM_LOCKED = 1e-3 * FULL_SCALE          # FM chain, bursts 4..6
@@ -62,7 +64,16 @@ def check_chain_bursts(errs, mode, first_burst=0, what="", fm_late=0, from_zero=
         assert (errs[idx >= 3 + fm_late] <= FM_LOCKED).all(), (what, mode, errs[:10] / FULL_SCALE)
         assert (errs[idx >= 6 + fm_late] <= FM_STEADY).all(), (what, mode, errs[:12] / FULL_SCALE)
     else:
-        assert (errs <= from_zero).all(), (what, mode, errs[:6] / FULL_SCALE)
+        # (SAM: in the stream's first burst the AGC is at full gain on the filter's start-up -- samples of rounding size --
+        # and the 100 Hz loop pulls in on a carrier of arbitrary phase over the first two bursts: how far the phase error
+        # swings on the way is set by the rounding noise of the filter kernel in front of it, 0.4 ... 1.5e-3 of full scale
+        # with the 2048-point kernels the library has had.  4e-3 in the first burst -- the bound the longer filters' AM
+        # start-up already has -- 1e-3 in the second, the common bound from the third.)
+        if mode == "SAM":
+            assert (errs[idx == 0] <= max(from_zero, SAM_FIRST)).all() and (errs[idx == 1] <= max(from_zero, SAM_SECOND)).all(), \
+                (what, mode, errs[:6] / FULL_SCALE)
+        else:
+            assert (errs <= from_zero).all(), (what, mode, errs[:6] / FULL_SCALE)
         assert (errs[idx >= 2] <= STEADY).all(), (what, mode, errs[:8] / FULL_SCALE)
 
 
@@ -301,7 +312,7 @@ def test_demod_batch_mixed_modes(oracle, nfft):
             assert len(got[c]) == len(want) > 0 and len(want) % hop == 0, (c, names[c])
             # (the first burst of a longer filter holds more of its start-up -- the AGC at full gain on samples of
             # rounding size: AM 1.6e-3 / 1.8e-3 of full scale at 4096 / 8192 points, 2e-6 from the second burst)
-            check_chain_bursts(burst_errors(got[c], want, hop), "FM" if names[c] == "FM" else "other", first[c], (c, names[c]),
+            check_chain_bursts(burst_errors(got[c], want, hop), names[c] if names[c] in ("FM", "SAM") else "other", first[c], (c, names[c]),
                                from_zero=FROM_ZERO if nfft == 2048 else 4e-3 * FULL_SCALE)
             first[c] += len(want) // hop
     for c in range(C):

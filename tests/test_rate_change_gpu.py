@@ -53,6 +53,8 @@ def _check_segment(errs, mode, settled, what):
         assert (errs[:3] <= (FM_LOCKED if settled else 2.5 * FULL_SCALE)).all(), (what, errs[:6] / FULL_SCALE)
         assert (errs[3:6] <= FM_LOCKED).all(), (what, errs[:8] / FULL_SCALE)
         assert (errs[6:] <= FM_STEADY).all(), (what, errs[:10] / FULL_SCALE)
+    elif mode == "SAM" and not settled:                     # the stream's start: the chain rule's SAM bounds
+        check_chain_bursts(errs, "SAM", 0, what)
     else:
         assert (errs[:2] <= FROM_ZERO).all(), (what, errs[:6] / FULL_SCALE)
         assert (errs[2:] <= STEADY).all(), (what, errs[:8] / FULL_SCALE)
