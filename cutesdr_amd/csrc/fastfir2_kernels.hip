@@ -44,6 +44,10 @@ namespace csdr {
 #ifndef K1_HREG4K
 #define K1_HREG4K 4         // ... at N = 4096, whose outer pass (eight columns of four points) keeps more values live
 #endif
+#ifndef K1_W1_FETCH_MAX_R0
+#define K1_W1_FETCH_MAX_R0 2 // outer radix up to which the base twiddles are fetched per block instead of held (2: N = 2048 only;
+                             // at N = 4096 the fetch removes the kernel's 40 bytes of scratch and measures 1.5 % SLOWER)
+#endif
 #ifndef K1_HREG2K
 #define K1_HREG2K 8         // ... at N = 2048 (the sixteen base twiddles are fetched where they are used: 0 / 4 / 8 resident measured 0.710 / 0.697 / 0.689 ms)
 #endif
@@ -162,12 +166,16 @@ void fastfir_os2_kernel(FastFirArgs a)
     // I3 and kept for F1 of the next block only: live across the whole loop they would not fit beside H
     // (N = 2048: sixteen base twiddles and no powers -- they are fetched where the outer passes use them, 8 KB of table
     // that stays in the vector cache, instead of thirty-two registers held for the whole run)
+    constexpr bool W1_RESIDENT = R0 > K1_W1_FETCH_MAX_R0;    // the base twiddles stay in registers for the whole run
+    auto w_pair = [&](int pp) { return *reinterpret_cast<const v4f *>(a.tw1 + PSTEP * pp + 2 * t); };
     v2f w1[R0 > 2 ? G : 1];
-    if constexpr (R0 > 2) {
+    auto load_w1 = [&] {
+        if constexpr (R0 > 2) {
 #pragma unroll
-        for (int e = 0; e < G; e++) w1[e] = a.tw1[PSTEP * (e / 2) + 2 * t + (e & 1)];
-    }
-    auto w_pair = [&](int pp) { return *reinterpret_cast<const v4f *>(a.tw1 + PSTEP * pp + 2 * t); };   // R0 == 2
+            for (int pp = 0; pp < G / 2; pp++) { const v4f v = w_pair(pp); w1[2 * pp] = v2f{v.x, v.y}; w1[2 * pp + 1] = v2f{v.z, v.w}; }
+        }
+    };
+    load_w1();
     v2f pw[G][R0];
     if constexpr (R0 > 2) {
 #pragma unroll
@@ -532,6 +540,7 @@ void fastfir_os2_kernel(FastFirArgs a)
                 });
             });
             if constexpr (R0 > 2) {
+                if constexpr (!W1_RESIDENT) load_w1();
 #pragma unroll
                 for (int e = 0; e < G; e++) twiddle_powers<R0>(opaque(w1[e]), pw[e]);     // while the reads are in flight
                 CSDR_SB();
