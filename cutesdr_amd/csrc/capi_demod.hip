@@ -844,11 +844,17 @@ int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate)
         if (p.nstages < 0 || p.nstages > DC_MAX_STAGES) return fail(CSDR_EINVAL, "no decimator chain for rate %g", rate);
         stages[c] = p.nstages;
     }
+    // (a group keeps the decimation MOST of its live rows get -- the first of them on a tie -- so that as few receivers as
+    // possible have to move; rows grouped at the commit share one bandwidth limit and all agree)
     std::vector<int> group_stages(b->cores.size(), -1);
     std::vector<double> group_bw(b->cores.size(), 0.0);
-    for (size_t ki = 0; ki < b->cores.size(); ki++)
-        for (int c : b->members[ki])
-            if (c >= 0) { group_stages[ki] = stages[c]; group_bw[ki] = b->cfg[c].want_bw; break; }
+    for (size_t ki = 0; ki < b->cores.size(); ki++) {
+        int votes[DC_MAX_STAGES + 1] = {0}, best = -1;
+        for (int c : b->members[ki]) if (c >= 0) votes[stages[c]]++;
+        for (int c : b->members[ki]) if (c >= 0 && (best < 0 || votes[stages[c]] > votes[best])) best = stages[c];
+        group_stages[ki] = best;
+        for (int c : b->members[ki]) if (c >= 0 && stages[c] == best) { group_bw[ki] = b->cfg[c].want_bw; break; }
+    }
     // ---- the rows that keep their group: in place (a muted row follows its group, it only has to decimate alike)
     std::vector<int> movers;
     for (size_t ki = 0; ki < b->cores.size(); ki++) {
