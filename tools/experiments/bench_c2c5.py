@@ -2,7 +2,7 @@
 """BASELINE configs C2 and C5 alone (bench.py's chain_one_receiver, no CPU legs): for A/B runs of post-chain changes."""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import cutesdr_amd as ca
 import bench
