@@ -2,7 +2,10 @@
 // CFft::PutInDisplayFFT + CDemodulator::ProcessData on 256-sample packets; interface/soundout.cpp:204:
 // CFractResampler; the blanker CNoiseProc runs in place in front of both, sdrinterface.cpp:884),
 // compiled against the drop-in headers with plain g++.
-//   dropin_host <in.bin> <out_prefix> <mode> <fs> <freq>
+//   dropin_host <in.bin> <out_prefix> <mode> <fs> <freq> [<switch_at> <new_fs>]
+// With the last two: at sample <switch_at> the radio's bandwidth is switched the way CSdrInterface does it
+// (interface/sdrinterface.cpp:751-755): SetFftSize (-> CFft::SetFFTParams with the new rate), then
+// CDemodulator::SetInputSampleRate, and NO SetDemod.
 // in.bin: interleaved doubles.  Writes <prefix>.audio (doubles), <prefix>.spec (int32 x 700),
 // <prefix>.meta (text).
 #include <cstdio>
@@ -57,8 +60,16 @@ int main(int argc, char **argv)
     std::vector<TYPEREAL> out(8192);         // the host's stack buffer, sdrinterface.cpp:910
     size_t fftpos = 0;
     int total = 0, rtotal = 0;
-    const double rate = demod.GetOutputRate() / 48000.0;
+    double rate = demod.GetOutputRate() / 48000.0;
+    const size_t switch_at = argc >= 8 ? (size_t)std::atoll(argv[6]) : (size_t)-1;
     for (size_t i = 0; i + 256 <= x.size(); i += 256) {
+        if (i == switch_at) {
+            const double nfs = std::atof(argv[7]);
+            fft.SetFFTParams(4096, false, 0.0, nfs);
+            demod.SetInputSampleRate(nfs);
+            rate = demod.GetOutputRate() / 48000.0;     // m_pSoundCardOut->ChangeUserDataRate(GetOutputRate())
+            fftpos = i;
+        }
         nb.ProcessBlanker(256, &x[i], &x[i]);       // in place, as the host does
         if (i + 256 - fftpos >= 4096) { fft.PutInDisplayFFT(4096, &x[fftpos]); fftpos += 4096; }
         const int n = demod.ProcessData(256, &x[i], out.data());

@@ -129,3 +129,55 @@ def test_dropin_host_matches_oracle(oracle, tmp_path):
     assert float(smeter) == pytest.approx(d.GetSMeterAve(), abs=0.02)
     _, wpix = f.GetScreenIntegerFFTData(255, 700, 0.0, -160.0, -900000, 900000)
     assert np.abs(pix - wpix).max() <= 1
+
+
+@pytest.mark.gpu
+def test_dropin_host_bandwidth_switch_matches_oracle(oracle, tmp_path):
+    """The C++ host through a bandwidth switch of the radio, the way CSdrInterface does it (interface/sdrinterface.cpp:
+    751-755: SetFftSize, then CDemodulator::SetInputSampleRate, no SetDemod): 2 MSPS -> 615 384.6 SPS in mid-stream, at a
+    datagram boundary that is NOT a window boundary (a partly filled m_pDemodInBuf crosses the change).  Counts exact,
+    audio under the FM chain rule before the switch and under the settled rule of tests/test_rate_change_gpu.py after
+    it, S-meter, screen pixels of the spectrum at the new rate."""
+    from util_signals import fm_carrier, FULL_SCALE
+    exe = build_exe()
+    fs, nfs = 2e6, 80e6 / 130.0
+    n1, n2 = 256 * 1600, 256 * 1700                              # 20.5 windows, then 21.8
+    x = np.concatenate([fm_carrier(n1, fs, 100e3, dbfs=-20.0), fm_carrier(n2, nfs, 100e3, dbfs=-20.0, channel=1)])
+    x = x.astype(np.complex64).astype(np.complex128)
+    x.tofile(tmp_path / "in.bin")
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "o"), "2", str(fs), "-100000", str(n1), repr(nfs)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    total, rtotal, rate, smeter, ov = (tmp_path / "o.meta").read_text().split()
+    audio = np.fromfile(tmp_path / "o.audio")
+    pix = np.fromfile(tmp_path / "o.spec", dtype=np.int32)
+    d, f, rs = oracle.CDemodulator(2048), oracle.CFft(), oracle.CFractResampler()
+    d.SetInputSampleRate(fs); d.SetDemod(oracle.DEMOD_FM, oracle.fm_defaults()); d.SetDemodFreq(-100e3)
+    f.SetFFTParams(4096, False, 0.0, fs); f.SetFFTAve(1); rs.Init(8192)
+    nb = oracle.CNoiseProc(); nb.SetupBlanker(True, 40.0, 10.0, fs)
+    x = x.copy()
+    want, wtotal, wr, fftpos, before = [], 0, 0, 0, 0
+    for i in range(0, len(x) - 255, 256):
+        if i == n1:
+            f.SetFFTParams(4096, False, 0.0, nfs); d.SetInputSampleRate(nfs); fftpos = i
+            before = wtotal
+        x[i:i + 256] = nb.ProcessBlanker(x[i:i + 256])
+        if i + 256 - fftpos >= 4096:
+            f.PutInDisplayFFT(x[fftpos:fftpos + 4096]); fftpos += 4096
+        k, o = d.ProcessData(x[i:i + 256])
+        if k:
+            wtotal += k
+            want.append(o[:k].copy())
+            wr += len(rs.Resample(o[:k], d.GetOutputRate() / 48000.0))
+    want = np.concatenate(want)
+    assert int(total) == wtotal == len(audio) and int(rtotal) == wr
+    assert d.GetOutputRate() == nfs / 8 and float(rate) == pytest.approx(nfs / 8, abs=1e-5)    # (the .meta file prints six decimals)
+    err = np.abs(audio - want).reshape(-1, 1024).max(axis=1)
+    nb0 = before // 1024
+    assert nb0 >= 8 and len(err) - nb0 >= 8
+    late = 1 if err[0] > 0.2 * FULL_SCALE else 0
+    assert err[3 + late:6 + late].max() <= 1e-3 * FULL_SCALE and err[6 + late:nb0].max() <= 3e-5 * FULL_SCALE
+    assert err[nb0:nb0 + 6].max() <= 1e-3 * FULL_SCALE and err[nb0 + 6:].max() <= 3e-5 * FULL_SCALE, err[nb0:nb0 + 10] / FULL_SCALE
+    assert float(smeter) == pytest.approx(d.GetSMeterAve(), abs=0.02)
+    _, wpix = f.GetScreenIntegerFFTData(255, 700, 0.0, -160.0, -900000, 900000)
+    assert np.abs(pix - wpix).max() <= 1
