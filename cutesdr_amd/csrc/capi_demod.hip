@@ -1070,8 +1070,8 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
 }
 /* d_in: [channels][in_stride] complex fp32; d_out: [channels][out_stride] fp32 mono audio.
  * Chunking: one call = one pass of the chain over n_per_channel samples (the host form uses
- * m_InBufLimit-sized passes; decimator and filter do not depend on the chunking -- the filter word for word, the
- * decimator up to the rounding of its oscillator's phasor between re-anchor points, 2e-8 of full scale --, the squelch
+ * m_InBufLimit-sized passes; decimator, filter and post-chain do not depend on the chunking, word for word, for calls
+ * of whole 512-sample tiles -- the decimator re-anchors its oscillator on an absolute grid --, the squelch
  * decision is taken once per FastFIR hop either way).  Asynchronous. */
 static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_stride, int n_per_channel,
                            float *d_out, long long out_stride, void *stream, bool stereo,

@@ -384,6 +384,23 @@ void downconv_kernel(DcArgs a)
     if (seg_end > a.n_in) seg_end = a.n_in;
     const v2f rowstep = phasor_of(cs.inc * (unsigned long long)DC_ROW);
     const float a_inf = a.amp[DC_AMP_N - 1], inv_a_inf = 1.0f / a_inf;
+    // Re-anchoring the phasors (exact phase from the 64-bit accumulator, then one complex multiply per row) on an
+    // ABSOLUTE grid -- every DC_ANCHOR_ROWS rows counted from the channel's first sample, not from wherever this
+    // workgroup's segment or this call happens to start: a tile that starts between two grid points anchors at the
+    // grid point behind it and walks the rows in between with the same multiplies a continuous run would have made.
+    // The mixed samples, hence the output WORDS, then do not depend on how the stream is cut into calls and segments
+    // (for calls that are whole tiles: a short tile breaks the row cadence and anchors where it stands, as before).
+    auto anchor = [&](long at, bool full_tile) {
+        int back = 0;                                    // whole tiles between the grid point and `at`
+        if (full_tile) {
+            const unsigned long long ab = cs.age + (unsigned long long)at;
+            if ((ab & (unsigned long long)(DC_TILE - 1)) == 0) back = (int)((ab / DC_TILE) & (unsigned long long)(DC_ANCHOR_ROWS / (DC_TILE / DC_ROW) - 1));
+        }
+        p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(at - (long)back * DC_TILE + 2 * t + 1)) * a_inf;
+        p1 = cmul(p0, step1);
+        for (int r = 0; r < back * (DC_TILE / DC_ROW); r++) { p0 = cmul(p0, rowstep); p1 = cmul(p1, rowstep); }
+        anchor_rows = full_tile ? DC_ANCHOR_ROWS - back * (DC_TILE / DC_ROW) : 0;
+    };
 
     // The raw input of a tile is fetched into registers one tile ahead, while the previous tile goes
     // through the cascade: nothing waits on HBM latency except the very first tile.
@@ -483,11 +500,7 @@ void downconv_kernel(DcArgs a)
                 const long lim = w ? seg_start : hi;
                 if (!(pos + DC_TILE <= lim && (seg > 0 || pos >= 0) && cs.age + (unsigned long long)pos >= DC_AMP_N)) break;
                 if constexpr (BLK) { if (pos - D1 - 1 < 0) break; }     // the delayed samples reach into the history: general tile
-                if (anchor_rows <= 0) {
-                    p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(pos + 2 * t + 1)) * a_inf;
-                    p1 = cmul(p0, step1);
-                    anchor_rows = DC_ANCHOR_ROWS;
-                }
+                if (anchor_rows <= 0) anchor(pos, true);
                 anchor_rows -= NR;
                 {
                     v2f *e = lds + LY.roff[0] + dc_hist_of(P::KIND[0]) / 2 + t, *o = e + LY.ooff[0];
@@ -615,11 +628,7 @@ void downconv_kernel(DcArgs a)
             // the phasors run on from tile to tile and are re-anchored every DC_ANCHOR_ROWS rows
             // (and after a short tile, which breaks the row cadence)
             // p0/p1 carry the steady-state amplitude a_inf
-            if (anchor_rows <= 0 || n != DC_TILE) {
-                p0 = phasor_of(cs.phase + cs.inc * (unsigned long long)(pos + 2 * t + 1)) * a_inf;
-                p1 = cmul(p0, step1);
-                anchor_rows = (n == DC_TILE) ? DC_ANCHOR_ROWS : 0;
-            }
+            if (anchor_rows <= 0 || n != DC_TILE) anchor(pos, n == DC_TILE);
             anchor_rows -= NR;
             // full tile, amplitude settled, no history to save: the lean path
             const bool lean = ns > 0 && n == DC_TILE && cs.age + (unsigned long long)pos >= DC_AMP_N &&

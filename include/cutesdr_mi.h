@@ -283,8 +283,9 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
  * 1e-9 turns -- a bound, not bit equality: the audio of such tiles (noise, acquisition) can differ from a one-thread
  * walk, and between builds with another tiling, by up to ~1e-6 of full scale (tests: 1e-6; CSDR_PLL_OVERLAP=0 selects
  * the one-thread walk).  Strict and pipelined mode run the same kernels with the same tiling: identical words.
- * How a stream is cut into calls moves the down-converter's segment boundaries, where its oscillator's phasor is
- * re-anchored: the same stream in other call lengths gives the same audio to ~1e-7 of full scale, not the same words. */
+ * The audio WORDS do not depend on how a stream is cut into calls either, as long as every call is a whole number of
+ * 512-sample tiles (the down-converter re-anchors its oscillator on a grid counted from the receiver's first sample,
+ * the filter walks whole hops, the post-chain whole bursts): one call of 24 windows = 24 calls of one, bit for bit. */
 int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
                              int n_per_channel, float *d_out, long long out_stride, void *stream);
 /* Pipelined mode for streaming hosts (off by default).  on != 0: the three stages of a call (down-converter |

@@ -294,6 +294,52 @@ def test_c4_full_width_2048_receivers_in_8_shards(oracle):
         del b
 
 
+def test_chain_words_do_not_depend_on_how_the_stream_is_cut():
+    """One call of 24 windows, 24 calls of one window, calls of 5 + 7 + 12 windows and twelve drop-in objects fed the
+    reference's way (m_InBufLimit passes): the same audio WORDS for every receiver of a mixed batch, the FM start-up --
+    which an ulp anywhere upstream would reshuffle -- included.  What makes it so: the down-converter re-anchors its
+    oscillator on a grid counted from the receiver's first sample (segments and calls may start anywhere on whole
+    tiles), the filter kernel walks whole hops whatever the run length, the post-chain whole bursts; the S-meter's
+    whole-call scan chunks its fp64 maps differently and agrees to rounding only (0.001 dB here)."""
+    import cutesdr_amd as ca
+    fs, lim = 2e6, 19968
+    names = ["FM", "AM", "USB", "SAM", "CWU", "LSB", "FM", "USB", "AM", "CWL", "FM", "AM"]
+    C, n = len(names), 24 * lim
+    x = np.stack([chain_input(m, n, fs) * np.exp(2j * np.pi * 700.0 * c * np.arange(n) / fs) for c, m in enumerate(names)]).astype(np.complex64)
+
+    def batch():
+        b = ca.DemodBatch(C, 2048)
+        b.set_input_rate(fs)
+        for c, name in enumerate(names):
+            m, kw = MODES[name]
+            b.set_demod(c, m, info(ca, **kw))
+        b.commit()
+        for c in range(C):
+            b.set_freq(c, -100e3 - 700.0 * c)
+        return b
+
+    outs, meters = [], []
+    for cuts in ([24], [1] * 24, [5, 7, 12]):
+        b, at, parts = batch(), 0, []
+        for k in cuts:
+            parts.append(b.process(x[:, at * lim:(at + k) * lim])); at += k
+        outs.append([np.concatenate(p) for p in zip(*parts)])
+        meters.append(b.smeter_all())
+    singles = []
+    for c, name in enumerate(names):
+        m, kw = MODES[name]
+        d = ca.CDemodulator(2048)
+        d.SetInputSampleRate(fs); d.SetDemod(m, info(ca, **kw)); d.SetDemodFreq(-100e3 - 700.0 * c)
+        singles.append(d.process_append(x[c].astype(np.complex128)).astype(np.float32))
+    for c in range(C):
+        assert len(outs[0][c]) >= 1024
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][c].view(np.uint32), o[c].view(np.uint32)), (c, names[c])
+        assert np.array_equal(outs[0][c].view(np.uint32), singles[c].view(np.uint32)), (c, names[c], "drop-in object")
+    for mtr in meters[1:]:
+        assert np.abs(mtr - meters[0]).max() <= 1e-3
+
+
 def test_pipelined_mode_gives_the_strict_mode_results():
     """csdr_demod_batch_set_pipelined: the post-chain of call k overlaps the down-converter of call k+1 on
     internal streams; four calls issued back to back without any host synchronisation, one flush at the end --

@@ -174,9 +174,10 @@ def test_committed_batch_changes_its_input_rate(oracle, pipelined, sharded):
     groups0 = None if sharded else b.group_count()
 
     def run(x, what, settled):
-        # window by window: the drop-in object's chunking (m_InBufLimit samples per pass), so that every kernel of the
-        # batch sees the call lengths the single objects' kernels see -- equal WORDS are demanded below
-        parts = [b.process(x[:, i:i + lim]) for i in range(0, x.shape[1], lim)]
+        # calls of eight windows against the drop-in objects' window-sized passes: the chain's words do not depend on how
+        # a stream is cut into calls of whole tiles (test_chain_words_do_not_depend_on_how_the_stream_is_cut) -- equal
+        # WORDS are demanded below
+        parts = [b.process(x[:, i:i + 8 * lim]) for i in range(0, x.shape[1], 8 * lim)]
         got = [np.concatenate(p) for p in zip(*parts)]
         for c, name in enumerate(names):
             one = singles[c].process_append(x[c].astype(np.complex128))
