@@ -130,8 +130,20 @@ SANITIZERS = {"asan": ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-f
               "tsan": ["-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-fno-gpu-sanitize"]}
 
 
-def build(force=False, verbose=False, sanitize=None):
+def build(force=False, verbose=False, sanitize=None, variant=None, variant_flags=()):
+    """variant=NAME + variant_flags: a diagnostic copy of the whole library compiled with extra flags (every unit, the
+    down-converter plans included) into cutesdr_amd/_var/NAME/libcutesdr_mi_NAME.so -- never the library the product
+    loads; pick it with CSDR_LIB_PATH (tools/wg_trace.py builds its traced copy this way)."""
     global OBJ, LIB, FLAGS
+    if variant:
+        saved = (OBJ, LIB, FLAGS)
+        OBJ = os.path.join(HERE, "_var", variant)
+        LIB = os.path.join(OBJ, "libcutesdr_mi_%s.so" % variant)
+        FLAGS = FLAGS + list(variant_flags)
+        try:
+            return _build(force, verbose)
+        finally:
+            OBJ, LIB, FLAGS = saved
     if sanitize:
         saved = (OBJ, LIB, FLAGS)
         OBJ = os.path.join(HERE, "_san", sanitize)
@@ -204,4 +216,6 @@ def _build(force=False, verbose=False, link_extra=()):
 
 if __name__ == "__main__":
     kind = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--sanitize=")), None)
-    print(build(force="--force" in sys.argv, verbose=True, sanitize=kind))
+    var = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), None)
+    print(build(force="--force" in sys.argv, verbose=True, sanitize=kind, variant=var,
+                variant_flags=[a for a in sys.argv[1:] if a.startswith("-D")]))

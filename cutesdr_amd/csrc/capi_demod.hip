@@ -48,6 +48,7 @@ extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, c
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
                                                     long long out_stride, void *stream, const void *d_packets, int pkt_len,
                                                     const csdr::DcBlank *blank);
+extern "C" int csdr__downconvert_batch_set_wgs(csdr_downconvert_batch *b, long wgs);
 extern "C" int csdr__noiseproc_batch_mask(struct csdr_noiseproc_batch *b, const float *d_in, long long in_stride, const void *d_packets,
                                           int npackets, int pkt_len, int n_per_channel, unsigned *d_mask, long long mask_stride,
                                           const void **d_state, const float **d_hist, void *stream);
@@ -708,7 +709,7 @@ int csdr_demod_get_buf_limit(csdr_demod *d) { return d ? d->limit : fail(CSDR_EI
 static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out, bool stereo, bool append)
 {
     if (!d || n < 0 || (n && (!in_iq || !out))) return fail(CSDR_EINVAL, "bad argument");
-    if (d->limit <= 0 || d->limit > 250000) return fail(CSDR_ESTATE, "input buffer limit %d out of range", d->limit);
+    if (d->limit <= 0 || d->limit > refc::DEMOD_MAX_INBUFSIZE) return fail(CSDR_ESTATE, "input buffer limit %d out of range", d->limit);
     if (!device_ok(d->k.device)) return CSDR_EHIP;
     int ret = 0;
     for (int i = 0; i < n; ) {
@@ -1120,6 +1121,22 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         }
         return err ? err : CSDR_OK;
     }
+    // Strict mode, several groups: every down-converter behind the first starts while the previous group's filter, S-meter,
+    // peaks and walk hold part of the chip, and its workgroups are long (one wave walks its whole segment: 350 us) -- the
+    // ones that do not fit at once start only when the first ones END, a second round that costs a whole workgroup time
+    // for a few hundred stragglers (tools/wg_trace.py: 4031 of 4080 at once for the second group, 3277 of 4042 for the
+    // third).  Alone the kernel loses 4-7 % at 13 / 12 waves per CU instead of 16 (tools/experiments/r6_k2_grid.sh), so the
+    // later groups are cut into 13 x CUs and 12 x CUs workgroups and run as ONE round: strict C4 step 1.75-1.78 -> 1.67 ms.
+    // CSDR_DC_WGS_CORUN="a[,b]" overrides (second group's, later groups' workgroups; 0 = one full round for all).
+    static long corun_wgs[2] = {-1, -1};
+    if (corun_wgs[0] < 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+        const char *e = getenv("CSDR_DC_WGS_CORUN");
+        corun_wgs[1] = e && strchr(e, ',') ? atol(strchr(e, ',') + 1) : (e ? atol(e) : 12L * cus);
+        corun_wgs[0] = e ? atol(e) : 13L * cus;
+    }
+    const bool strict_multi = forked && !b->pipelined && plain && b->cores.size() > 1;
     // strict mode: CSDR_CHAIN_DC_CHAINED=0 starts every group's down-converter at once (A/B)
     static const bool dc_chained = !(getenv("CSDR_CHAIN_DC_CHAINED") && atoi(getenv("CSDR_CHAIN_DC_CHAINED")) == 0);
     for (size_t oi = 0; oi < b->cores.size(); oi++) {
@@ -1128,6 +1145,8 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         k.pk = d_packets; k.pk_len = pkt_len;            // this call's input as datagrams, or nullptr
         k.blank = blank;                                  // this call's blanker mask, or nullptr
         hipStream_t st = forked ? b->streams[ki] : caller;
+        if (strict_multi) csdr__downconvert_batch_set_wgs(k.dc, oi > 0 ? corun_wgs[oi > 1 ? 1 : 0] : 0);
+        else csdr__downconvert_batch_set_wgs(k.dc, 0);
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
         // pipelined: the caller's stream catches up with the PREVIOUS call only now, behind this call's fork
         // event, so that this call's down-converter is not held back by it: previous input consumed, output

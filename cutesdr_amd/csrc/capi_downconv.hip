@@ -29,6 +29,7 @@ struct csdr_downconvert_batch {
     // arithmetic; after a retune or a rate change (state_dirty / lists_dirty) the next call uploads it.
     int chan_cur; bool state_dirty, lists_dirty;
     std::vector<int> list_off, list_len;   // per plan: offset and length of its channel list in d_list
+    long wgs_hint = 0;                     // > 0: workgroups of the next launches (csdr__downconvert_batch_set_wgs), else one round
 };
 
 static int ensure_hist(csdr_downconvert_batch *b)
@@ -88,6 +89,15 @@ extern "C" int csdr__downconvert_batch_copy_channel(csdr_downconvert_batch *dst,
 /* internal (tests): 1 = every down-converter launch takes the run-time-plan kernel, 0 = precompiled plans where
  * they exist, -1 = query only; returns the number of precompiled plans in the library */
 extern "C" int csdr__downconv_force_dynamic(int on) { return downconv_force_dynamic(on); }
+/* internal (the batch chain): how many one-wave workgroups the next launches of this handle are cut into; 0 = the
+ * default, one round of the chip's 4096 slots.  A down-converter that starts while another group's walks hold part
+ * of the chip is sized for what is left, so that it still runs as ONE round (capi_demod.hip). */
+extern "C" int csdr__downconvert_batch_set_wgs(csdr_downconvert_batch *b, long wgs)
+{
+    if (!b || wgs < 0) return fail(CSDR_EINVAL, "bad argument");
+    b->wgs_hint = wgs;
+    return CSDR_OK;
+}
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
                                                     long long out_stride, void *stream, const void *d_packets, int pkt_len,
@@ -297,7 +307,7 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
         // -3 / -4 / -5 % (FM / SSB / AM, 86 receivers x 2^21), the strict chain -1.6 %, pipelined +-0.  (A few workgroups more
         // than a whole number of rounds start a nearly empty one: 86 x 96 = 8256 took 1.8x the time of 85 x 96.)
         static const long dc_wgs = getenv("CSDR_DC_WGS") ? atol(getenv("CSDR_DC_WGS")) : 4096;
-        long nseg = dc_wgs / a.nchan;
+        long nseg = (b->wgs_hint > 0 ? b->wgs_hint : dc_wgs) / a.nchan;
         if (nseg > n_per_channel / min_seg) nseg = n_per_channel / min_seg;
         if (nseg < 1) nseg = 1;
         long seg_len = (n_per_channel + nseg - 1) / nseg;

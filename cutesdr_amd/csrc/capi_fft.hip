@@ -67,8 +67,8 @@ static int fft_set_params(csdr_fft_batch *f, int size, int invert, double db_com
         CSDR_HIP(hipMalloc((void **)&f->d_ave, nb));
         if (l2 < 11 || l2 > 14) CSDR_HIP(hipMalloc((void **)&f->d_work, nb * 4));   // [2][channels][N] complex
         CSDR_HIP(hipMemset(f->d_pwr, 0, nb));
-        f->kb = f->db_comp - 20 * std::log10((double)n * 32767.0 / 2.0);
-        f->kc = std::pow(10.0, (-220.0 - f->kb) / 10.0);
+        f->kb = f->db_comp - 20 * std::log10((double)n * refc::FFT_K_AMPMAX / 2.0);
+        f->kc = std::pow(10.0, (refc::FFT_K_MINDB - f->kb) / 10.0);
         f->kb = f->kb / 10.0;
         std::vector<float> win(n), tw1(2048), tw2(2048);
         for (int i = 0; i < n; i++) win[i] = (float)(2.0 * (.5 - .5 * std::cos((kTwoPi * i) / (n - 1))));

@@ -3,6 +3,7 @@
 // NCO-spur DC estimate (interface/sdrinterface.cpp:829-848).
 #include "capi_common.hpp"
 #include "frontend_kernels.h"
+#include "ref_constants.hpp"
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -38,7 +39,7 @@ static int nb_setup_one(csdr_noiseproc_batch *b, int c, int on, double thresh, d
     n.width_n = (int)(width * 1e-6 * fs);
     if (n.width_n < 1) n.width_n = 1;
     else if (n.width_n > NB_MAX_WIDTH) n.width_n = NB_MAX_WIDTH;
-    n.mag_n = (int)(0.005 * fs);
+    n.mag_n = (int)(refc::NB_MAGAVE_TIME * fs);
     if (n.mag_n > NB_HIST - 1)
         return fail(CSDR_EINVAL, "sample rate %.0f: the 5 ms magnitude window (%d samples) exceeds the "
                     "reference's 32768-entry buffer", fs, n.mag_n);

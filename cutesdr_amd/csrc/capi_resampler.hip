@@ -91,9 +91,9 @@ int csdr_resampler_init(csdr_resampler *r, int max_input_size)
     if (!r->d_sinc) {
         std::vector<float> tab(RS_LEN);
         for (int i = 0; i < RS_LEN; i++) {
-            const double w = 0.35875 - 0.48829 * std::cos((kTwoPi * i) / (RS_LEN - 1)) +
-                             0.14128 * std::cos((2.0 * kTwoPi * i) / (RS_LEN - 1)) -
-                             0.01168 * std::cos((3.0 * kTwoPi * i) / (RS_LEN - 1));
+            const double w = refc::RS_WIN_A0 - refc::RS_WIN_A1 * std::cos((kTwoPi * i) / (RS_LEN - 1)) +
+                             refc::RS_WIN_A2 * std::cos((2.0 * kTwoPi * i) / (RS_LEN - 1)) -
+                             refc::RS_WIN_A3 * std::cos((3.0 * kTwoPi * i) / (RS_LEN - 1));
             const double fi = kPi * (double)(i - RS_LEN / 2) / (double)RS_PTS;
             tab[i] = (i != RS_LEN / 2) ? (float)(w * std::sin(fi) / fi) : 1.0f;
         }
@@ -135,9 +135,9 @@ static int rs_build_sinc(float **d_sinc)
 {
     std::vector<float> tab(RS_LEN);
     for (int i = 0; i < RS_LEN; i++) {
-        const double w = 0.35875 - 0.48829 * std::cos((kTwoPi * i) / (RS_LEN - 1)) +
-                         0.14128 * std::cos((2.0 * kTwoPi * i) / (RS_LEN - 1)) -
-                         0.01168 * std::cos((3.0 * kTwoPi * i) / (RS_LEN - 1));
+        const double w = refc::RS_WIN_A0 - refc::RS_WIN_A1 * std::cos((kTwoPi * i) / (RS_LEN - 1)) +
+                         refc::RS_WIN_A2 * std::cos((2.0 * kTwoPi * i) / (RS_LEN - 1)) -
+                         refc::RS_WIN_A3 * std::cos((3.0 * kTwoPi * i) / (RS_LEN - 1));
         const double fi = kPi * (double)(i - RS_LEN / 2) / (double)RS_PTS;
         tab[i] = (i != RS_LEN / 2) ? (float)(w * std::sin(fi) / fi) : 1.0f;
     }

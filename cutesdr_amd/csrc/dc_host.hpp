@@ -27,7 +27,7 @@ inline DcPlan dc_make_plan(double in_rate, double max_bw)
     double f = in_rate;
     int n = 0;
     long need = 0;
-    while (max_bw > 0 && f > (max_bw / csdr_hb_maxbw[CSDR_HB_NUM_FILTERS - 1]) && f > (7900.0 * 2.0) &&
+    while (max_bw > 0 && f > (max_bw / csdr_hb_maxbw[CSDR_HB_NUM_FILTERS - 1]) && f > refc::DCV_MIN_OUTPUT_RATE &&
            n < DC_MAX_STAGES) {
         DcStage &s = p.st[n];
         if (f >= (max_bw / CSDR_CIC3_MAXBW)) {

@@ -302,8 +302,11 @@ __device__ __forceinline__ float dc_rotl1(float v)
 
 // BLK: the noise blanker's decision applied in this kernel's loads (DcArgs::nb_mask; a kernel of its own so that the
 // plain kernel keeps its registers: the blanked form carries the mask words and one more sample per tile)
+#ifndef CSDR_DC_WAVES_PER_EU
+#define CSDR_DC_WAVES_PER_EU 4
+#endif
 template <class P, bool BLK = false>
-__global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(CSDR_DC_WAVES_PER_EU, CSDR_DC_WAVES_PER_EU)))
 void downconv_kernel(DcArgs a)
 {
     constexpr bool FIX = P::NS >= 0;                      // compile-time plan
@@ -312,6 +315,7 @@ void downconv_kernel(DcArgs a)
     v2f *lds = reinterpret_cast<v2f *>(smem_raw);
     const int t = threadIdx.x;
     const int ns = FIX ? P::NS : a.nstages;
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_DC);
     const int wg = blockIdx.x;
     const int ci = wg / a.nseg, seg = wg % a.nseg;
     if (ci >= a.nchan) return;

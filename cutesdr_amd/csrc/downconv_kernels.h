@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "wire_format.hpp"
 #include "frontend_kernels.h"
+#include "wg_trace.hpp"
 
 namespace csdr {
 
@@ -53,6 +54,9 @@ struct DcArgs {
     int ooff[DC_MAX_STAGES + 1];             // offset of the odd-sample half inside region s
     int kind[DC_MAX_STAGES];                 // 3 = CIC3, otherwise the half-band length (11, 15, .. 51)
     DcStage st[DC_MAX_STAGES];
+#ifdef CSDR_WG_TRACE
+    WgTraceArg trace;
+#endif
 };
 
 // what a caller hands over to have the blanker's mask applied (csdr__downconvert_batch_process_rows)

@@ -44,6 +44,9 @@ int downconv_force_dynamic(int on)
 hipError_t downconv_launch(DcArgs &a, hipStream_t stream)
 {
     const int lds = downconv_layout(a);
+#ifdef CSDR_WG_TRACE
+    a.trace = wgtrace_next();
+#endif
     if (!dc_force_dynamic)
         for (const DcCompiledPlan *p = dc_compiled; p->launch; p++) {
             if (p->ns != a.nstages) continue;

@@ -100,6 +100,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(K1Cfg<LOG2N>::T) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fastfir_os2_kernel(FastFirArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_FF);
     using Cfg = FastFirCfg<LOG2N>;
     constexpr int N = Cfg::N, T = Cfg::T, R0 = Cfg::R0, G = Cfg::G, L = N / 2;
     constexpr int HALF = R0 / 2;
@@ -686,6 +687,13 @@ static hipError_t launch2_one(const FastFirArgs &a, hipStream_t stream)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<LOG2N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
+#ifdef CSDR_WG_TRACE
+    FastFirArgs b = a;
+    b.trace = wgtrace_next();
+    hipLaunchKernelGGL((fastfir_os2_kernel<LOG2N>), dim3((a.channels * a.runs + Cfg::VW - 1) / Cfg::VW), dim3(Cfg::T),
+                       Cfg::LDS_BYTES, stream, b);
+    return hipGetLastError();
+#endif
     hipLaunchKernelGGL((fastfir_os2_kernel<LOG2N>), dim3((a.channels * a.runs + Cfg::VW - 1) / Cfg::VW), dim3(Cfg::T),
                        Cfg::LDS_BYTES, stream, a);
     return hipGetLastError();

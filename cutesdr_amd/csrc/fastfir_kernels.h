@@ -1,6 +1,7 @@
 // fastfir_kernels.h -- launch interface of the batched overlap-save kernel (internal).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wg_trace.hpp"
 
 namespace csdr {
 
@@ -24,6 +25,9 @@ struct FastFirArgs {
     int runs;             // ceil(nblocks / blocks_per_run)
     int dbg_stage;        // 0 in production; >0 selects the diagnostic twin kernel
     v2f_h *dbg;           // [N] LDS image dump of the diagnostic twin
+#ifdef CSDR_WG_TRACE
+    WgTraceArg trace;
+#endif
 };
 
 hipError_t fastfir_launch(int log2n, const FastFirArgs &a, hipStream_t stream);

@@ -8,6 +8,7 @@
 // element-wise kernels around it with exactly the arithmetic of spectrum_kernel.
 #include "fft_core.hpp"
 #include "spectrum_kernels.h"
+#include "ref_constants.hpp"
 
 namespace csdr {
 
@@ -34,7 +35,7 @@ __global__ void spec_prep_kernel(SpectrumArgs a, int n, int frame, v2f *work, lo
     if (i >= n) return;
     const v2f s = reinterpret_cast<const v2f *>(a.in)[(long)ch * a.in_stride + (long)frame * n + i];
     const float w = a.win[i];
-    if (s.x > 32000.0f) a.overload[ch] = 1;
+    if (s.x > refc::FFT_OVER_LIMIT_F) a.overload[ch] = 1;
     work[(long)ch * wstride + i] = v2f{w * s.y, w * s.x};
 }
 __global__ void spec_count_kernel(SpectrumArgs a)

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <complex>
 #include <vector>
+#include "ref_constants.hpp"
 
 namespace csdr {
 
@@ -55,9 +56,9 @@ inline bool fastfir_design(int n, double flo, double fhi, double offset, double 
         if ((double)i == centre) {
             z = 2.0 * nfc;
         } else {
-            const double w = 0.3635819 - 0.4891775 * std::cos((kTwoPi * i) / (p - 1)) +
-                             0.1365995 * std::cos((2.0 * kTwoPi * i) / (p - 1)) -
-                             0.0106411 * std::cos((3.0 * kTwoPi * i) / (p - 1));
+            const double w = refc::FF_WIN_A0 - refc::FF_WIN_A1 * std::cos((kTwoPi * i) / (p - 1)) +
+                             refc::FF_WIN_A2 * std::cos((2.0 * kTwoPi * i) / (p - 1)) -
+                             refc::FF_WIN_A3 * std::cos((3.0 * kTwoPi * i) / (p - 1));
             z = std::sin(kTwoPi * x * nfc) / (kPi * x) * w;
         }
         H[i] = cd(z * std::cos(nfs * x) / (double)n, z * std::sin(nfs * x) / (double)n);

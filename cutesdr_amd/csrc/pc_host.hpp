@@ -5,6 +5,7 @@
 #include <cstring>
 #include "host_math.hpp"
 #include "postchain.h"
+#include "ref_constants.hpp"
 
 namespace csdr {
 
@@ -120,8 +121,8 @@ inline void smeter_rate(PcSMeter &s, double fs)
 {
     if (fs != s.fs) {
         s.fs = fs;
-        s.att_a = (1.0 - std::exp(-1.0 / (fs * .01)));
-        s.dec_a = (1.0 - std::exp(-1.0 / (fs * .5)));
+        s.att_a = (1.0 - std::exp(-1.0 / (fs * refc::SM_ATTACK_TIMECONST)));
+        s.dec_a = (1.0 - std::exp(-1.0 / (fs * refc::SM_DECAY_TIMECONST)));
     }
 }
 
@@ -144,18 +145,18 @@ struct HostAgc {
             rc = 2;
         }
         d.on = on; d.hang = hang;
-        d.manual_gain = 32767.0 * std::pow(10.0, -(100 - (double)manual) / 20.0);
+        d.manual_gain = refc::AGC_MAX_MANUAL_AMPLITUDE * std::pow(10.0, -(100 - (double)manual) / 20.0);
         d.knee = (double)thresh / 20.0;
         d.gain_slope = slope / (100.0);
-        d.fixed_gain = 0.7 * std::pow(10.0, d.knee * (d.gain_slope - 1.0));
-        d.att_rise = (1.0 - std::exp(-1.0 / (fs * .002)));
-        d.att_fall = (1.0 - std::exp(-1.0 / (fs * .005)));
-        d.dec_rise = (1.0 - std::exp(-1.0 / (fs * (double)decay * .001 * .3)));
+        d.fixed_gain = refc::AGC_OUTSCALE * std::pow(10.0, d.knee * (d.gain_slope - 1.0));
+        d.att_rise = (1.0 - std::exp(-1.0 / (fs * refc::AGC_ATTACK_RISE_TIMECONST)));
+        d.att_fall = (1.0 - std::exp(-1.0 / (fs * refc::AGC_ATTACK_FALL_TIMECONST)));
+        d.dec_rise = (1.0 - std::exp(-1.0 / (fs * (double)decay * .001 * refc::AGC_DECAY_RISEFALL_RATIO)));
         d.hang_time = (int)(fs * (double)decay * .001);
-        if (hang) d.dec_fall = (1.0 - std::exp(-1.0 / (fs * .05)));
+        if (hang) d.dec_fall = (1.0 - std::exp(-1.0 / (fs * refc::AGC_RELEASE_TIMECONST)));
         else      d.dec_fall = (1.0 - std::exp(-1.0 / (fs * (double)decay * .001)));
-        d.dly_n = (int)(fs * .015);
-        d.win_n = (int)(fs * .018);
+        d.dly_n = (int)(fs * refc::AGC_DELAY_TIMECONST);
+        d.win_n = (int)(fs * refc::AGC_WINDOW_TIMECONST);
         if (d.dly_n >= PC_AGC_RING - 1) d.dly_n = PC_AGC_RING - 1;
         if (d.win_n > PC_AGC_RING) d.win_n = PC_AGC_RING;      // reference overruns its buffer here (App. A.6)
         if (d.dly_n < 1) d.dly_n = 1;
@@ -180,9 +181,9 @@ inline void sam_init(PcSam &d, HostFir &fir, double fs)         // samdemod.cpp:
 {
     const double norm = kTwoPi / fs;
     d.y1 = d.z1 = 0.0; d.phase = 0.0; d.freq = 0.0;
-    d.lo = -1000.0 * norm; d.hi = 1000.0 * norm;
-    d.alpha = 2.0 * .707 * 100.0 * norm;
-    d.beta = (d.alpha * d.alpha) / (4.0 * .707 * .707);
+    d.lo = -refc::SAM_PLL_LIMIT * norm; d.hi = refc::SAM_PLL_LIMIT * norm;
+    d.alpha = 2.0 * refc::SAM_PLL_ZETA * refc::SAM_PLL_BW * norm;
+    d.beta = (d.alpha * d.alpha) / (4.0 * refc::SAM_PLL_ZETA * refc::SAM_PLL_ZETA);
     fir.init_lp(1.0, 40.0, 4500, 5500, fs);
     fir.gen_hilbert(5000.0);
     fir.upload(d.fir, true);
@@ -191,15 +192,15 @@ inline void fm_init(PcFm &d, HostFir &hp, double fs)            // fmdemod.cpp:6
 {
     const double norm = kTwoPi / fs;
     d.err_dc = 0.0; d.phase = 0.0; d.freq = 0.0;
-    d.lo = -6000.0 * norm; d.hi = 6000.0 * norm;
-    d.alpha = 2.0 * .707 * 3000.0 * 2.0 * norm;
-    d.beta = (d.alpha * d.alpha) / (4.0 * .707 * .707);
-    d.out_gain = 25000.0 / d.hi;
-    d.dc_alpha = (1.0 - std::exp(-1.0 / (fs * 0.01)));
-    d.hp_freq = 3000.0;
+    d.lo = -refc::FM_PLL_RANGE * norm; d.hi = refc::FM_PLL_RANGE * norm;
+    d.alpha = 2.0 * refc::FM_PLL_ZETA * refc::FM_VOICE_BANDWIDTH * 2.0 * norm;      // 2.0*FMPLL_ZETA*FMPLL_BW*norm, FMPLL_BW = VOICE_BANDWIDTH*2.0
+    d.beta = (d.alpha * d.alpha) / (4.0 * refc::FM_PLL_ZETA * refc::FM_PLL_ZETA);
+    d.out_gain = refc::FM_MAX_OUT / d.hi;
+    d.dc_alpha = (1.0 - std::exp(-1.0 / (fs * refc::FM_DC_ALPHA)));
+    d.hp_freq = refc::FM_VOICE_BANDWIDTH;
     d.sq_ave = 0.0; d.squelched = 1; d.sq_thresh = 0.0;
-    d.sq_alpha = (1.0 - std::exp(-1.0 / (fs * .02)));
-    iir_design(d.lp, 0, 3000.0, 1.0, fs);
+    d.sq_alpha = (1.0 - std::exp(-1.0 / (fs * refc::FM_SQUELCHAVE_TIMECONST)));
+    iir_design(d.lp, 0, refc::FM_VOICE_BANDWIDTH, 1.0, fs);
     hp.init_hp(1.0, 50.0, d.hp_freq, d.hp_freq * .6, fs);
     hp.upload(d.hp, true);
 }
@@ -213,7 +214,7 @@ inline void fm_set_bw(PcFm &d, HostFir &hp, double fs, double fm_bw)   // fmdemo
 }
 inline void fm_set_squelch(PcFm &d, int value)                  // fmdemod.cpp:95-98
 {
-    d.sq_thresh = (double)(5000.0 - ((5000.0 * value) / 99));
+    d.sq_thresh = (double)(refc::FM_SQUELCH_MAX - ((refc::FM_SQUELCH_MAX * value) / 99));
 }
 
 }  // namespace csdr

@@ -6,6 +6,7 @@
 // data path and the transcendentals run in fp32.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wg_trace.hpp"
 
 namespace csdr {
 
@@ -88,6 +89,9 @@ struct PcArgs {
     float *pkbuf;                       // PC_AGC_PRE: [channels][nbursts * burst] sliding peak of the log magnitudes
     float *magtail;                     // PC_AGC_PRE: [channels][PC_AGC_RING] the call's last win_n-1 log magnitudes
     int pre_bpw;                        // PC_AGC_PRE: bursts per workgroup of the peaks kernel
+#ifdef CSDR_WG_TRACE
+    WgTraceArg trace;
+#endif
 };
 constexpr int PC_SQ_REC = 12;           // per burst: squelch-average map (2), low-pass state map (4 + 2), decision, start state (2)
 

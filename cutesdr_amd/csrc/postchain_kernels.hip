@@ -15,6 +15,7 @@
 // (<= 78 kS/s per channel): the kernel is measured in cycles per sample, not against a roofline.
 #include <hip/hip_runtime.h>
 #include "postchain.h"
+#include "ref_constants.hpp"
 #include <cstdlib>
 
 namespace csdr {
@@ -981,6 +982,7 @@ template <int NW, bool LEAN>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? (LEAN ? CSDR_PC_LEAN_WAVES_PER_EU : CSDR_PC_WAVES_PER_EU) : 1)))
 void postchain_kernel(PcArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_WALK);
     using G = Wg<NW>;
     constexpr int NT = G::NT, LC = G::LC;
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
@@ -1041,7 +1043,8 @@ void postchain_kernel(PcArgs a)
         for (int i = t; i < nt - 1; i += NT) { S.w0[i] = (mode == PC_MODE_FM || (mode == PC_MODE_AM && !stereo)) ? fir->zreal[i] : fir->zr[i]; S.w1[i] = fir->zi[i]; }
     }
     pow_table(S.pw_sm, 1.0 - sm.att_a, t);
-    pow_table(S.pw_dc, 0.99, t);
+    static_assert(refc::AM_DC_ALPHA == refc::SAM_DC_ALPHA, "one table of DC-blocker powers serves AM and SAM");
+    pow_table(S.pw_dc, refc::AM_DC_ALPHA, t);
     pow_table(S.pw_sq, 1.0 - C.fm.sq_alpha, t);
     pow_table(S.pw_fd, 1.0 - C.fm.dc_alpha, t);
     biquad_table(S.bq, lp, t);
@@ -1091,7 +1094,7 @@ void postchain_kernel(PcArgs a)
             // ---------------- S-meter (smeter.cpp:62-93) ----------------
             if constexpr (!LEAN) if (do_sm) {
                 for (int i = t; i < n; i += NT) {
-                    const float pw = (x[i].x * x[i].x + x[i].y * x[i].y) * (1.0f / (32767.0f * 32767.0f));
+                    const float pw = (x[i].x * x[i].x + x[i].y * x[i].y) * refc::SM_INV_MAX_PWR_F;
                     S.w2[i] = pw > 0.f ? 10.0f * log10f(pw) : -500.0f;
                 }
                 g.sync();
@@ -1113,7 +1116,7 @@ void postchain_kernel(PcArgs a)
                         for (int i = t; i < n; i += NT) {
                             float m = fabsf(x[i].x);
                             if (!agc_real) { const float mi = fabsf(x[i].y); if (mi > m) m = mi; }
-                            mg[i] = log10f(m + 3.2767e-4f) - 4.51543987f;
+                            mg[i] = log10f(m + refc::AGC_MIN_CONSTANT_F) - refc::AGC_LOG10_MAX_AMPLITUDE_F;
                         }
                         g.sync();
                         // sliding maximum: pk[i] = max E[i .. i+W1], E = [W1 history | tile] = S.mg
@@ -1211,7 +1214,7 @@ void postchain_kernel(PcArgs a)
                 for (int i = t; i < n; i += NT) w[i] = sqrtf(x[i].x * x[i].x + x[i].y * x[i].y);
                 g.sync();
                 // DC block z0 = x + 0.99 z1, out = z0 - z1 (amdemod.cpp:70-80)
-                am_z1 = lin1_scan<true>(g, w, n, 0.99, 1.0, am_z1, S.pw_dc,
+                am_z1 = lin1_scan<true>(g, w, n, refc::AM_DC_ALPHA, 1.0, am_z1, S.pw_dc,
                                         [&](int i, float, double z0, double z1) { w[i] = (float)(z0 - z1); });
                 g.sync();
                 float acc[LC], acq[LC];
@@ -1339,10 +1342,10 @@ void postchain_kernel(PcArgs a)
                     }
                     g.sync();
                     // DC blocks
-                    sam_z1 = lin1_scan<true>(g, au, n, 0.99, 1.0, sam_z1, S.pw_dc,
+                    sam_z1 = lin1_scan<true>(g, au, n, refc::SAM_DC_ALPHA, 1.0, sam_z1, S.pw_dc,
                                              [&](int i, float, double z0, double z1) { au[i] = (float)(z0 - z1); });
                     if (stereo)
-                        sam_y1 = lin1_scan<true>(g, th, n, 0.99, 1.0, sam_y1, S.pw_dc,
+                        sam_y1 = lin1_scan<true>(g, th, n, refc::SAM_DC_ALPHA, 1.0, sam_y1, S.pw_dc,
                                                  [&](int i, float, double y0, double y1) { th[i] = (float)(y0 - y1); });
                     g.sync();
                     if (!stereo) {
@@ -1368,8 +1371,8 @@ void postchain_kernel(PcArgs a)
         if constexpr (!LEAN) if (mode == PC_MODE_FM && a.burst <= 16384 && !defer) {
             const PcFm &F = C.fm;
             if (0 == F.sq_thresh) fm_squelched = 1;
-            else if (fm_squelched) { if (fm_sq < (F.sq_thresh - 100.0)) fm_squelched = 0; }
-            else { if (fm_sq >= (F.sq_thresh + 100.0)) fm_squelched = 1; }
+            else if (fm_squelched) { if (fm_sq < (F.sq_thresh - refc::FM_SQUELCH_HYSTERESIS)) fm_squelched = 0; }
+            else { if (fm_sq >= (F.sq_thresh + refc::FM_SQUELCH_HYSTERESIS)) fm_squelched = 1; }
             const long g0 = (long)b * a.burst;
             g.sync();
             for (int t0 = 0; t0 < a.burst; t0 += PT) {
@@ -1440,6 +1443,7 @@ void postchain_kernel(PcArgs a)
 __global__ __launch_bounds__(256)
 void agc_peaks_kernel(PcArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_PEAKS);
     using G = Wg<4>;
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
@@ -1459,7 +1463,7 @@ void agc_peaks_kernel(PcArgs a)
         float m = fabsf(v.x);
         const float mi = fabsf(v.y);
         if (mi > m) m = mi;
-        return log10f(m + 3.2767e-4f) - 4.51543987f;     // agc.cpp:196-201
+        return log10f(m + refc::AGC_MIN_CONSTANT_F) - refc::AGC_LOG10_MAX_AMPLITUDE_F;     // agc.cpp:196-201
     };
     const long p0 = (long)b0 * a.burst, p1 = (long)b1 * a.burst, total = (long)a.nbursts * a.burst;
     // the window in front of this group's first sample
@@ -1502,6 +1506,9 @@ hipError_t agc_peaks_launch(const PcArgs &a, hipStream_t stream)
     b.pre_bpw = (int)(((long)a.channels * a.nbursts + slots - 1) / slots);
     if (b.pre_bpw < 1) b.pre_bpw = 1;
     const int ngrp = (a.nbursts + b.pre_bpw - 1) / b.pre_bpw;
+#ifdef CSDR_WG_TRACE
+    b.trace = wgtrace_next();
+#endif
     hipLaunchKernelGGL(agc_peaks_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(PreLds), stream, b);
     return hipGetLastError();
 }
@@ -1525,6 +1532,7 @@ struct SmLds {
 __global__ __launch_bounds__(256)
 void smeter_call_kernel(PcArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_SMETER);
     using G = Wg<4>;
     __shared__ SmLds S;
     const int t = threadIdx.x, ch = blockIdx.x;
@@ -1541,7 +1549,7 @@ void smeter_call_kernel(PcArgs a)
         g.sync();                                        // the previous super-tile's runs have been read (and S.pw written)
         for (int i = t; i < n; i += 256) {
             const float2 v = in[p0 + i];
-            const float pw = (v.x * v.x + v.y * v.y) * (1.0f / (32767.0f * 32767.0f));
+            const float pw = (v.x * v.x + v.y * v.y) * refc::SM_INV_MAX_PWR_F;
             S.db[i + (i >> 5)] = pw > 0.f ? 10.0f * log10f(pw) : -500.0f;
         }
         g.sync();
@@ -1568,7 +1576,11 @@ void smeter_call_kernel(PcArgs a)
 }
 hipError_t smeter_call_launch(const PcArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(smeter_call_kernel, dim3(a.channels), dim3(256), 0, stream, a);
+    PcArgs b = a;
+#ifdef CSDR_WG_TRACE
+    b.trace = wgtrace_next();
+#endif
+    hipLaunchKernelGGL(smeter_call_kernel, dim3(a.channels), dim3(256), 0, stream, b);
     return hipGetLastError();
 }
 
@@ -1610,6 +1622,7 @@ __device__ __forceinline__ void sq_lp_maps(const Wg<NW> &g, const float *sq, con
 __global__ __launch_bounds__(256)
 void fm_squelch_maps_kernel(PcArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_SQ_MAPS);
     using G = Wg<4>;
     constexpr int NT = G::NT, LC = G::LC;
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
@@ -1691,6 +1704,7 @@ void fm_squelch_maps_kernel(PcArgs a)
 __global__ __launch_bounds__(64)
 void fm_squelch_decide_kernel(PcArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_SQ_DECIDE);
     const int t = threadIdx.x, ch = blockIdx.x;
     if (a.out_rows && a.out_rows[ch] < 0) return;
     PcChannel &C = a.chan[ch];
@@ -1730,8 +1744,8 @@ void fm_squelch_decide_kernel(PcArgs a)
                 const double *r = rec[b];
                 sq = r[0] * sq + r[1];
                 if (0 == F.sq_thresh) sqd = 1;                                  // fmdemod.cpp:128-151
-                else if (sqd) { if (sq < (F.sq_thresh - 100.0)) sqd = 0; }
-                else { if (sq >= (F.sq_thresh + 100.0)) sqd = 1; }
+                else if (sqd) { if (sq < (F.sq_thresh - refc::FM_SQUELCH_HYSTERESIS)) sqd = 0; }
+                else { if (sq >= (F.sq_thresh + refc::FM_SQUELCH_HYSTERESIS)) sqd = 1; }
                 res[b][0] = (double)sqd; res[b][1] = w1; res[b][2] = w2;
                 if (!sqd) {                                                     // the low-pass runs on open bursts only
                     const double nw1 = r[2] * w1 + r[3] * w2 + r[6], nw2 = r[4] * w1 + r[5] * w2 + r[7];
@@ -1751,6 +1765,7 @@ void fm_squelch_decide_kernel(PcArgs a)
 __global__ __launch_bounds__(256)
 void fm_squelch_apply_kernel(PcArgs a)
 {
+    CSDR_WG_TRACE_SCOPE(a.trace, WGT_SQ_APPLY);
     using G = Wg<4>;
     constexpr int NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_smem[];
@@ -1801,8 +1816,17 @@ hipError_t fm_squelch_launch(const PcArgs &a, hipStream_t stream)
     b.sq_bpw = (int)(((long)a.channels * a.nbursts + slots - 1) / slots);
     if (b.sq_bpw < 1) b.sq_bpw = 1;
     const int ngrp = (a.nbursts + b.sq_bpw - 1) / b.sq_bpw;
+#ifdef CSDR_WG_TRACE
+    b.trace = wgtrace_next();
+#endif
     hipLaunchKernelGGL(fm_squelch_maps_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(SqLds), stream, b);
+#ifdef CSDR_WG_TRACE
+    b.trace = wgtrace_next();
+#endif
     hipLaunchKernelGGL(fm_squelch_decide_kernel, dim3(a.channels), dim3(64), 0, stream, b);
+#ifdef CSDR_WG_TRACE
+    b.trace = wgtrace_next();
+#endif
     hipLaunchKernelGGL(fm_squelch_apply_kernel, dim3(a.channels * ngrp), dim3(256), sizeof(SqLds), stream, b);
     return hipGetLastError();
 }
@@ -1844,9 +1868,9 @@ __global__ void smeter_collect_kernel(PcChannel *chan, int channels, const int *
     if (c >= channels) return;
     const int o = rows ? rows[c] : c;
     if (o < 0) return;                  // a row whose receiver has moved to another plan group (csdr_demod_batch_set_demod)
-    if (ave) ave[o] = (T)(chan[c].sm.ave_mag + 5.0);
+    if (ave) ave[o] = (T)(chan[c].sm.ave_mag + refc::SM_CALIBRATION);
     if (peak) {
-        peak[o] = (T)(chan[c].sm.peak_mag + 5.0);
+        peak[o] = (T)(chan[c].sm.peak_mag + refc::SM_CALIBRATION);
         chan[c].sm.peak_mag = 0.0;
     }
 }
@@ -1870,7 +1894,11 @@ static hipError_t pc_launch_nw(const PcArgs &a, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PcLds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((postchain_kernel<NW, LEAN>), dim3(a.channels), dim3(64 * NW), sizeof(PcLds), stream, a);
+    PcArgs b = a;
+#ifdef CSDR_WG_TRACE
+    b.trace = wgtrace_next();
+#endif
+    hipLaunchKernelGGL((postchain_kernel<NW, LEAN>), dim3(a.channels), dim3(64 * NW), sizeof(PcLds), stream, b);
     return hipGetLastError();
 }
 hipError_t postchain_launch(const PcArgs &a, hipStream_t stream)

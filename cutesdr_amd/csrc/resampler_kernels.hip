@@ -9,6 +9,7 @@
 // table index bit-identical.
 #include <hip/hip_runtime.h>
 #include "resampler_kernels.h"
+#include "ref_constants.hpp"
 
 namespace csdr {
 
@@ -29,8 +30,8 @@ __global__ void resample_kernel(ResampleArgs a)
     }
     if (a.out_i16) {
         float x = ar * a.gain, y = ai * a.gain;                      // :215-227: scale, clip, truncate
-        x = fminf(fmaxf(x, -32767.0f), 32767.0f);
-        y = fminf(fmaxf(y, -32767.0f), 32767.0f);
+        x = fminf(fmaxf(x, -refc::RS_MAX_SOUNDCARDVAL_F), refc::RS_MAX_SOUNDCARDVAL_F);
+        y = fminf(fmaxf(y, -refc::RS_MAX_SOUNDCARDVAL_F), refc::RS_MAX_SOUNDCARDVAL_F);
         if (a.cpx) { a.out_i16[2 * m] = (short)x; a.out_i16[2 * m + 1] = (short)y; }
         else a.out_i16[m] = (short)x;
     } else if (a.cpx) {
@@ -73,7 +74,7 @@ __global__ void resample_batch_kernel(ResampleBatchArgs a)
             acc += (j < RS_PERIODS ? hist[j] : in[j - RS_PERIODS]) * a.sinc[k];
         }
         if (a.out_i16) {
-            const float x = fminf(fmaxf(acc * a.gain, -32767.0f), 32767.0f);
+            const float x = fminf(fmaxf(acc * a.gain, -refc::RS_MAX_SOUNDCARDVAL_F), refc::RS_MAX_SOUNDCARDVAL_F);
             a.out_i16[(long)ch * a.out_stride + m] = (short)x;
         } else {
             a.out_f32[(long)ch * a.out_stride + m] = acc;

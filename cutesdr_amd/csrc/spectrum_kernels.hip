@@ -11,6 +11,7 @@
 #define CSDR_PLAIN_CONST_FMA 1
 #include "fft_core.hpp"
 #include "spectrum_kernels.h"
+#include "ref_constants.hpp"
 
 namespace csdr {
 
@@ -201,7 +202,7 @@ void spectrum_kernel(SpectrumArgs a)
                 v2f s;
                 if constexpr (PREFETCH) s = nxt[e * R0 + n1]; else s = in[(long)f * N + i];
                 const float w = a.win[i];
-                if (s.x > 32000.0f) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
+                if (s.x > refc::FFT_OVER_LIMIT_F) over = 1;                     // OVER_LIMIT, fft.cpp:30,275
                 x[e * R0 + n1] = v2f{w * s.y, w * s.x};           // I/Q swapped, fft.cpp:280-281
             }
         if (f + 1 < f1) fetch(f + 1);
@@ -290,7 +291,7 @@ void spectrum16_kernel(SpectrumArgs a)
         static_for<0, 16>([&](auto Q) {
             constexpr int q = Q.value;
             const v2f s_ = nxt[q];
-            if (s_.x > 32000.0f) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
+            if (s_.x > refc::FFT_OVER_LIMIT_F) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
             x[bitrev<16>(q)] = v2f{wn[q] * s_.y, wn[q] * s_.x};    // I/Q swapped, fft.cpp:280-281
         });
         if (f + 1 < f1) fetch(f + 1);
@@ -396,7 +397,7 @@ void spectrum8_kernel(SpectrumArgs a)
         static_for<0, 16>([&](auto Q) {
             constexpr int q = Q.value;
             const v2f s_ = nxt[q];
-            if (s_.x > 32000.0f) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
+            if (s_.x > refc::FFT_OVER_LIMIT_F) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
             x[bitrev<16>(q)] = v2f{wn[q] * s_.y, wn[q] * s_.x};    // I/Q swapped, fft.cpp:280-281
         });
         if (f + 1 < f1) fetch(f + 1);
@@ -531,7 +532,7 @@ void spectrum32_kernel(SpectrumArgs a)
         static_for<0, 16>([&](auto Q) {
             constexpr int q = Q.value;
             const v2f s_ = nxt[q];
-            if (s_.x > 32000.0f) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
+            if (s_.x > refc::FFT_OVER_LIMIT_F) over = 1;                        // OVER_LIMIT, fft.cpp:30,275
             x[bitrev<16>(q)] = v2f{wn[q] * s_.y, wn[q] * s_.x};    // I/Q swapped, fft.cpp:280-281
         });
         if (f + 1 < f1) fetch(f + 1);

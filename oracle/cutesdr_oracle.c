@@ -18,6 +18,105 @@
 static void *zalloc(size_t n) { void *p = calloc(1, n ? n : 1); return p; }
 
 /* ==================================================================================== */
+/* The reference's named constants: every #define of the dsp sources and headers that enters the arithmetic below,
+ * under a name of its own with the file it comes from, and the window coefficients.  The code below uses
+ * these names only; orc_constants() exports the table, and tests/test_reference_constants.py (build
+ * container only -- /root/reference never travels) compares every value with the reference's TEXT.       */
+/* ==================================================================================== */
+#define AGC_DELAY_TIMECONST .015            /* agc.cpp:50 DELAY_TIMECONST */
+#define AGC_WINDOW_TIMECONST .018           /* agc.cpp:53 */
+#define AGC_ATTACK_RISE_TIMECONST .002      /* agc.cpp:57 */
+#define AGC_ATTACK_FALL_TIMECONST .005      /* agc.cpp:58 */
+#define AGC_DECAY_RISEFALL_RATIO .3         /* agc.cpp:60 */
+#define AGC_RELEASE_TIMECONST .05           /* agc.cpp:64 */
+#define AGC_OUTSCALE 0.7                    /* agc.cpp:67 AGC_OUTSCALE */
+#define AGC_MAX_AMPLITUDE 32767.0           /* agc.cpp:69 */
+#define AGC_MAX_MANUAL_AMPLITUDE 32767.0    /* agc.cpp:70 */
+#define AGC_MIN_CONSTANT 3.2767e-4          /* agc.cpp:72 */
+#define AGC_RING 2048                       /* agc.h:16 MAX_DELAY_BUF */
+#define AM_DC_ALPHA 0.99                    /* amdemod.cpp:44 DC_ALPHA */
+#define DCV_MIN_OUTPUT_RATE (7900.0 * 2.0)  /* downconvert.cpp:52 */
+#define DC_HB_SCRATCH 32768                 /* downconvert.cpp:54 MAX_HALF_BAND_BUFSIZE */
+#define DC_MAX_STAGES 9                     /* downconvert.h:18 MAX_DECSTAGES - 1 (one null at the end of the list) */
+#define FF_WIN_A0 0.3635819                 /* fastfir.cpp:95-98: Blackman-Nuttall */
+#define FF_WIN_A1 0.4891775
+#define FF_WIN_A2 0.1365995
+#define FF_WIN_A3 0.0106411
+#define FFT_K_AMPMAX 32767.0                /* fft.cpp:19 */
+#define FFT_K_MAXDB 0.0                     /* fft.cpp:20 */
+#define FFT_K_MINDB -220.0                  /* fft.cpp:21 */
+#define FFT_OVER_LIMIT 32000.0              /* fft.cpp:23 */
+#define FFT_MAX_SIZE 65536                  /* fft.h:21 */
+#define FFT_MIN_SIZE 512                    /* fft.h:22 */
+#define FIR_MAX 75                          /* fir.h:16 MAX_NUMCOEF */
+#define FM_PLL_RANGE 6000.0                 /* fmdemod.cpp:45 FMPLL_RANGE */
+#define FM_VOICE_BANDWIDTH 3000.0           /* fmdemod.cpp:46 */
+#define FM_PLL_BW FM_VOICE_BANDWIDTH * 2.0  /* fmdemod.cpp:48 FMPLL_BW (no parentheses there either) */
+#define FM_PLL_ZETA .707                    /* fmdemod.cpp:49 */
+#define FM_DC_ALPHA 0.01                    /* fmdemod.cpp:51 FMDC_ALPHA */
+#define FM_MAX_OUT 25000.0                  /* fmdemod.cpp:53 MAX_FMOUT */
+#define FM_SQUELCH_MAX 5000.0               /* fmdemod.cpp:55 */
+#define FM_SQUELCHAVE_TIMECONST .02         /* fmdemod.cpp:56 */
+#define FM_SQUELCH_HYSTERESIS 100.0         /* fmdemod.cpp:57 */
+#define FM_SQBUF 16384                      /* fmdemod.h:14 MAX_SQBUF_SIZE */
+#define RS_PTS 10000                        /* fractresampler.cpp:50 SINC_PERIOD_PTS */
+#define RS_PERIODS 28                       /* fractresampler.cpp:53 SINC_PERIODS */
+#define RS_LEN (RS_PERIODS * RS_PTS + 1)    /* fractresampler.cpp:57 SINC_LENGTH */
+#define RS_MAX_SOUNDCARDVAL 32767.0         /* fractresampler.cpp:59 */
+#define RS_WIN_A0 0.35875                   /* fractresampler.cpp:102-105: Blackman-Harris */
+#define RS_WIN_A1 0.48829
+#define RS_WIN_A2 0.14128
+#define RS_WIN_A3 0.01168
+#define NB_MAX_WIDTH 4096                   /* noiseproc.cpp:49 */
+#define NB_MAX_DELAY 4096                   /* noiseproc.cpp:50 */
+#define NB_MAX_AVE 32768                    /* noiseproc.cpp:51 */
+#define NB_MAGAVE_TIME 0.005                /* noiseproc.cpp:53 */
+#define SAM_DC_ALPHA 0.99                   /* samdemod.cpp:45 DC_ALPHA */
+#define SAM_PLL_BW 100.0                    /* samdemod.cpp:47 */
+#define SAM_PLL_ZETA .707                   /* samdemod.cpp:48 */
+#define SAM_PLL_LIMIT 1000.0                /* samdemod.cpp:49 */
+#define SM_ATTACK_TIMECONST .01             /* smeter.cpp:42 */
+#define SM_DECAY_TIMECONST .5               /* smeter.cpp:43 */
+#define SM_CALIBRATION 5.0                  /* smeter.cpp:45 SMETER_CALIBRATION */
+#define SM_MAX_PWR (32767.0 * 32767.0)      /* smeter.cpp:47 */
+#define DEMOD_BUF 250000                    /* demodulator.h:30 MAX_INBUFSIZE */
+
+/* name = "<reference file>:<its #define>" (window coefficients: "<file>:WIN_A<k>"), value as used below */
+int orc_constants(const char **names, double *values, int cap)
+{
+    static const struct { const char *name; double value; } tab[] = {
+        {"agc.cpp:DELAY_TIMECONST", AGC_DELAY_TIMECONST}, {"agc.cpp:WINDOW_TIMECONST", AGC_WINDOW_TIMECONST},
+        {"agc.cpp:ATTACK_RISE_TIMECONST", AGC_ATTACK_RISE_TIMECONST}, {"agc.cpp:ATTACK_FALL_TIMECONST", AGC_ATTACK_FALL_TIMECONST},
+        {"agc.cpp:DECAY_RISEFALL_RATIO", AGC_DECAY_RISEFALL_RATIO}, {"agc.cpp:RELEASE_TIMECONST", AGC_RELEASE_TIMECONST},
+        {"agc.cpp:AGC_OUTSCALE", AGC_OUTSCALE}, {"agc.cpp:MAX_AMPLITUDE", AGC_MAX_AMPLITUDE},
+        {"agc.cpp:MAX_MANUAL_AMPLITUDE", AGC_MAX_MANUAL_AMPLITUDE}, {"agc.cpp:MIN_CONSTANT", AGC_MIN_CONSTANT},
+        {"agc.h:MAX_DELAY_BUF", AGC_RING}, {"amdemod.cpp:DC_ALPHA", AM_DC_ALPHA},
+        {"downconvert.cpp:MIN_OUTPUT_RATE", DCV_MIN_OUTPUT_RATE}, {"downconvert.cpp:MAX_HALF_BAND_BUFSIZE", DC_HB_SCRATCH},
+        {"downconvert.h:MAX_DECSTAGES", DC_MAX_STAGES + 1},
+        {"fastfir.cpp:WIN_A0", FF_WIN_A0}, {"fastfir.cpp:WIN_A1", FF_WIN_A1}, {"fastfir.cpp:WIN_A2", FF_WIN_A2}, {"fastfir.cpp:WIN_A3", FF_WIN_A3},
+        {"fft.cpp:K_AMPMAX", FFT_K_AMPMAX}, {"fft.cpp:K_MAXDB", FFT_K_MAXDB}, {"fft.cpp:K_MINDB", FFT_K_MINDB}, {"fft.cpp:OVER_LIMIT", FFT_OVER_LIMIT},
+        {"fft.h:MAX_FFT_SIZE", FFT_MAX_SIZE}, {"fft.h:MIN_FFT_SIZE", FFT_MIN_SIZE}, {"fir.h:MAX_NUMCOEF", FIR_MAX},
+        {"fmdemod.cpp:FMPLL_RANGE", FM_PLL_RANGE}, {"fmdemod.cpp:VOICE_BANDWIDTH", FM_VOICE_BANDWIDTH}, {"fmdemod.cpp:FMPLL_BW", FM_PLL_BW},
+        {"fmdemod.cpp:FMPLL_ZETA", FM_PLL_ZETA}, {"fmdemod.cpp:FMDC_ALPHA", FM_DC_ALPHA}, {"fmdemod.cpp:MAX_FMOUT", FM_MAX_OUT},
+        {"fmdemod.cpp:SQUELCH_MAX", FM_SQUELCH_MAX}, {"fmdemod.cpp:SQUELCHAVE_TIMECONST", FM_SQUELCHAVE_TIMECONST},
+        {"fmdemod.cpp:SQUELCH_HYSTERESIS", FM_SQUELCH_HYSTERESIS}, {"fmdemod.h:MAX_SQBUF_SIZE", FM_SQBUF},
+        {"fractresampler.cpp:SINC_PERIOD_PTS", RS_PTS}, {"fractresampler.cpp:SINC_PERIODS", RS_PERIODS}, {"fractresampler.cpp:SINC_LENGTH", RS_LEN},
+        {"fractresampler.cpp:MAX_SOUNDCARDVAL", RS_MAX_SOUNDCARDVAL},
+        {"fractresampler.cpp:WIN_A0", RS_WIN_A0}, {"fractresampler.cpp:WIN_A1", RS_WIN_A1}, {"fractresampler.cpp:WIN_A2", RS_WIN_A2}, {"fractresampler.cpp:WIN_A3", RS_WIN_A3},
+        {"noiseproc.cpp:MAX_WIDTH", NB_MAX_WIDTH}, {"noiseproc.cpp:MAX_DELAY", NB_MAX_DELAY}, {"noiseproc.cpp:MAX_AVE", NB_MAX_AVE},
+        {"noiseproc.cpp:MAGAVE_TIME", NB_MAGAVE_TIME},
+        {"samdemod.cpp:DC_ALPHA", SAM_DC_ALPHA}, {"samdemod.cpp:PLL_BW", SAM_PLL_BW}, {"samdemod.cpp:PLL_ZETA", SAM_PLL_ZETA}, {"samdemod.cpp:PLL_LIMIT", SAM_PLL_LIMIT},
+        {"smeter.cpp:ATTACK_TIMECONST", SM_ATTACK_TIMECONST}, {"smeter.cpp:DECAY_TIMECONST", SM_DECAY_TIMECONST},
+        {"smeter.cpp:SMETER_CALIBRATION", SM_CALIBRATION}, {"smeter.cpp:MAX_PWR", SM_MAX_PWR},
+        {"demodulator.h:MAX_INBUFSIZE", DEMOD_BUF}, {"datatypes.h:K_2PI", TWO_PI}, {"datatypes.h:K_PI", ONE_PI},
+    };
+    const int n = (int)(sizeof(tab) / sizeof(tab[0]));
+    int i;
+    for (i = 0; i < n && i < cap; i++) { names[i] = tab[i].name; values[i] = tab[i].value; }
+    return n;
+}
+
+/* ==================================================================================== */
 /* FFT: plain iterative radix-2, same transform as the reference's Ooura cdft           */
 /* (dsp/fft.cpp:416-426: isgn=+1 forward has the POSITIVE exponent, no scaling).        */
 /* ==================================================================================== */
@@ -117,8 +216,8 @@ void orc_cfft_set_params(orc_cfft *f, int size, int invert, double db_comp, doub
     f->invert = invert;
     f->fs = fs;
     if (f->db_comp != db_comp) { f->last_size = 0; f->db_comp = db_comp; }
-    if (size < 512) f->size = 512;
-    else if (size > 65536) f->size = 65536;
+    if (size < FFT_MIN_SIZE) f->size = FFT_MIN_SIZE;
+    else if (size > FFT_MAX_SIZE) f->size = FFT_MAX_SIZE;
     else f->size = size;
     if (f->last_size != f->size) {
         int n = f->size;
@@ -130,8 +229,8 @@ void orc_cfft_set_params(orc_cfft *f, int size, int invert, double db_comp, doub
         f->sum = (double *)zalloc(sizeof(double) * n);
         f->work = (orc_cpx *)zalloc(sizeof(orc_cpx) * n);
         f->xlat = (int *)zalloc(sizeof(int) * n);
-        f->kb = f->db_comp - 20 * log10((double)n * 32767.0 / 2.0);
-        f->kc = pow(10.0, (-220.0 - f->kb) / 10.0);
+        f->kb = f->db_comp - 20 * log10((double)n * FFT_K_AMPMAX / 2.0);
+        f->kc = pow(10.0, (FFT_K_MINDB - f->kb) / 10.0);
         f->kb = f->kb / 10.0;
         for (i = 0; i < n; i++)
             f->win[i] = 2.0 * (.5 - .5 * cos((TWO_PI * i) / (n - 1)));
@@ -191,7 +290,7 @@ int orc_cfft_put_display(orc_cfft *f, int n, const orc_cpx *in)
     int i;
     f->overload = 0;
     for (i = 0; i < n; i++) {
-        if (in[i].re > 32000.0) f->overload = 1;
+        if (in[i].re > FFT_OVER_LIMIT) f->overload = 1;
         f->work[i].im = f->win[i] * in[i].re;
         f->work[i].re = f->win[i] * in[i].im;
     }
@@ -305,10 +404,10 @@ orc_fastfir *orc_fastfir_new(int fft_size)
     f->ovl = (orc_cpx *)zalloc(sizeof(orc_cpx) * f->p);
     f->pos = f->p - 1;
     for (i = 0; i < f->p; i++)      /* Blackman-Nuttall, :93-101 */
-        f->win[i] = 0.3635819
-                  - 0.4891775 * cos((TWO_PI * i) / (f->p - 1))
-                  + 0.1365995 * cos((2.0 * TWO_PI * i) / (f->p - 1))
-                  - 0.0106411 * cos((3.0 * TWO_PI * i) / (f->p - 1));
+        f->win[i] = FF_WIN_A0
+                  - FF_WIN_A1 * cos((TWO_PI * i) / (f->p - 1))
+                  + FF_WIN_A2 * cos((2.0 * TWO_PI * i) / (f->p - 1))
+                  - FF_WIN_A3 * cos((3.0 * TWO_PI * i) / (f->p - 1));
     f->flo = -1.0; f->fhi = 1.0; f->off = 1.0; f->fs = 1.0;
     f->side = orc_cfft_new();
     orc_cfft_set_params(f->side, f->n, 0, 0.0, 1.0);
@@ -382,8 +481,6 @@ int orc_fastfir_process(orc_fastfir *f, int n, const orc_cpx *in, orc_cpx *out)
 /* ==================================================================================== */
 /* CDownConvert                                                                          */
 /* ==================================================================================== */
-#define DC_MAX_STAGES 9
-#define DC_HB_SCRATCH 32768        /* MAX_HALF_BAND_BUFSIZE, dsp/downconvert.cpp:54 */
 
 typedef struct {
     int kind;                 /* 3 = CIC3, 11 = unrolled HB11, else generic HB length */
@@ -437,7 +534,7 @@ double orc_downconv_set_data_rate(orc_downconv *d, double in_rate, double max_bw
     if (d->in_rate != in_rate || d->max_bw != max_bw) {
         d->in_rate = in_rate; d->max_bw = max_bw;
         dc_drop_stages(d);
-        while (f > (max_bw / csdr_hb_maxbw[CSDR_HB_NUM_FILTERS - 1]) && f > (7900.0 * 2.0)) {
+        while (f > (max_bw / csdr_hb_maxbw[CSDR_HB_NUM_FILTERS - 1]) && f > DCV_MIN_OUTPUT_RATE) {
             dc_stage *s;
             int k;
             if (d->nstages >= DC_MAX_STAGES) break;   /* reference: unchecked (downconvert.h:18) */
@@ -560,7 +657,6 @@ int orc_downconv_process(orc_downconv *d, int n, orc_cpx *in, orc_cpx *out)
 /* ==================================================================================== */
 /* CFir                                                                                   */
 /* ==================================================================================== */
-#define FIR_MAX 75
 struct orc_fir {
     double fs;
     int ntaps, state;
@@ -768,7 +864,6 @@ void orc_iir_process_cpx(orc_iir *f, int n, const orc_cpx *in, orc_cpx *out)
 /* ==================================================================================== */
 /* CAgc (dsp/agc.cpp)                                                                    */
 /* ==================================================================================== */
-#define AGC_RING 2048
 struct orc_agc {
     int on, hang, thresh, manual, decay;
     double slope_factor;               /* TYPEREAL compared against int, agc.cpp:109 */
@@ -804,18 +899,18 @@ void orc_agc_set(orc_agc *a, int on, int hang, int thresh, int manual_gain, int 
         a->peak = -16.0; a->decay_ave = -5.0; a->attack_ave = -5.0;
         a->mag_pos = 0;
     }
-    a->manual_gain = 32767.0 * pow(10.0, -(100 - (double)a->manual) / 20.0);
+    a->manual_gain = AGC_MAX_MANUAL_AMPLITUDE * pow(10.0, -(100 - (double)a->manual) / 20.0);
     a->knee = (double)a->thresh / 20.0;
     a->gain_slope = a->slope_factor / (100.0);
-    a->fixed_gain = 0.7 * pow(10.0, a->knee * (a->gain_slope - 1.0));
-    a->att_rise = (1.0 - exp(-1.0 / (a->fs * .002)));
-    a->att_fall = (1.0 - exp(-1.0 / (a->fs * .005)));
-    a->dec_rise = (1.0 - exp(-1.0 / (a->fs * (double)a->decay * .001 * .3)));
+    a->fixed_gain = AGC_OUTSCALE * pow(10.0, a->knee * (a->gain_slope - 1.0));
+    a->att_rise = (1.0 - exp(-1.0 / (a->fs * AGC_ATTACK_RISE_TIMECONST)));
+    a->att_fall = (1.0 - exp(-1.0 / (a->fs * AGC_ATTACK_FALL_TIMECONST)));
+    a->dec_rise = (1.0 - exp(-1.0 / (a->fs * (double)a->decay * .001 * AGC_DECAY_RISEFALL_RATIO)));
     a->hang_time = (int)(a->fs * (double)a->decay * .001);
-    if (a->hang) a->dec_fall = (1.0 - exp(-1.0 / (a->fs * .05)));
+    if (a->hang) a->dec_fall = (1.0 - exp(-1.0 / (a->fs * AGC_RELEASE_TIMECONST)));
     else         a->dec_fall = (1.0 - exp(-1.0 / (a->fs * (double)a->decay * .001)));
-    a->dly_n = (int)(a->fs * .015);
-    a->win_n = (int)(a->fs * .018);
+    a->dly_n = (int)(a->fs * AGC_DELAY_TIMECONST);
+    a->win_n = (int)(a->fs * AGC_WINDOW_TIMECONST);
     if (a->dly_n >= AGC_RING - 1) a->dly_n = AGC_RING - 1;
     /* window is NOT clamped in the reference (App. A.6); stay below 113.7 kS/s */
 }
@@ -851,7 +946,7 @@ static double agc_track(orc_agc *a, double mag)
     }
     mag = a->attack_ave > a->decay_ave ? a->attack_ave : a->decay_ave;
     if (mag <= a->knee) return a->fixed_gain;
-    return 0.7 * pow(10.0, mag * (a->gain_slope - 1.0));
+    return AGC_OUTSCALE * pow(10.0, mag * (a->gain_slope - 1.0));
 }
 
 /* dsp/agc.cpp:174-296 */
@@ -868,7 +963,7 @@ void orc_agc_process_cpx(orc_agc *a, int n, const orc_cpx *in, orc_cpx *out)
         a->dly[a->dly_pos++] = x;
         if (a->dly_pos >= a->dly_n) a->dly_pos = 0;
         if (mim > mag) mag = mim;
-        mag = log10(mag + 3.2767e-4) - log10(32767.0);
+        mag = log10(mag + AGC_MIN_CONSTANT) - log10(AGC_MAX_AMPLITUDE);
         g = agc_track(a, mag);
         out[i].re = delayed.re * g;
         out[i].im = delayed.im * g;
@@ -883,7 +978,7 @@ void orc_agc_process_real(orc_agc *a, int n, const double *in, double *out)
         double x = in[i], delayed = a->dly[a->dly_pos].re, g;
         a->dly[a->dly_pos++].re = x;
         if (a->dly_pos >= a->dly_n) a->dly_pos = 0;
-        g = agc_track(a, log10(fabs(x) + 3.2767e-4) - log10(32767.0));
+        g = agc_track(a, log10(fabs(x) + AGC_MIN_CONSTANT) - log10(AGC_MAX_AMPLITUDE));
         out[i] = delayed * g;
     }
 }
@@ -905,11 +1000,11 @@ void orc_smeter_process(orc_smeter *s, int n, const orc_cpx *in, double fs)
     int i;
     if (fs != s->fs) {
         s->fs = fs;
-        s->att_a = (1.0 - exp(-1.0 / (fs * .01)));
-        s->dec_a = (1.0 - exp(-1.0 / (fs * .5)));
+        s->att_a = (1.0 - exp(-1.0 / (fs * SM_ATTACK_TIMECONST)));
+        s->dec_a = (1.0 - exp(-1.0 / (fs * SM_DECAY_TIMECONST)));
     }
     for (i = 0; i < n; i++) {
-        double mag = 10.0 * log10((in[i].re * in[i].re + in[i].im * in[i].im) / (32767.0 * 32767.0) + 1e-50);
+        double mag = 10.0 * log10((in[i].re * in[i].re + in[i].im * in[i].im) / SM_MAX_PWR + 1e-50);
         s->att_ave = (1.0 - s->att_a) * s->att_ave + s->att_a * mag;
         s->dec_ave = (1.0 - s->dec_a) * s->dec_ave + s->dec_a * mag;
         if (s->att_ave > s->dec_ave) { s->ave_mag = s->att_ave; s->dec_ave = s->att_ave; }
@@ -917,8 +1012,8 @@ void orc_smeter_process(orc_smeter *s, int n, const orc_cpx *in, double fs)
         if (mag > s->peak_mag) s->peak_mag = mag;
     }
 }
-double orc_smeter_peak(orc_smeter *s) { double x = s->peak_mag; s->peak_mag = 0; return x + 5.0; }
-double orc_smeter_ave(orc_smeter *s) { return s->ave_mag + 5.0; }
+double orc_smeter_peak(orc_smeter *s) { double x = s->peak_mag; s->peak_mag = 0; return x + SM_CALIBRATION; }
+double orc_smeter_ave(orc_smeter *s) { return s->ave_mag + SM_CALIBRATION; }
 
 /* ==================================================================================== */
 /* AM (dsp/amdemod.cpp)                                                                   */
@@ -937,7 +1032,7 @@ void orc_amdemod_set_bandwidth(orc_amdemod *d, double bw)
 static double am_env(orc_amdemod *d, orc_cpx x)
 {   /* envelope then H(z)=(1-z^-1)/(1-.99 z^-1), amdemod.cpp:70-80 */
     double mag = sqrt(x.re * x.re + x.im * x.im);
-    double z0 = mag + (d->z1 * 0.99), y = z0 - d->z1;
+    double z0 = mag + (d->z1 * AM_DC_ALPHA), y = z0 - d->z1;
     d->z1 = z0;
     return y;
 }
@@ -968,9 +1063,9 @@ orc_samdemod *orc_samdemod_new(double fs)
     orc_samdemod *d = (orc_samdemod *)zalloc(sizeof(*d));
     double norm = TWO_PI / fs;
     d->fs = fs;
-    d->lo = -1000.0 * norm; d->hi = 1000.0 * norm;
-    d->alpha = 2.0 * .707 * 100.0 * norm;
-    d->beta = (d->alpha * d->alpha) / (4.0 * .707 * .707);
+    d->lo = -SAM_PLL_LIMIT * norm; d->hi = SAM_PLL_LIMIT * norm;
+    d->alpha = 2.0 * SAM_PLL_ZETA * SAM_PLL_BW * norm;
+    d->beta = (d->alpha * d->alpha) / (4.0 * SAM_PLL_ZETA * SAM_PLL_ZETA);
     d->fir = orc_fir_new();
     orc_fir_init_lp(d->fir, 1.0, 40.0, 4500, 5500, fs);
     orc_fir_gen_hilbert(d->fir, 5000.0);
@@ -995,7 +1090,7 @@ int orc_samdemod_process_mono(orc_samdemod *d, int n, const orc_cpx *in, double 
     int i;
     for (i = 0; i < n; i++) {
         orc_cpx t = sam_pll(d, in[i], -1.0);
-        double z0 = t.re + (d->z1 * 0.99);
+        double z0 = t.re + (d->z1 * SAM_DC_ALPHA);
         out[i] = (z0 - d->z1);
         d->z1 = z0;
     }
@@ -1007,7 +1102,7 @@ int orc_samdemod_process_stereo(orc_samdemod *d, int n, const orc_cpx *in, orc_c
     int i;
     for (i = 0; i < n; i++) {
         orc_cpx t = sam_pll(d, in[i], +1.0);
-        double z0 = t.re + (d->z1 * 0.99), y0 = t.im + (d->y1 * 0.99);
+        double z0 = t.re + (d->z1 * SAM_DC_ALPHA), y0 = t.im + (d->y1 * SAM_DC_ALPHA);
         out[i].re = (z0 - d->z1);
         out[i].im = (y0 - d->y1);
         d->y1 = y0; d->z1 = z0;
@@ -1025,7 +1120,6 @@ int orc_samdemod_process_stereo(orc_samdemod *d, int n, const orc_cpx *in, orc_c
 /* ==================================================================================== */
 /* NBFM (dsp/fmdemod.cpp)                                                                 */
 /* ==================================================================================== */
-#define FM_SQBUF 16384
 struct orc_fmdemod {
     int squelched;
     double fs, hp_freq, out_gain, err_dc, dc_alpha, phase, freq, lo, hi, alpha, beta;
@@ -1040,22 +1134,22 @@ orc_fmdemod *orc_fmdemod_new(double fs)
     orc_fmdemod *d = (orc_fmdemod *)zalloc(sizeof(*d));
     double norm = TWO_PI / fs;
     d->fs = fs;
-    d->lo = -6000.0 * norm; d->hi = 6000.0 * norm;
-    d->alpha = 2.0 * .707 * 3000.0 * 2.0 * norm;
-    d->beta = (d->alpha * d->alpha) / (4.0 * .707 * .707);
-    d->out_gain = 25000.0 / d->hi;
-    d->dc_alpha = (1.0 - exp(-1.0 / (fs * 0.01)));
-    d->hp_freq = 3000.0;
+    d->lo = -FM_PLL_RANGE * norm; d->hi = FM_PLL_RANGE * norm;
+    d->alpha = 2.0 * FM_PLL_ZETA * FM_PLL_BW * norm;
+    d->beta = (d->alpha * d->alpha) / (4.0 * FM_PLL_ZETA * FM_PLL_ZETA);
+    d->out_gain = FM_MAX_OUT / d->hi;
+    d->dc_alpha = (1.0 - exp(-1.0 / (fs * FM_DC_ALPHA)));
+    d->hp_freq = FM_VOICE_BANDWIDTH;
     d->sq_ave = 0.0; d->squelched = 1;
-    d->sq_alpha = (1.0 - exp(-1.0 / (fs * .02)));
+    d->sq_alpha = (1.0 - exp(-1.0 / (fs * FM_SQUELCHAVE_TIMECONST)));
     d->hp = orc_fir_new(); d->lp = orc_iir_new();
-    orc_iir_init(d->lp, 0, 3000.0, 1.0, fs);
+    orc_iir_init(d->lp, 0, FM_VOICE_BANDWIDTH, 1.0, fs);
     fm_init_squelch(d);
     return d;
 }
 void orc_fmdemod_free(orc_fmdemod *d) { if (d) { orc_fir_free(d->hp); orc_iir_free(d->lp); free(d); } }
 void orc_fmdemod_set_squelch(orc_fmdemod *d, int value)
-{ d->sq_thresh = (double)(5000.0 - ((5000.0 * value) / 99)); }    /* :95-98 */
+{ d->sq_thresh = (double)(FM_SQUELCH_MAX - ((FM_SQUELCH_MAX * value) / 99)); }    /* :95-98 */
 int orc_fmdemod_squelched(const orc_fmdemod *d) { return d->squelched; }
 
 /* :113-152: one hysteresis decision per call, after the whole block's EMA */
@@ -1067,8 +1161,8 @@ static void fm_squelch(orc_fmdemod *d, int n, double *audio)
     for (i = 0; i < n; i++)
         d->sq_ave = (1.0 - d->sq_alpha) * d->sq_ave + d->sq_alpha * fabs(d->sq[i]);
     if (0 == d->sq_thresh) d->squelched = 1;
-    else if (d->squelched) { if (d->sq_ave < (d->sq_thresh - 100.0)) d->squelched = 0; }
-    else { if (d->sq_ave >= (d->sq_thresh + 100.0)) d->squelched = 1; }
+    else if (d->squelched) { if (d->sq_ave < (d->sq_thresh - FM_SQUELCH_HYSTERESIS)) d->squelched = 0; }
+    else { if (d->sq_ave >= (d->sq_thresh + FM_SQUELCH_HYSTERESIS)) d->squelched = 1; }
     if (d->squelched) for (i = 0; i < n; i++) audio[i] = 0.0;
     else orc_iir_process_real(d->lp, n, audio, audio);
 }
@@ -1115,9 +1209,6 @@ int orc_ssbdemod_process_stereo(int n, const orc_cpx *in, orc_cpx *out)
 /* ==================================================================================== */
 /* CFractResampler (dsp/fractresampler.cpp)                                               */
 /* ==================================================================================== */
-#define RS_PTS 10000
-#define RS_PERIODS 28
-#define RS_LEN (RS_PERIODS * RS_PTS + 1)
 struct orc_resampler { double t; double *sinc; orc_cpx *buf; int cap; };
 orc_resampler *orc_resampler_new(void) { return (orc_resampler *)zalloc(sizeof(orc_resampler)); }
 void orc_resampler_free(orc_resampler *r) { if (r) { free(r->sinc); free(r->buf); free(r); } }
@@ -1130,10 +1221,10 @@ void orc_resampler_init(orc_resampler *r, int max_input)
     r->buf = (orc_cpx *)zalloc(sizeof(orc_cpx) * max_input);
     r->cap = max_input;
     for (i = 0; i < RS_LEN; i++) {
-        double w = 0.35875
-                 - 0.48829 * cos((TWO_PI * i) / (RS_LEN - 1))
-                 + 0.14128 * cos((2.0 * TWO_PI * i) / (RS_LEN - 1))
-                 - 0.01168 * cos((3.0 * TWO_PI * i) / (RS_LEN - 1));
+        double w = RS_WIN_A0
+                 - RS_WIN_A1 * cos((TWO_PI * i) / (RS_LEN - 1))
+                 + RS_WIN_A2 * cos((2.0 * TWO_PI * i) / (RS_LEN - 1))
+                 - RS_WIN_A3 * cos((3.0 * TWO_PI * i) / (RS_LEN - 1));
         double fi = ONE_PI * (double)(i - RS_LEN / 2) / (double)RS_PTS;
         r->sinc[i] = (i != RS_LEN / 2) ? w * sin(fi) / fi : 1.0;
     }
@@ -1158,10 +1249,10 @@ static int rs_run(orc_resampler *r, int n, double rate, int is_cpx, const void *
         }
         if (out_i16) {
             double a = ar * gain, b = ai * gain;
-            if (a > 32767.0) a = 32767.0;
-            if (a < -32767.0) a = -32767.0;
-            if (b > 32767.0) b = 32767.0;
-            if (b < -32767.0) b = -32767.0;
+            if (a > RS_MAX_SOUNDCARDVAL) a = RS_MAX_SOUNDCARDVAL;
+            if (a < -RS_MAX_SOUNDCARDVAL) a = -RS_MAX_SOUNDCARDVAL;
+            if (b > RS_MAX_SOUNDCARDVAL) b = RS_MAX_SOUNDCARDVAL;
+            if (b < -RS_MAX_SOUNDCARDVAL) b = -RS_MAX_SOUNDCARDVAL;
             if (is_cpx) { out_i16[2 * nout] = (short)a; out_i16[2 * nout + 1] = (short)b; }
             else out_i16[nout] = (short)a;
         } else if (is_cpx) { out_cpx[nout].re = ar; out_cpx[nout].im = ai; }
@@ -1187,7 +1278,6 @@ int orc_resampler_cpx_i16(orc_resampler *r, int n, double rate, const orc_cpx *i
 /* ==================================================================================== */
 /* CDemodulator (dsp/demodulator.cpp)                                                     */
 /* ==================================================================================== */
-#define DEMOD_BUF 250000
 typedef struct { double *v; int n, cap; } tapvec;
 struct orc_demod {
     orc_downconv *dc; orc_fastfir *ff; orc_agc *agc; orc_smeter *sm;
@@ -1341,9 +1431,6 @@ int orc_demod_process_mono_append(orc_demod *d, int n, const orc_cpx *in, double
 /* ==================================================================================== */
 /* CNoiseProc::ProcessBlanker  (dsp/noiseproc.cpp:78-176)  -- SURVEY 8(f) row f1           */
 /* ==================================================================================== */
-#define NB_MAX_WIDTH 4096      /* noiseproc.cpp:49-51 */
-#define NB_MAX_DELAY 4096
-#define NB_MAX_AVE 32768
 struct orc_noiseproc {
     int on, dptr, mptr, blank, delay_n, mag_n, width_n, configured;
     double thresh, width, fs, ratio, sum;
@@ -1367,7 +1454,7 @@ int orc_noiseproc_setup(orc_noiseproc *p, int on, double thresh, double width, d
     p->width_n = (int)(width * 1e-6 * fs);               /* :92-96 */
     if (p->width_n < 1) p->width_n = 1;
     else if (p->width_n > NB_MAX_WIDTH) p->width_n = NB_MAX_WIDTH;
-    p->mag_n = (int)(0.005 * fs);                        /* MAGAVE_TIME, :98 */
+    p->mag_n = (int)(NB_MAGAVE_TIME * fs);               /* :98 */
     if (p->mag_n > NB_MAX_AVE - 1) return -1;            /* the reference would overrun m_MagBuf here */
     p->ratio = .005 * thresh * (double)p->mag_n;         /* :100 */
     p->delay_n = p->width_n / 2;                         /* :102 */

@@ -27,6 +27,11 @@ extern "C" {
 
 typedef struct { double re, im; } orc_cpx;
 
+/* ---- the reference's named constants as this file USES them ("<reference file>:<its #define>" -> value; the
+ * window coefficients as "<file>:WIN_A<k>").  Fills up to cap entries, returns how many there are.
+ * tests/test_reference_constants.py compares every entry with the reference's text (build container only). */
+int orc_constants(const char **names, double *values, int cap);
+
 /* ---- complex FFT, reference sign conventions (dsp/fft.cpp:416-426) ---------------
  * sign=+1: X[k]=sum x[n] e^{+j2pi nk/N} (CFft::FwdFFT); sign=-1: CFft::RevFFT.
  * Unnormalised, natural order in and out, n a power of two. */

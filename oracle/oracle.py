@@ -31,6 +31,16 @@ def lib():
     return _lib
 
 
+def constants():
+    """{"<reference file>:<#define>": value} as the oracle's arithmetic uses them (orc_constants)"""
+    L = lib()
+    n = L.orc_constants(None, None, 0)
+    names = (C.c_char_p * n)()
+    vals = (C.c_double * n)()
+    L.orc_constants(C.cast(names, C.c_void_p), C.cast(vals, C.c_void_p), n)
+    return {names[i].decode(): float(vals[i]) for i in range(n)}
+
+
 class DemodInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "HiCut", "HiCutmin", "HiCutmax", "LowCut", "LowCutmin", "LowCutmax",
@@ -50,6 +60,7 @@ def _declare(L):
         fn.restype = res
         fn.argtypes = list(args)
     f("orc_fft", None, I, I, P)
+    f("orc_constants", I, P, P, I)
     f("orc_cfft_new", P); f("orc_cfft_free", None, P)
     f("orc_cfft_set_params", None, P, I, I, D, D)
     f("orc_cfft_set_ave", None, P, I); f("orc_cfft_reset", None, P)
