@@ -2,7 +2,7 @@
 // dsp/*.h that enters this library's arithmetic (host set-up math and kernels alike), under a name of its own with the
 // place it comes from, and the window coefficients.  The code uses these names only; csdr__constants() (capi_core.hip)
 // exports the table, and tests/test_reference_constants.py -- build container only, the reference never travels --
-// compares every value with the reference's TEXT (and with the oracle's own table): a constant mistyped in both
+// compares every value with the reference's TEXT (and with the CPU checker's own table): a constant mistyped in both
 // restatements cannot survive that.
 #pragma once
 #include "resampler_kernels.h"      // RS_PTS, RS_PERIODS, RS_LEN (fractresampler.cpp:50-57)
