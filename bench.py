@@ -59,8 +59,16 @@ def dist_init(backend=None):
         # rehearsal of the multi-rank code on a one-GPU box (tests): every rank on cuda:0, collectives over gloo
         ctx.local, backend = 0, "gloo"
         ctx.backend = backend
-    if ctx.world > 1:
+    # CSDR_BENCH_FORCE_DIST=1: a process group even for ONE rank, so that the barrier, the MAX-reduce, the census and the
+    # chain's gather go through the real library (RCCL) on a one-GPU box -- the world == 1 short-cuts are switched off
+    # (tests/test_bench_dist.py::test_one_rank_through_rccl)
+    ctx.dist_on = ctx.world > 1 or bool(os.environ.get("CSDR_BENCH_FORCE_DIST"))
+    if ctx.dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ctx.world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend is None:
             import torch
             ndev = torch.cuda.device_count()
@@ -84,7 +92,7 @@ def rank_census(ctx):
         pr = torch.cuda.get_device_properties(ctx.local)
         me.update(device=ctx.local, name=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None),
                   uuid=str(getattr(pr, "uuid", "")) or None)
-    if ctx.world == 1:
+    if not getattr(ctx, "dist_on", ctx.world > 1):
         return {"backend": None, "world_size": 1, "ranks": [me]}
     everyone = [None] * ctx.world
     ctx.dist.all_gather_object(everyone, me)
@@ -98,12 +106,12 @@ def shard_channels(ctx, total_channels):
 
 
 def dist_barrier(ctx):
-    if ctx.world > 1:
+    if getattr(ctx, "dist_on", ctx.world > 1):
         ctx.dist.barrier()
 
 
 def dist_max(ctx, value):
-    if ctx.world == 1:
+    if not getattr(ctx, "dist_on", ctx.world > 1):
         return float(value)
     import torch
     dev = torch.device("cuda", ctx.local) if ctx.backend == "nccl" else torch.device("cpu")
@@ -113,7 +121,7 @@ def dist_max(ctx, value):
 
 
 def dist_finish(ctx):
-    if ctx.world > 1:
+    if getattr(ctx, "dist_on", ctx.world > 1):
         ctx.dist.destroy_process_group()
 
 
@@ -200,9 +208,70 @@ def result_line(ctx, channels, samples, steps, warmup, elapsed, kern_ms, traffic
         "roofline": roofline_obj(alg / (kern_ms * 1e-3) / 1e9, kern_ms, kernel, alg, traffic),
         "cpu_baseline": cpu,
     }
+    line["roofline"]["frac_of_measured_copy"] = round(alg / (kern_ms * 1e-3) / 1e9 / COPY_MEASURED_GBS, 4)
     if extra:
+        pc = extra.pop("power_clock", None)
+        if pc:                                            # socket power / shader clock while the headline launch repeats
+            line["roofline"].update({k: pc[k] for k in ("power_w", "sclk_ghz") if k in pc})
+            line["roofline"]["power_source"] = pc.get("power_source")
+        others, secondary = condensed(extra)
+        if others:
+            line["roofline"]["others"] = others           # scalars only: the driver keeps `roofline` and `config` whole
+        if secondary:
+            line["config"]["secondary"] = secondary
         line.update(extra)
     return line
+
+
+COPY_MEASURED_GBS = 6300.0        # what a device-to-device copy reaches on this part: the practical ceiling
+
+
+def condensed(extra):
+    """The secondary measurements as SCALARS under the keys the driver's record keeps (`roofline`, `config`): every
+    other top-level object of the line is preserved only as far as the tail of stdout reaches.  -> (others, secondary)"""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    def roof(obj, ms_key="ms_per_launch"):
+        if not obj:
+            return None
+        r = {"ms": g(obj, ms_key), "frac": g(obj, "roofline", "frac"), "traffic_over_algorithmic": g(obj, "roofline", "traffic_over_algorithmic"),
+             "parity_ok": g(obj, "parity_checked", "ok")}
+        return {k: v for k, v in r.items() if v is not None}
+    others = {}
+    c4 = extra.get("chain_c4")
+    if c4:
+        others["chain_c4_strict"] = {k: v for k, v in {
+            "ms": g(c4, "strict", "ms_per_step"), "event_ms": g(c4, "strict", "event_ms_per_step"), "frac": g(c4, "strict", "frac_of_hbm_peak"),
+            "traffic_over_algorithmic": g(c4, "roofline", "traffic_over_algorithmic"), "parity_ok": g(c4, "parity_checked", "ok")}.items() if v is not None}
+        others["chain_c4_pipelined"] = {"ms": g(c4, "ms_per_step"), "frac": g(c4, "frac_of_hbm_peak")}
+    for key, name in (("downconv_k2", "downconv_k2"), ("spectrum_c1", "spectrum_c1"), ("blanker_k6", "blanker_k6")):
+        if extra.get(key):
+            others[name] = roof(extra[key])
+    mk = g(extra, "packets_chain", "mask_kernel")
+    if mk:
+        others["mask_kernel"] = roof(mk)
+    for size in ("2048", "4096", "8192"):
+        o = g(extra, "fastfir_sizes", "fastfir", size)
+        if o:
+            others["fastfir_" + size] = {"ms": o.get("ms"), "frac": o.get("frac"), "parity_ok": g(o, "parity_checked", "ok")}
+    for size in ("8192", "16384"):
+        o = g(extra, "fastfir_sizes", "spectrum", size)
+        if o:
+            others["spectrum_" + size] = {"ms": o.get("ms"), "frac": o.get("frac"), "parity_ok": g(o, "parity_checked", "ok")}
+    sec = {"host_form_MSps": g(extra, "host_form", "raw_input_MSamples_per_s"), "host_form_parity_ok": g(extra, "host_form", "parity_checked", "ok"),
+           "chain_c2_ms": g(extra, "chain_c2", "ms_per_call"), "chain_c2_parity_ok": g(extra, "chain_c2", "parity_checked", "ok"),
+           "chain_c5_ms": g(extra, "chain_c5", "ms_per_call"), "chain_c5_parity_ok": g(extra, "chain_c5", "parity_checked", "ok"),
+           "packets_chain_ms": g(extra, "packets_chain", "packets_chain_ms"),
+           "packets_blanker_chain_ms": g(extra, "packets_chain", "packets_blanker_chain_ms"),
+           "packets16_blanker_chain_ms": g(extra, "packets_chain", "packets16_blanker_chain_ms"),
+           "packets_parity_ok": g(extra, "packets_chain", "parity_checked", "ok"),
+           "retune_us": g(extra, "control_plane", "retune_us"), "retune_step_increase_ms": g(extra, "control_plane", "step_increase_ms"),
+           "retune_parity_ok": g(extra, "control_plane", "parity_ok")}
+    return others, {k: v for k, v in sec.items() if v is not None}
 
 
 def k1_source_hash():
@@ -867,6 +936,76 @@ def timed_steps(torch, ctx, step, steps, warmup, prewarm=True):
     return elapsed, sum(a.elapsed_time(b) for a, b in ev) / steps
 
 
+def _read_power_w():
+    """socket power in watts: the amdgpu hwmon node (no process started), else one rocm-smi call"""
+    import glob
+    for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+        for f in sorted(glob.glob(pat)):
+            try:
+                v = float(open(f).read().strip()) * 1e-6
+                if v > 1.0:
+                    return v, "hwmon"
+            except (OSError, ValueError):
+                pass
+    try:
+        import re
+        out = subprocess.run(["rocm-smi", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        for card in json.loads(out).values():
+            for k, v in card.items():
+                if "ower" in k:
+                    m = re.search(r"[0-9.]+", str(v))
+                    if m:
+                        return float(m.group(0)), "rocm-smi"
+    except Exception:
+        pass
+    return None, None
+
+
+def power_and_clock(torch, ca, ctx, step, seconds=1.5):
+    """Socket power and the shader clock the chip holds WHILE the headline launch repeats (after the timed region, never
+    inside it): the kernel sits at the socket's power cap, so a box that lands under the target says why in
+    its own record.  Clock: one-wave probes (csdr__clock_probe: shader cycles per 100 MHz tick) on a side stream beside
+    the launches; power: the hwmon node read every 20 ms (or rocm-smi)."""
+    import ctypes as C
+    import threading
+    L = ca.lib()
+    L.csdr__clock_probe.restype = C.c_int
+    L.csdr__clock_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    side = torch.cuda.Stream()
+    nwg, rounds = 8, []
+    samples, src, stop = [], [None], [False]
+
+    def sampler():
+        while not stop[0]:
+            v, how = _read_power_w()
+            if v is not None:
+                samples.append(v); src[0] = how
+            time.sleep(0.02 if how == "hwmon" else 0.2)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        buf = torch.zeros((2 * nwg,), device="cuda", dtype=torch.int64)
+        for i in range(60):
+            step()
+            if i == 30 and L.csdr__clock_probe(ctx.local, C.c_void_p(side.cuda_stream), C.c_void_p(buf.data_ptr()), nwg, 2000) != 0:
+                break
+        torch.cuda.synchronize()
+        rounds.append(buf.cpu().numpy().reshape(nwg, 2).astype(float))
+    stop[0] = True
+    th.join(timeout=2.0)
+    import numpy as np
+    clk = None
+    if rounds:
+        a = np.concatenate(rounds[1:] or rounds)
+        ok = a[:, 1] > 0
+        if ok.any():
+            clk = float(np.median(a[ok, 0] / a[ok, 1])) * 0.1          # cycles per 10 ns tick -> GHz
+    tail = samples[len(samples) // 3:]
+    return {"power_w": round(sum(tail) / len(tail), 1) if tail else None, "power_source": src[0], "power_samples": len(tail),
+            "sclk_ghz": None if clk is None else round(clk, 3)}
+
+
 # ---------------------------------------------------------------- workloads
 class C3Workload:
     """256 channels x 2^19 samples through the 16384-pt overlap-save filter, all resident in HBM."""
@@ -1068,7 +1207,7 @@ class C4Workload:
             payload[:, 1:] = self.aud[:, :n_aud]
         pack()
         torch.cuda.synchronize()
-        if ctx.world == 1:
+        if not getattr(ctx, "dist_on", ctx.world > 1):
             return {"ms": None, "bytes_to_rank0": 0, "note": "single rank: nothing to gather",
                     "smeter_db_first4": [round(float(v), 2) for v in self.sm[:4].cpu()]}
         on_gpu = ctx.backend == "nccl"                            # (gloo rehearsal: through host memory)
@@ -1095,6 +1234,7 @@ class C4Workload:
         ms = dist_max(ctx, time.perf_counter() - t0) / reps * 1e3
         nbytes = payload.numel() * 4 * (ctx.world - 1)
         return {"ms": round(ms, 3), "bytes_to_rank0": nbytes, "GBps_into_rank0": round(nbytes / ms / 1e6, 1),
+                "backend": ctx.dist.get_backend(), "messages_per_step": len(parts),
                 "collective": "torch.distributed.gather (RCCL send/recv over xGMI) in messages of 64 receivers, "
                               "S-meter + %d audio samples per receiver" % n_aud}
 
@@ -1265,6 +1405,8 @@ def run_rank(args):
         elapsed, kern_ms = timed_steps(torch, ctx, w.step, args.steps, args.warmup)
         if ctx.rank == 0 and not args.no_check:
             extra["parity_checked"] = w.parity_check()
+        if ctx.rank == 0 and ctx.world == 1 and not args.no_secondary:
+            extra["power_clock"] = power_and_clock(torch, ca, ctx, w.step)
         if ctx.rank == 0 and not args.no_secondary:
             extra["distinct_filters"] = w.distinct_filters(ctx)
             if ctx.world == 1:

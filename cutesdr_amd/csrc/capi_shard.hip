@@ -28,6 +28,11 @@ struct csdr_demod_shard {
     std::vector<hipEvent_t> ev_block;                    // per shard: process_shared's reads of the caller's block are done
     std::map<int, hipEvent_t> ev_ready;                  // per source device: the caller's block is complete (process_shared)
     bool committed = false, pipelined = false;
+    // tests on a one-GPU box (csdr__demod_shard_force_peer): every shard but the first takes the PEER copy of the broadcast
+    // even when it names the source's device (hipMemcpyPeerAsync between two ordinals that are equal is legal); peer_copies
+    // counts the peer copies issued so far
+    bool force_peer = false;
+    long peer_copies = 0;
     ~csdr_demod_shard()
     {
         for (size_t s = 0; s < b.size(); s++) {
@@ -243,11 +248,18 @@ int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, i
     S->ev_block.resize(S->b.size(), nullptr);
     std::vector<char> recorded(S->b.size(), 0);
     int err = 0;
+    // (errors inside the loop are captured, never returned from: the tail below -- src_stream waits for every read of the
+    // block already enqueued, the current device goes back to the source's -- runs on every path)
     for (size_t s = 0; s < S->b.size(); s++) {
         if (!device_ok(S->device[s])) { err = CSDR_EHIP; break; }
-        if (!S->ev_block[s]) CSDR_HIP(hipEventCreateWithFlags(&S->ev_block[s], hipEventDisableTiming));
+        if (!S->ev_block[s] && hipEventCreateWithFlags(&S->ev_block[s], hipEventDisableTiming) != hipSuccess) {
+            S->ev_block[s] = nullptr;
+            err = fail(CSDR_EHIP, "hipEventCreateWithFlags failed for shard %zu", s);
+            break;
+        }
         const float *in = d_block;
-        const bool copy = S->device[s] != src_device || S->pipelined;
+        const bool peer = S->device[s] != src_device || (S->force_peer && s > 0);
+        const bool copy = peer || S->pipelined;
         hipError_t e = hipStreamWaitEvent(S->stream[s], ready, 0);
         if (e == hipSuccess && copy) {
             // the previous call's readers of d_block[s] first (pipelined mode; a no-op in strict mode)
@@ -260,10 +272,11 @@ int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, i
                 e = hipMalloc((void **)&S->d_block[s], bytes);
                 if (e == hipSuccess) S->block_cap[s] = bytes;
             }
-            if (e == hipSuccess)
-                e = S->device[s] != src_device
-                        ? hipMemcpyPeerAsync(S->d_block[s], S->device[s], d_block, src_device, bytes, S->stream[s])
-                        : hipMemcpyAsync(S->d_block[s], d_block, bytes, hipMemcpyDeviceToDevice, S->stream[s]);
+            if (e == hipSuccess) {
+                e = peer ? hipMemcpyPeerAsync(S->d_block[s], S->device[s], d_block, src_device, bytes, S->stream[s])
+                         : hipMemcpyAsync(S->d_block[s], d_block, bytes, hipMemcpyDeviceToDevice, S->stream[s]);
+                if (e == hipSuccess && peer) S->peer_copies++;
+            }
             if (e == hipSuccess) e = hipEventRecord(S->ev_block[s], S->stream[s]);     // the caller's block has been read
             in = S->d_block[s];
         }
@@ -280,6 +293,15 @@ int csdr_demod_shard_process_shared(csdr_demod_shard *S, const float *d_block, i
         if (recorded[s] && hipStreamWaitEvent((hipStream_t)src_stream, S->ev_block[s], 0) != hipSuccess && !err)
             err = fail(CSDR_EHIP, "hipStreamWaitEvent");
     return err;
+}
+/* internal (tests on a one-GPU box): on != 0 makes every shard but the first take the peer-copy branch of
+ * csdr_demod_shard_process_shared even when it sits on the source's device; returns the number of peer copies issued
+ * so far (on < 0: query only) */
+long csdr__demod_shard_force_peer(csdr_demod_shard *S, int on)
+{
+    if (!S) return fail(CSDR_EINVAL, "bad handle");
+    if (on >= 0) S->force_peer = on != 0;
+    return S->peer_copies;
 }
 /* waits for everything issued on the shards' own streams */
 int csdr_demod_shard_sync(csdr_demod_shard *S)

@@ -1,5 +1,6 @@
 // downconv_kernels.hip -- launch side of the NCO + decimator cascade (K2): the LDS layout, the run-time-plan
 // instantiation of the kernel and the table of the precompiled plans (downconv_kernel.hpp holds the device code).
+#include "launch_once.hpp"
 #include "downconv_kernel.hpp"
 
 namespace csdr {
@@ -54,19 +55,17 @@ hipError_t downconv_launch(DcArgs &a, hipStream_t stream)
             for (int s = 0; s < p->ns; s++) same = same && p->kind[s] == a.kind[s];
             if (same) return p->launch(a, stream);
         }
-    // per launch: the attribute belongs to the current device, and a process may drive several
+    // (once per device: launch_once.hpp; never needed in practice -- a cascade is ~10 KB)
     if (a.nb_mask) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<DcPlanDyn, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e = CSDR_MAX_LDS_ONCE((&downconv_kernel<DcPlanDyn, true>), lds);
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL((downconv_kernel<DcPlanDyn, true>), dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);
         return hipGetLastError();
     }
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&downconv_kernel<DcPlanDyn>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = CSDR_MAX_LDS_ONCE((&downconv_kernel<DcPlanDyn>), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(downconv_kernel<DcPlanDyn>, dim3(a.nchan * a.nseg), dim3(DC_T), lds, stream, a);

@@ -22,6 +22,7 @@
 // next block.
 #define CSDR_FMA_BFLY 1          // FMA-form decimation-in-time butterflies (fft_core.hpp)
 #define CSDR_PLAIN_CONST_FMA 1   // ... written without asm where the twiddle is a compile-time constant
+#include "launch_once.hpp"
 #include "fastfir_dev.hpp"
 #include "fastfir_kernels.h"
 
@@ -683,9 +684,9 @@ template <int LOG2N>
 static hipError_t launch2_one(const FastFirArgs &a, hipStream_t stream)
 {
     using Cfg = K1Cfg<LOG2N>;
-    // per launch: the attribute belongs to the current device, and a process may drive several
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os2_kernel<LOG2N>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    // once per device and size (the attribute belongs to the device, and a process may drive several): the per-launch
+    // call cost the per-datagram host form microseconds
+    hipError_t e = CSDR_MAX_LDS_ONCE(&fastfir_os2_kernel<LOG2N>, Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
 #ifdef CSDR_WG_TRACE
     FastFirArgs b = a;

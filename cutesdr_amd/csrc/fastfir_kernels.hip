@@ -18,6 +18,7 @@
 // input in registers, so every input sample is read from HBM once.
 //
 // HBM roofline accounting: 8 B read + 8 B written per output sample.
+#include "launch_once.hpp"
 #include "fastfir_dev.hpp"
 #include "fastfir_kernels.h"
 
@@ -297,15 +298,13 @@ template <int LOG2N>
 static hipError_t launch_one(const FastFirArgs &a, hipStream_t stream)
 {
     using Cfg = FastFirCfg<LOG2N>;
-    {   // per launch: the attribute belongs to the current device, and a process may drive several
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os_kernel<LOG2N, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    {   // once per device (launch_once.hpp)
+        hipError_t e = CSDR_MAX_LDS_ONCE((&fastfir_os_kernel<LOG2N, false>), Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     dim3 grid(a.channels * a.runs), block(Cfg::T);
     if (a.dbg_stage > 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastfir_os_kernel<LOG2N, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = CSDR_MAX_LDS_ONCE((&fastfir_os_kernel<LOG2N, true>), Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((fastfir_os_kernel<LOG2N, true>), dim3(1), block, Cfg::LDS_BYTES, stream, a);
     } else {

@@ -15,6 +15,7 @@
 // unpack_kernel replaces the datagram conversion loops of CUdpThread::OnreadyRead
 // (interface/netiobase.cpp:497-503, 521-526); spurcal_kernel the running I/Q means of
 // CSdrInterface::NcoSpurCalibrate (interface/sdrinterface.cpp:829-848).
+#include "launch_once.hpp"
 #include <cstdlib>
 #include "frontend_kernels.h"
 
@@ -411,17 +412,15 @@ void noiseblank_kernel(NbArgs a)
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 {
     if (a.out == nullptr && a.ring) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&noiseblank_kernel<true, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NB_RING * 4);
+        hipError_t e = CSDR_MAX_LDS_ONCE((&noiseblank_kernel<true, true>), NB_RING * 4);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((noiseblank_kernel<true, true>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
     }
     else if (a.out == nullptr)
         hipLaunchKernelGGL((noiseblank_kernel<true, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);
     else if (a.ring) {
-        // per launch: the attribute belongs to the current device (static + dynamic LDS are above 64 KB)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&noiseblank_kernel<false, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NB_RING * 4);
+        // once per device (static + dynamic LDS are above 64 KB)
+        hipError_t e = CSDR_MAX_LDS_ONCE((&noiseblank_kernel<false, true>), NB_RING * 4);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((noiseblank_kernel<false, true>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
     } else hipLaunchKernelGGL((noiseblank_kernel<false, false>), dim3(a.channels * a.nseg), dim3(NB_T), 0, stream, a);

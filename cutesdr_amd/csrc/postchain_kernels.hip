@@ -17,6 +17,7 @@
 #include "postchain.h"
 #include "ref_constants.hpp"
 #include <cstdlib>
+#include "launch_once.hpp"
 
 namespace csdr {
 
@@ -1888,10 +1889,9 @@ hipError_t smeter_collect_launch(PcChannel *chan, int channels, const int *rows,
 template <int NW, bool LEAN>
 static hipError_t pc_launch_nw(const PcArgs &a, hipStream_t stream)
 {
-    // per launch: the attribute belongs to the current device, and a process may drive several
+    // once per device and instantiation (the attribute belongs to the device, and a process may drive several)
     if (sizeof(PcLds) > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&postchain_kernel<NW, LEAN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PcLds));
+        hipError_t e = CSDR_MAX_LDS_ONCE((&postchain_kernel<NW, LEAN>), sizeof(PcLds));
         if (e != hipSuccess) return e;
     }
     PcArgs b = a;

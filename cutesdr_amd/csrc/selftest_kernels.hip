@@ -83,3 +83,34 @@ extern "C" int csdr__selftest_fft(int device, const float *h_in /*36 cpx*/, floa
     (void)hipFree(d_in); (void)hipFree(d_out);
     return CSDR_OK;
 }
+
+// ---- the clock the chip holds (bench.py: roofline.sclk_ghz) ------------------------------------------------------------
+// One wave per workgroup runs a fixed chain of dependent multiply-adds between two readings of the shader-clock
+// counter (s_memtime) and of the constant 100 MHz counter (s_memrealtime): cycles / time = the clock of that XCD while
+// whatever else is running runs.  Launched on a side stream beside the measured kernel (MI355X_MICROARCH.md, DVFS: the
+// chip lowers its clock under load, and the headline kernel sits at the socket's power cap).
+namespace csdr {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, int spins)
+{
+    float a = 1.0f + threadIdx.x * 1e-7f, b = 0.999999f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < spins; i++) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) a = __builtin_fmaf(a, b, 1e-9f);
+    }
+    asm volatile("" : "+v"(a));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0 + (a == 12345.0f ? 1 : 0); }
+}
+}  // namespace csdr
+
+/* internal (bench.py): nwg one-wave probes on `stream`; d_out[2 i] = shader cycles, d_out[2 i + 1] = 100 MHz ticks */
+extern "C" int csdr__clock_probe(int device, void *stream, unsigned long long *d_out, int nwg, int spins)
+{
+    using namespace csdr;
+    if (!d_out || nwg < 1 || spins < 1) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(device)) return CSDR_EHIP;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(nwg), dim3(64), 0, (hipStream_t)stream, d_out, spins);
+    CSDR_HIP(hipGetLastError());
+    return CSDR_OK;
+}

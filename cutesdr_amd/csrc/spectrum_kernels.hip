@@ -9,6 +9,7 @@
 // into display order.  8 B in + 4 B out per bin.
 #define CSDR_FMA_BFLY 1          // FMA-form decimation-in-time butterflies (fft_core.hpp)
 #define CSDR_PLAIN_CONST_FMA 1
+#include "launch_once.hpp"
 #include "fft_core.hpp"
 #include "spectrum_kernels.h"
 #include "ref_constants.hpp"
@@ -697,8 +698,7 @@ template <int LOG2N>
 static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
 {
     using Cfg = SpecCfg<LOG2N>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spectrum_kernel<LOG2N>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = CSDR_MAX_LDS_ONCE((&spectrum_kernel<LOG2N>), Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
     static const bool wide = !(getenv("CSDR_SPEC16") && atoi(getenv("CSDR_SPEC16")) == 0);
     if (LOG2N == 12 && wide)
@@ -706,7 +706,7 @@ static hipError_t spec_launch_one(const SpectrumArgs &a, hipStream_t s)
     else if (LOG2N == 11 && wide)
         hipLaunchKernelGGL(spectrum8_kernel, dim3(a.channels * a.nparts), dim3(128), SPEC8_LDS, s, a);
     else if (LOG2N == 13 && wide) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spectrum32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SPEC32_LDS);
+        e = CSDR_MAX_LDS_ONCE((&spectrum32_kernel), SPEC32_LDS);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(spectrum32_kernel, dim3(a.channels * a.nparts), dim3(512), SPEC32_LDS, s, a);
     } else
@@ -721,8 +721,7 @@ template <int LOG2N>
 static hipError_t plain_launch_one(int sign, const float *in, float *out, const float *tw1, const float *tw2, hipStream_t s)
 {
     using Cfg = SpecCfg<LOG2N>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_plain_kernel<LOG2N>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipError_t e = CSDR_MAX_LDS_ONCE((&fft_plain_kernel<LOG2N>), Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fft_plain_kernel<LOG2N>, dim3(1), dim3(Cfg::T), Cfg::LDS_BYTES, s, (const v2f *)in, (v2f *)out,
                        (const v2f *)tw1, (const v2f *)tw2, sign);

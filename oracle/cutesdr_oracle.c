@@ -1287,7 +1287,47 @@ struct orc_demod {
     int mode, pos, limit;
     orc_amdemod *am; orc_samdemod *sam; orc_fmdemod *fm; int ssb;
     int taps_on; tapvec tap[4];
+    int perturb; double perturb_eps; unsigned long long perturb_state;    /* orc_demod_perturb_filter_output */
 };
+/* TEST-OF-THE-TESTS hook (tests/test_oracle_independent.py): what an fp32 filter in front of the fp64 stages does to
+ * THIS chain's own output.  The filter output z of every pass is replaced by
+ *   mode 1: z rounded to fp32;   mode 2: that, moved by -1 / 0 / +1 ulp(fp32) at random;
+ *   mode 3: z + eps * max|z of the pass| * u, u uniform in [-1, 1) per component -- the ABSOLUTE error floor an fp32
+ *           FFT filter has (the product's K1 measures 3e-7 of the block's largest sample), which is what reaches the
+ *           AGC at full gain while the filter is still starting up on samples of rounding size.
+ * mode 0 (default): nothing -- the oracle proper.  The spread between mode 0 and the others is the room a start-up
+ * tolerance of the GPU chain can claim, and no more. */
+static double perturb_uniform(orc_demod *d)
+{   /* SplitMix64 -> [-1, 1) */
+    unsigned long long z = (d->perturb_state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+static double perturb_f32(orc_demod *d, double v)
+{
+    float f = (float)v;
+    if (d->perturb == 2) {
+        const double u = perturb_uniform(d);
+        if (u < -1.0 / 3.0) f = nextafterf(f, -INFINITY);
+        else if (u > 1.0 / 3.0) f = nextafterf(f, INFINITY);
+    }
+    return (double)f;
+}
+static void perturb_filter_output(orc_demod *d, int n, orc_cpx *z)
+{
+    int i;
+    if (d->perturb == 1 || d->perturb == 2) {
+        for (i = 0; i < n; i++) { z[i].re = perturb_f32(d, z[i].re); z[i].im = perturb_f32(d, z[i].im); }
+    } else if (d->perturb == 3) {
+        double mx = 0.0;
+        for (i = 0; i < n; i++) { const double a = fabs(z[i].re), b = fabs(z[i].im); if (a > mx) mx = a; if (b > mx) mx = b; }
+        for (i = 0; i < n; i++) { z[i].re += d->perturb_eps * mx * perturb_uniform(d); z[i].im += d->perturb_eps * mx * perturb_uniform(d); }
+    }
+}
+void orc_demod_perturb_filter_output(orc_demod *d, int mode, double eps, unsigned long long seed)
+{ d->perturb = mode; d->perturb_eps = eps; d->perturb_state = seed; }
 static void tap_push(tapvec *t, const double *src, int ndoubles)
 {
     if (t->n + ndoubles > t->cap) {
@@ -1379,6 +1419,7 @@ static int demod_chain(orc_demod *d, int stereo, double *out_real, orc_cpx *out_
     int n = orc_downconv_process(d->dc, d->pos, d->inbuf, d->inbuf);
     if (d->taps_on) tap_push(&d->tap[0], (double *)d->inbuf, 2 * n);
     n = orc_fastfir_process(d->ff, n, d->inbuf, d->tmpbuf);
+    if (d->perturb) perturb_filter_output(d, n, d->tmpbuf);
     if (d->taps_on) tap_push(&d->tap[1], (double *)d->tmpbuf, 2 * n);
     orc_smeter_process(d->sm, n, d->tmpbuf, d->out_rate);
     orc_agc_process_cpx(d->agc, n, d->tmpbuf, d->tmpbuf);

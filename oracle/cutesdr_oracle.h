@@ -177,6 +177,9 @@ int  orc_demod_process_mono_append(orc_demod *d, int n, const orc_cpx *in, doubl
 /* stage taps (the reference's DisplayData PROFILE_1..4 points, demodulator.cpp:175-208):
  * when enabled, each inner pass appends its stage buffers here. tap: 1..4 */
 void orc_demod_enable_taps(orc_demod *d, int on);
+/* test-of-the-tests hook: perturb the filter output of every pass (mode 0 off, 1 round to fp32, 2 fp32 +-1 ulp at random,
+ * 3 additive eps * max|z| uniform noise); see cutesdr_oracle.c */
+void orc_demod_perturb_filter_output(orc_demod *d, int mode, double eps, unsigned long long seed);
 int  orc_demod_tap_len(const orc_demod *d, int tap);
 const double *orc_demod_tap_data(const orc_demod *d, int tap); /* cpx interleaved for 1-3; real for 4 */
 void orc_demod_clear_taps(orc_demod *d);

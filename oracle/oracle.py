@@ -142,6 +142,7 @@ def _declare(L):
     f("orc_demod_process_stereo", I, P, I, P, P)
     f("orc_demod_process_mono_append", I, P, I, P, P)
     f("orc_demod_enable_taps", None, P, I)
+    f("orc_demod_perturb_filter_output", None, P, I, D, C.c_ulonglong)
     f("orc_demod_tap_len", I, P, I)
     f("orc_demod_tap_data", P, P, I)
     f("orc_demod_clear_taps", None, P)
@@ -547,6 +548,10 @@ class CDemodulator(_Handle):
         out = np.zeros(len(a) + 65536)
         k = lib().orc_demod_process_mono_append(self.h, len(a), _ptr(a), _ptr(out))
         return out[:k]
+
+    def perturb_filter_output(self, mode, eps=0.0, seed=1):
+        """test-of-the-tests hook (cutesdr_oracle.c): 0 off, 1 fp32 rounding, 2 fp32 +-1 ulp, 3 additive eps * max|z|"""
+        lib().orc_demod_perturb_filter_output(self.h, int(mode), float(eps), int(seed))
 
     def enable_taps(self, on=True):
         lib().orc_demod_enable_taps(self.h, int(on))

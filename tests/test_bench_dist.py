@@ -135,3 +135,27 @@ def test_two_ranks_rehearsed_on_one_gpu():
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_lines(r.stdout)[0]
     assert line["n_gpus"] == 2 and "C4" in line["config"]["workload"] and line["gather"]["ms"] > 0
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl():
+    """VERDICT r5 task 3: RCCL itself, on the one GPU there is.  CSDR_BENCH_FORCE_DIST=1 makes bench.py build a ONE-rank
+    "nccl" process group (a fresh child process, started before anything touches the GPU) and switches the world == 1
+    short-cuts off: the barrier, the MAX all-reduce of the elapsed time on a DEVICE tensor, the all_gather_object census
+    and the chain workload's torch.distributed.gather of S-meters and audio all go through librccl -- the same lines the
+    8-GPU run executes.  N > 1 over xGMI stays unmeasured (no multi-GPU box is available to the builder)."""
+    env = dict(_clean_env(), CSDR_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--steps", "3", "--warmup", "2",
+                        "--no-cpu"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["n_gpus"] == 1 and "C4" in line["config"]["workload"] and line["value"] > 0
+    assert line["ranks"]["backend"] == "nccl" and line["ranks"]["world_size"] == 1
+    assert line["ranks"]["ranks"][0]["device"] == 0
+    g = line["gather"]
+    assert g["backend"] == "nccl" and g["ms"] > 0 and g["messages_per_step"] == 4 and g["bytes_to_rank0"] == 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu", "--no-secondary"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["ranks"]["backend"] == "nccl" and line["parity_checked"]["ok"] and line["value"] > 0

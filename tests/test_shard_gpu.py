@@ -105,6 +105,56 @@ def test_shared_block_is_broadcast_to_every_shard(oracle):
         del sh
 
 
+def test_shared_block_takes_the_peer_copy_branch(oracle):
+    """VERDICT r5 task 3: the broadcast of csdr_demod_shard_process_shared is N - 1 hipMemcpyPeerAsync copies out of the
+    source device; on a one-GPU box every shard names device 0 and the branch would never run.  csdr__demod_shard_force_peer
+    routes every shard but the first through hipMemcpyPeerAsync (device 0 -> device 0 is legal) and counts the copies: the
+    branch ran, and every receiver still equals the oracle's chain on its row.  With two devices visible the second
+    pass runs one shard per device without the switch."""
+    import ctypes as C
+    import cutesdr_amd as ca
+    L = ca.lib()
+    L.csdr__demod_shard_force_peer.restype = C.c_long
+    L.csdr__demod_shard_force_peer.argtypes = [C.c_void_p, C.c_int]
+    fs, lim = 2e6, 19968
+    names = ["FM", "AM", "USB", "FM", "AM", "USB"]
+    Cn, S, n = len(names), 2, lim * 6
+    t = np.arange(n)
+    station = lambda c: 100e3 + 40e3 * (c // S)
+    block = np.zeros((S, n), dtype=np.complex128)
+    for c, m in enumerate(names):
+        block[c % S] += 0.3 * make_input(m, n, fs) * np.exp(2j * np.pi * (station(c) - 100e3) * t / fs)
+    block = block.astype(np.complex64)
+    rows = np.array([c % S for c in range(Cn)], dtype=np.int32)
+    sets = [([0, 0, 0], True)]
+    if ca.lib().csdr_device_count() >= 2:
+        sets.append(([0, 1], False))
+    for devices, force in sets:
+        sh = ca.ShardedDemodBatch(devices, Cn, 2048)
+        sh.set_input_rate(fs)
+        for c, name in enumerate(names):
+            m, kw = MODES[name]
+            sh.set_demod(c, m, info(ca, **kw))
+        sh.commit()
+        for c in range(Cn):
+            sh.set_freq(c, -station(c))
+        sh.set_input_rows(rows, S)
+        assert L.csdr__demod_shard_force_peer(sh.h, 1 if force else 0) == 0
+        got = sh.process_shared(block, src_device=devices[0])
+        got2 = sh.process_shared(block, src_device=devices[0])          # a second call reuses the per-shard copies
+        assert L.csdr__demod_shard_force_peer(sh.h, -1) == 2 * (len(devices) - 1)
+        for c, name in enumerate(names):
+            r = oracle.CDemodulator(2048); m, kw = MODES[name]
+            r.SetInputSampleRate(fs); r.SetDemod(m, info(oracle, **kw)); r.SetDemodFreq(-station(c))
+            want = r.process_append(block[c % S].astype(np.complex128))
+            want2 = r.process_append(block[c % S].astype(np.complex128))
+            assert len(got[c]) == len(want) and len(got2[c]) == len(want2)
+            check_chain_bursts(burst_errors(got[c], want), name if name == "FM" else "other", 0, (devices, c, name))
+            check_chain_bursts(burst_errors(np.concatenate([got[c], got2[c]]), np.concatenate([want, want2])),
+                               name if name == "FM" else "other", 0, (devices, c, name, "second call"))
+        del sh
+
+
 def test_shared_block_reused_by_back_to_back_pipelined_calls():
     """in pipelined mode the down-converters of call k still run on the batch's own streams while
     call k+1 is being issued, so a second csdr_demod_shard_process_shared that refilled the per-shard copy of the block --
