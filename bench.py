@@ -936,11 +936,12 @@ def timed_steps(torch, ctx, step, steps, warmup, prewarm=True):
     return elapsed, sum(a.elapsed_time(b) for a, b in ev) / steps
 
 
-def _read_power_w():
-    """socket power in watts: the amdgpu hwmon node (no process started), else one rocm-smi call"""
+def _read_power_w(pci=None):
+    """socket power in watts of the device at PCI address `pci` ("dddd:bb:dd.f"): its amdgpu hwmon node (no process
+    started), else one rocm-smi call (a host shows every card's node: the first one found is not ours)"""
     import glob
-    for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
-        for f in sorted(glob.glob(pat)):
+    for name in ("power1_average", "power1_input"):
+        for f in sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*/%s" % (pci or "*", name))):
             try:
                 v = float(open(f).read().strip()) * 1e-6
                 if v > 1.0:
@@ -965,19 +966,25 @@ def power_and_clock(torch, ca, ctx, step, seconds=1.5):
     """Socket power and the shader clock the chip holds WHILE the headline launch repeats (after the timed region, never
     inside it): the kernel sits at the socket's power cap, so a box that lands under the target says why in
     its own record.  Clock: one-wave probes (csdr__clock_probe: shader cycles per 100 MHz tick) on a side stream beside
-    the launches; power: the hwmon node read every 20 ms (or rocm-smi)."""
+    the launches; power: the hwmon node read every 20 ms (or rocm-smi).  The side stream is BORROWED from the library's
+    stream pool and handed back (a torch stream of the bench's own took one of the process's hardware queues for good: the
+    chain measured after it ran 1.98 instead of 1.61 ms; probes in the launch stream itself read the IDLE clock, 2.34 GHz --
+    the chip raises its clock within microseconds of the load ending)."""
     import ctypes as C
     import threading
     L = ca.lib()
     L.csdr__clock_probe.restype = C.c_int
     L.csdr__clock_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    side = torch.cuda.Stream()
+    pr = torch.cuda.get_device_properties(ctx.local)
+    pci = None
+    if getattr(pr, "pci_bus_id", None) is not None:
+        pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0) or 0, pr.pci_bus_id, getattr(pr, "pci_device_id", 0) or 0)
     nwg, rounds = 8, []
     samples, src, stop = [], [None], [False]
 
     def sampler():
         while not stop[0]:
-            v, how = _read_power_w()
+            v, how = _read_power_w(pci)
             if v is not None:
                 samples.append(v); src[0] = how
             time.sleep(0.02 if how == "hwmon" else 0.2)
@@ -988,7 +995,7 @@ def power_and_clock(torch, ca, ctx, step, seconds=1.5):
         buf = torch.zeros((2 * nwg,), device="cuda", dtype=torch.int64)
         for i in range(60):
             step()
-            if i == 30 and L.csdr__clock_probe(ctx.local, C.c_void_p(side.cuda_stream), C.c_void_p(buf.data_ptr()), nwg, 2000) != 0:
+            if i == 30 and L.csdr__clock_probe(ctx.local, None, C.c_void_p(buf.data_ptr()), nwg, 2000) != 0:
                 break
         torch.cuda.synchronize()
         rounds.append(buf.cpu().numpy().reshape(nwg, 2).astype(float))
@@ -1003,7 +1010,7 @@ def power_and_clock(torch, ca, ctx, step, seconds=1.5):
             clk = float(np.median(a[ok, 0] / a[ok, 1])) * 0.1          # cycles per 10 ns tick -> GHz
     tail = samples[len(samples) // 3:]
     return {"power_w": round(sum(tail) / len(tail), 1) if tail else None, "power_source": src[0], "power_samples": len(tail),
-            "sclk_ghz": None if clk is None else round(clk, 3)}
+            "sclk_ghz": None if clk is None else round(clk, 3), "pci": pci}
 
 
 # ---------------------------------------------------------------- workloads

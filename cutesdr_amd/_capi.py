@@ -45,7 +45,7 @@ def _ctype(t):
     t = t.replace("const", "").strip()
     if "*" in t:
         return C.c_char_p if t.replace(" ", "") == "char*" else P
-    return {"int": I, "double": D, "void": None, "long long": LL, "unsigned long long": U64, "float": C.c_float, "short": C.c_short}[t]
+    return {"int": I, "double": D, "void": None, "long long": LL, "unsigned long long": U64, "float": C.c_float, "short": C.c_short, "csdr_tap_fn": P}[t]
 
 
 def prototypes():
@@ -53,6 +53,7 @@ def prototypes():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"typedef struct csdr_demod_info \{.*?\} csdr_demod_info;", "", txt, flags=re.S)
+    txt = re.sub(r"typedef void \(\*csdr_tap_fn\)\([^)]*\);", "", txt)
     out = {}
     for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(csdr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()

@@ -5,6 +5,7 @@
 #include "capi_common.hpp"
 #include "pc_unit.hpp"
 #include "dc_host.hpp"
+#include "stream_pool.hpp"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -13,36 +14,6 @@
 #include <vector>
 
 using namespace csdr;
-
-// The batch objects' internal streams come from a process-wide pool and go back to it: what a stream costs or gains
-// depends on the hardware queue the runtime gave it when it was created, and a strict-mode object made after a
-// pipelined one had been destroyed ran 2.1-2.3 ms per C4 call against 1.8 for the same object in a fresh process
-// (new streams landing beside the queues the old ones had held).  Reused, a plan group's stream is the same stream
-// for every object the process makes.  (An idle pooled stream may still have work of its former owner in flight: a
-// stream is in-order, the new owner's work queues behind it.)
-namespace {
-struct StreamPool {
-    std::mutex m;
-    std::map<std::pair<int, int>, std::vector<hipStream_t>> idle;      // (device, priority) -> streams
-    hipError_t get(int device, int prio, hipStream_t *out)
-    {
-        {
-            std::lock_guard<std::mutex> g(m);
-            auto &v = idle[{device, prio}];
-            if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
-        }
-        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
-    }
-    void put(int device, hipStream_t s)
-    {
-        int prio = 0;
-        if (hipStreamGetPriority(s, &prio) != hipSuccess) { (void)hipStreamDestroy(s); return; }
-        std::lock_guard<std::mutex> g(m);
-        idle[{device, prio}].push_back(s);
-    }
-};
-StreamPool &stream_pool() { static StreamPool *p = new StreamPool(); return *p; }   // never destroyed: outlives every object
-}  // namespace
 
 extern "C" int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float *d_in, long long in_stride,
                                                     const int *d_in_rows, int n_per_channel, float *d_out,
@@ -97,6 +68,11 @@ struct ChainCore {
     const DcBlank *blank = nullptr;     // this call's blanker mask, applied by the down-converter (or nullptr)
     int pending = 0;                    // decimated samples waiting for a full hop (same in every row)
     int last_out = 0;
+    // stage taps (csdr_demod_set_taps / csdr_demod_batch_set_taps): bit k-1 = PROFILE_k.  Tap 1 -- this call's down-converter
+    // output -- is copied to d_tap1 before the staging shift; tap 2 is d_filt; with tap 3 on the post-chain runs as
+    // S-meter + AGC into d_agc, then the demodulator from there (the words are those of the fused walk)
+    int taps = 0;
+    float *d_tap1 = nullptr; long tap1_cap = 0; int tap1_n = 0;
 
     ~ChainCore()
     {
@@ -107,6 +83,7 @@ struct ChainCore {
         if (d_agc) (void)hipFree(d_agc);
         if (d_filt2) (void)hipFree(d_filt2);
         if (d_stage2) (void)hipFree(d_stage2);
+        if (d_tap1) (void)hipFree(d_tap1);
         if (s_post) stream_pool().put(device, s_post);
         if (s_fir) stream_pool().put(device, s_fir);
         if (ev_dc) (void)hipEventDestroy(ev_dc);
@@ -137,6 +114,11 @@ struct ChainCore {
         // off by default: with four waves per channel one fused launch already fills the chip and the
         // extra launches cost more than the overlap returns (CSDR_CHAIN_PIPELINE=1 turns it on)
         static const bool pipelined = getenv("CSDR_CHAIN_PIPELINE") && atoi(getenv("CSDR_CHAIN_PIPELINE")) != 0;
+        if (taps & 4) {                 // PROFILE_3: the AGC's output through device memory
+            int rc = pc.run(PC_DO_SMETER | PC_DO_AGC, filt, cap, d_agc, cap, nb, L, s, nullptr);
+            if (rc) return rc;
+            return pc.run(PC_DO_DEMOD | st, d_agc, cap, d_out, out_stride, nb, L, s, d_out_rows);
+        }
         if (nb < 16 || !pipelined)
             return pc.run(PC_DO_SMETER | PC_DO_AGC | PC_DO_DEMOD | st, filt, cap, d_out, out_stride, nb, L, s, d_out_rows);
         int rc = pipeline_init();
@@ -246,6 +228,20 @@ struct ChainCore {
     int step_post(float *d_out, long out_stride, const int *d_out_rows, bool stereo, hipStream_t s)
     {
         const int total = pending + m_call, nb = total / L;
+        if (taps & 1) {                 // PROFILE_1: what the down-converter appended in this call, before the staging moves
+            if (m_call > tap1_cap) {
+                CSDR_HIP(hipStreamSynchronize(s));
+                if (d_tap1) (void)hipFree(d_tap1);
+                d_tap1 = nullptr; tap1_cap = 0;
+                const long want = ((long)m_call + 1023) / 1024 * 1024;
+                CSDR_HIP(hipMalloc((void **)&d_tap1, (size_t)rows * want * 8));
+                tap1_cap = want;
+            }
+            if (m_call > 0)
+                CSDR_HIP(hipMemcpy2DAsync(d_tap1, (size_t)tap1_cap * 8, d_stage + 2 * (size_t)pending, (size_t)cap * 8,
+                                          (size_t)m_call * 8, rows, hipMemcpyDeviceToDevice, s));
+            tap1_n = m_call;
+        }
         m_call = 0;
         last_out = 0;
         last_post = -1;
@@ -401,6 +397,10 @@ struct csdr_demod {
     int pos = 0;
     float *d_in = nullptr, *d_out = nullptr;
     size_t cap_in = 0, cap_out = 0;
+    // stage taps (csdr_demod_set_taps): per pass either the callback or the per-profile accumulators
+    csdr_tap_fn tap_fn = nullptr; void *tap_user = nullptr;
+    std::vector<double> tap_acc[4];
+    std::vector<float> tap_tmp;
     ~csdr_demod()
     {
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -430,6 +430,7 @@ struct csdr_demod_batch {
     std::vector<hipEvent_t> dc_done;                  // core -> its down-converter has been issued and finished
     hipEvent_t fork = nullptr;
     bool pipelined = false;                           // csdr_demod_batch_set_pipelined
+    int taps = 0;                                     // csdr_demod_batch_set_taps (new groups inherit it)
     std::vector<int> prev_post;                       // pipelined: per core, the post-chain event of the previous call
     std::vector<char> prev_join;                      // pipelined: per core, joins[] of the previous call not yet waited for
     float *d_blank = nullptr;                         // blanked input of process_packets (two-pass form)
@@ -702,10 +703,60 @@ double csdr_demod_get_output_rate(csdr_demod *d) { return d ? d->c.out_rate : 0.
 double csdr_demod_get_smeter_peak(csdr_demod *d) { return d ? d->k.pc.smeter_peak(0) : 0.0; }
 double csdr_demod_get_smeter_ave(csdr_demod *d) { return d ? d->k.pc.smeter_ave(0) : 0.0; }
 int csdr_demod_get_buf_limit(csdr_demod *d) { return d ? d->limit : fail(CSDR_EINVAL, "bad handle"); }
+/* the chain's test points (dsp/demodulator.cpp:175,180,187,208): see include/cutesdr_mi.h */
+int csdr_demod_set_taps(csdr_demod *d, int mask, csdr_tap_fn fn, void *user)
+{
+    if (!d || mask < 0 || mask > 15) return fail(CSDR_EINVAL, "bad argument");
+    if (d->s) CSDR_HIP(hipStreamSynchronize(d->s));
+    d->k.taps = mask; d->tap_fn = fn; d->tap_user = user;
+    for (auto &a : d->tap_acc) a.clear();
+    return CSDR_OK;
+}
+int csdr_demod_get_tap(csdr_demod *d, int profile, double *out, int cap)
+{
+    if (!d || profile < 1 || profile > 4 || cap < 0 || (cap && !out)) return fail(CSDR_EINVAL, "bad argument");
+    std::vector<double> &a = d->tap_acc[profile - 1];
+    if ((size_t)cap < a.size()) return fail(CSDR_EINVAL, "tap %d holds %zu doubles, room for %d", profile, a.size(), cap);
+    const int n = (int)a.size();
+    if (n) memcpy(out, a.data(), sizeof(double) * (size_t)n);
+    a.clear();
+    return n;
+}
 
 /* CDemodulator::ProcessData (demodulator.cpp:163-215 mono, :221-273 stereo).  Every inner pass
  * writes its output at out[0] and the return value is the SUM over the passes, exactly as the
  * reference does; append != 0 selects the batch-harness form that appends. */
+// the stage taps of the pass that has just been issued (csdr_demod_set_taps): waits for it, then per profile the callback or
+// the accumulator, in the reference's order (demodulator.cpp:175,180,187,208)
+static int demod_emit_taps(csdr_demod *d, int k, bool stereo)
+{
+    ChainCore &c = d->k;
+    CSDR_HIP(hipStreamSynchronize(d->s));
+    auto emit = [&](int profile, const float *dev_or_host, bool on_device, int n, bool cpx) -> int {
+        if (!(c.taps & (1 << (profile - 1)))) return CSDR_OK;
+        const size_t nf = (size_t)n * (cpx ? 2 : 1);
+        d->tap_tmp.resize(nf ? nf : 1);
+        if (nf) {
+            if (on_device) CSDR_HIP(hipMemcpy(d->tap_tmp.data(), dev_or_host, nf * 4, hipMemcpyDeviceToHost));
+            else memcpy(d->tap_tmp.data(), dev_or_host, nf * 4);
+        }
+        if (d->tap_fn) {
+            std::vector<double> v(nf ? nf : 1);
+            for (size_t i = 0; i < nf; i++) v[i] = (double)d->tap_tmp[i];
+            d->tap_fn(d->tap_user, profile, n, v.data(), cpx ? 1 : 0, d->c.out_rate);
+        } else {
+            std::vector<double> &a = d->tap_acc[profile - 1];
+            for (size_t i = 0; i < nf; i++) a.push_back((double)d->tap_tmp[i]);
+        }
+        return CSDR_OK;
+    };
+    int rc;
+    if ((rc = emit(1, c.d_tap1, true, c.tap1_n, true))) return rc;
+    if ((rc = emit(2, c.d_filt, true, k, true))) return rc;
+    if ((rc = emit(3, c.d_agc, true, k, true))) return rc;
+    const float *audio = d->zero_copy ? d->pin_out.p : d->d_out;
+    return emit(4, audio, !d->zero_copy, k, stereo);
+}
 static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out, bool stereo, bool append)
 {
     if (!d || n < 0 || (n && (!in_iq || !out))) return fail(CSDR_EINVAL, "bad argument");
@@ -771,6 +822,7 @@ static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out,
         CSDR_HIP(hipEventRecord(d->ev_win[wcur], d->s));
         d->win_busy[wcur] = true;
         if (k < 0) return k;
+        if (d->k.taps) { const int rct = demod_emit_taps(d, k, stereo); if (rct) return rct; }
         if (k > 0) {                                      // a pass that returns samples: the one wait of this call
             const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
             if (!d->zero_copy) {
@@ -1295,6 +1347,35 @@ int csdr_demod_batch_process_blanked(csdr_demod_batch *b, const float *d_in, lon
                                         &b->blank.state, &b->blank.hist, stream);
     if (rc < 0) return rc;
     return demod_batch_run(b, d_in, in_stride, (int)n, d_out, out_stride, stream, false, nullptr, 0, &b->blank);
+}
+/* stage taps of a batch's receivers: see include/cutesdr_mi.h */
+int csdr_demod_batch_set_taps(csdr_demod_batch *b, int mask)
+{
+    if (!b || mask < 0 || mask > 15) return fail(CSDR_EINVAL, "bad argument");
+    if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (mask && b->pipelined) return fail(CSDR_ESTATE, "stage taps need the strict mode");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    for (auto *k : b->cores) { k->taps = mask; k->tap1_n = 0; }
+    b->taps = mask;
+    return CSDR_OK;
+}
+int csdr_demod_batch_get_tap(csdr_demod_batch *b, int channel, int profile, float *out, int cap)
+{
+    if (!b || channel < 0 || channel >= b->channels || profile < 1 || profile > 3 || cap < 0 || (cap && !out))
+        return fail(CSDR_EINVAL, "bad argument (PROFILE_4 is the caller's own output row)");
+    if (b->core_of[channel] < 0) return fail(CSDR_ESTATE, "commit first");
+    ChainCore &k = *b->cores[b->core_of[channel]];
+    if (!(k.taps & (1 << (profile - 1)))) return fail(CSDR_ESTATE, "tap %d is not switched on", profile);
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    const int r = b->row_of[channel];
+    const int n = profile == 1 ? k.tap1_n : k.last_out;
+    if (2 * n > cap) return fail(CSDR_EINVAL, "tap %d holds %d floats, room for %d", profile, 2 * n, cap);
+    const float *src = profile == 1 ? k.d_tap1 + 2 * (size_t)r * k.tap1_cap
+                                    : (profile == 2 ? k.d_filt : k.d_agc) + 2 * (size_t)r * k.cap;
+    if (n) CSDR_HIP(hipMemcpy(out, src, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return 2 * n;
 }
 int csdr_demod_batch_group_count(csdr_demod_batch *b, int *rows)
 {

@@ -3,6 +3,7 @@
 // point csdr__selftest_fft(), not part of the public ABI.
 #include "capi_common.hpp"
 #include "fft_core.hpp"
+#include "stream_pool.hpp"
 
 namespace csdr {
 
@@ -104,13 +105,26 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out
 }
 }  // namespace csdr
 
-/* internal (bench.py): nwg one-wave probes on `stream`; d_out[2 i] = shader cycles, d_out[2 i + 1] = 100 MHz ticks */
+/* internal (bench.py): nwg one-wave probes; d_out[2 i] = shader cycles, d_out[2 i + 1] = 100 MHz ticks.  stream == NULL:
+ * on a stream BORROWED from the library's pool (the highest-priority one, the one the first plan group of a batch chain
+ * takes) and handed straight back, so that the probes run BESIDE whatever the caller keeps launching on its own stream
+ * without the process owning one stream more afterwards (a stream more costs the chain a hardware queue: stream_pool.hpp) */
 extern "C" int csdr__clock_probe(int device, void *stream, unsigned long long *d_out, int nwg, int spins)
 {
     using namespace csdr;
     if (!d_out || nwg < 1 || spins < 1) return fail(CSDR_EINVAL, "bad argument");
     if (!device_ok(device)) return CSDR_EHIP;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(nwg), dim3(64), 0, (hipStream_t)stream, d_out, spins);
-    CSDR_HIP(hipGetLastError());
+    hipStream_t s = (hipStream_t)stream;
+    bool borrowed = false;
+    if (!s) {
+        int pr_lo = 0, pr_hi = 0;
+        CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        CSDR_HIP(stream_pool().get(device, pr_hi, &s));
+        borrowed = true;
+    }
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(nwg), dim3(64), 0, s, d_out, spins);
+    const hipError_t e = hipGetLastError();
+    if (borrowed) stream_pool().put(device, s);
+    CSDR_HIP(e);
     return CSDR_OK;
 }

@@ -22,6 +22,18 @@ typedef QString csdr_label_t;
 typedef std::string csdr_label_t;
 #endif
 
+// A host that keeps the reference's test bench defines CSDR_DROPIN_TESTBENCH (and has its own gui/testbench.h on the include
+// path): every pass of the chain then hands its four test points to g_pTestBench->DisplayData(n, buf, m_OutputRate,
+// PROFILE_1..4) exactly where the reference does (dsp/demodulator.cpp:175,180,187,208), through csdr_demod_set_taps.  With the
+// taps on every pass waits for its results -- a diagnostic build, as a host with the test bench open is.
+// CSDR_DROPIN_TESTBENCH_MASK (default 15) selects the profiles: bit k-1 = PROFILE_k.
+#ifdef CSDR_DROPIN_TESTBENCH
+#include "gui/testbench.h"
+#ifndef CSDR_DROPIN_TESTBENCH_MASK
+#define CSDR_DROPIN_TESTBENCH_MASK 15
+#endif
+#endif
+
 #define DEMOD_AM 0
 #define DEMOD_SAM 1
 #define DEMOD_FM 2
@@ -57,7 +69,12 @@ typedef struct _sdmd
 class CDemodulator
 {
 public:
-    CDemodulator() : m_h(csdr_dropin_handle(csdr_demod_create(CSDR_DEVICE, CSDR_FASTFIR_SIZE), "CDemodulator")) {}
+    CDemodulator() : m_h(csdr_dropin_handle(csdr_demod_create(CSDR_DEVICE, CSDR_FASTFIR_SIZE), "CDemodulator"))
+    {
+#ifdef CSDR_DROPIN_TESTBENCH
+        csdr_dropin_count(csdr_demod_set_taps(m_h, CSDR_DROPIN_TESTBENCH_MASK, &CDemodulator::TestBenchTap, this), "CDemodulator taps");
+#endif
+    }
     virtual ~CDemodulator() { csdr_demod_destroy(m_h); }
     CDemodulator(const CDemodulator &) = delete;
     CDemodulator &operator=(const CDemodulator &) = delete;
@@ -87,6 +104,15 @@ public:
     { std::lock_guard<std::mutex> g(m_Mutex); return csdr_dropin_count(csdr_demod_process_stereo(m_h, InLength, &pInData->re, &pOutData->re), "CDemodulator::ProcessData"); }
 
 private:
+#ifdef CSDR_DROPIN_TESTBENCH
+    static void TestBenchTap(void *, int profile, int n, const double *data, int is_complex, double rate)
+    {
+        if (!g_pTestBench) return;
+        // TYPECPX is two doubles (dsp/datatypes.h); DisplayData takes non-const pointers and does not write through them
+        if (is_complex) g_pTestBench->DisplayData(n, reinterpret_cast<TYPECPX *>(const_cast<double *>(data)), rate, profile);
+        else g_pTestBench->DisplayData(n, const_cast<TYPEREAL *>(data), rate, profile);
+    }
+#endif
     csdr_demod *m_h;
     std::mutex m_Mutex;
 };

@@ -559,6 +559,26 @@ class CDemodulator(_Obj):
         k = check(lib().csdr_demod_process_mono_append(self.h, len(a), _vp(a), _vp(out)), "process_append")
         return out[:k]
 
+    def enable_taps(self, mask=15, callback=None):
+        """the chain's test points PROFILE_1..4 (dsp/demodulator.cpp:175,180,187,208): bit k-1 of mask switches tap k on;
+        callback(profile, n, data, is_complex, rate) is called per pass, else the samples accumulate for tap()"""
+        self._tap_cb = None
+        fn = None
+        if callback is not None:
+            proto = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double)
+            def thunk(user, profile, n, data, cpx, rate):
+                v = np.ctypeslib.as_array(data, shape=(n * (2 if cpx else 1),)).copy() if n else np.zeros(0)
+                callback(profile, n, v.view(np.complex128) if cpx else v, bool(cpx), rate)
+            self._tap_cb = proto(thunk)                       # keep the thunk alive as long as the taps are on
+            fn = C.cast(self._tap_cb, C.c_void_p)
+        check(lib().csdr_demod_set_taps(self.h, int(mask), fn, None), "csdr_demod_set_taps")
+
+    def tap(self, k, cap=1 << 22):
+        """what tap k (1..4) has accumulated since it was last read (complex for 1..3; tap 4 as the doubles it holds)"""
+        out = np.zeros(cap)
+        n = check(lib().csdr_demod_get_tap(self.h, k, _vp(out), cap), "csdr_demod_get_tap")
+        return out[:n].view(np.complex128).copy() if k < 4 else out[:n].copy()
+
 
 class DemodBatch(_Obj):
     """Batched device-resident receive chains: [channels][T] fp32 I/Q in, mono fp32 audio out."""
@@ -570,6 +590,15 @@ class DemodBatch(_Obj):
 
     def set_input_rate(self, rate):
         check(lib().csdr_demod_batch_set_input_rate(self.h, rate))
+
+    def set_taps(self, mask):
+        """stage taps PROFILE_1..3 of every receiver (strict mode): the last call's samples stay on the device for tap()"""
+        check(lib().csdr_demod_batch_set_taps(self.h, int(mask)), "csdr_demod_batch_set_taps")
+
+    def tap(self, channel, k, cap=1 << 20):
+        out = np.zeros(cap, dtype=np.float32)
+        n = check(lib().csdr_demod_batch_get_tap(self.h, channel, k, _vp(out), cap), "csdr_demod_batch_get_tap")
+        return out[:n].astype(np.float64).view(np.complex128).copy()
 
     def set_demod(self, channel, mode, info):
         check(lib().csdr_demod_batch_set_demod(self.h, channel, mode, C.byref(info)), "batch_set_demod")

@@ -240,6 +240,18 @@ int csdr_demod_process_mono(csdr_demod *d, int n, const double *in_iq, double *o
 int csdr_demod_process_stereo(csdr_demod *d, int n, const double *in_iq, double *out_iq);
 /* same chain, passes append instead of overwriting (batch harness form) */
 int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, double *out);
+/* Stage taps of the chain: what the reference hands to g_pTestBench->DisplayData(n, buf, m_OutputRate, PROFILE_k) in
+ * every pass (dsp/demodulator.cpp:175,180,187,208; gui/testbench.h:29-38) -- PROFILE_1 the down-converter's output,
+ * PROFILE_2 the band-pass filter's, PROFILE_3 the AGC's (n complex samples each, n = 0 while the filter is filling),
+ * PROFILE_4 the audio (mono: n reals, stereo: n complex).  mask bit k-1 switches PROFILE_k on; 0 = off (the default:
+ * nothing of this costs anything then).  With taps on every pass waits for its results, the AGC's output goes through
+ * device memory (S-meter + AGC and the demodulator as two launches; same words out), and per pass and profile either
+ * `fn` is called -- from inside the ProcessData call, with `user` -- or, fn == NULL, the samples are appended to a
+ * per-profile host buffer that csdr_demod_get_tap returns and empties (returns the number of doubles written; complex
+ * samples are two). */
+typedef void (*csdr_tap_fn)(void *user, int profile, int n, const double *data, int is_complex, double rate);
+int csdr_demod_set_taps(csdr_demod *d, int mask, csdr_tap_fn fn, void *user);
+int csdr_demod_get_tap(csdr_demod *d, int profile, double *out, int cap);
 
 /* batched device-resident chain: configure every channel, commit once, then process */
 typedef struct csdr_demod_batch csdr_demod_batch;
@@ -304,6 +316,13 @@ int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream);
 int csdr_demod_batch_process_stereo(csdr_demod_batch *b, const float *d_in, long long in_stride,
                                     int n_per_channel, float *d_out_iq, long long out_stride, void *stream);
 int csdr_demod_batch_out_count(csdr_demod_batch *b, int channel);
+/* The same stage taps for the receivers of a batch (strict mode only).  With a non-zero mask every group keeps the
+ * LAST call's down-converter output, filter output and AGC output in device memory (the AGC's through a split launch,
+ * as above); csdr_demod_batch_get_tap copies receiver `channel`'s samples of that call to host memory -- PROFILE_1 ..
+ * 3: interleaved fp32 I/Q, PROFILE_1 counts the samples the down-converter appended in that call, 2 and 3 the samples
+ * the filter released -- and returns the number of floats (synchronous; PROFILE_4 is the caller's own output row). */
+int csdr_demod_batch_set_taps(csdr_demod_batch *b, int mask);
+int csdr_demod_batch_get_tap(csdr_demod_batch *b, int channel, int profile, float *out, int cap);
 /* Diagnostics: the number of plan groups the batch runs per call (rows that share one decimation; every group is one
  * set of launches), and with rows != NULL the number of rows -- live and muted -- of all groups.  A mode change to a
  * chain of the same decimation stays in its row; one to another decimation moves the receiver into a muted row of a

@@ -1287,14 +1287,19 @@ struct orc_demod {
     int mode, pos, limit;
     orc_amdemod *am; orc_samdemod *sam; orc_fmdemod *fm; int ssb;
     int taps_on; tapvec tap[4];
-    int perturb; double perturb_eps; unsigned long long perturb_state;    /* orc_demod_perturb_filter_output */
+    int perturb; double perturb_eps, perturb_max; unsigned long long perturb_state;    /* orc_demod_perturb_filter_output */
 };
 /* TEST-OF-THE-TESTS hook (tests/test_oracle_independent.py): what an fp32 filter in front of the fp64 stages does to
  * THIS chain's own output.  The filter output z of every pass is replaced by
  *   mode 1: z rounded to fp32;   mode 2: that, moved by -1 / 0 / +1 ulp(fp32) at random;
- *   mode 3: z + eps * max|z of the pass| * u, u uniform in [-1, 1) per component -- the ABSOLUTE error floor an fp32
- *           FFT filter has (the product's K1 measures 3e-7 of the block's largest sample), which is what reaches the
- *           AGC at full gain while the filter is still starting up on samples of rounding size.
+ *   mode 3: z + eps * M * u, u uniform in [-1, 1) per component, M = the largest filter INPUT component so far -- the
+ *           ABSOLUTE error floor of an fp32 FFT filter (its rounding is relative to the transform's largest values:
+ *           the product's K1 measures 3e-7 of the block's largest input sample), which is what reaches the AGC at
+ *           full gain while the filter's OUTPUT is still starting up on samples of rounding size.
+ *   mode 4: z + q * k, q = eps * M, k an integer uniform in [-3, 3] per component -- the same floor as a GRID: where the
+ *           true output is far below it (the filter's start-up, 1e-12) an fp32 filter's samples are small multiples of one
+ *           quantum (the product's 2048-point filter: multiples of 2^-15 for a carrier of 3277, eps = 1e-8), so their PHASES
+ *           take a handful of values and can drive a PLL coherently -- noise of mode 3 cannot.
  * mode 0 (default): nothing -- the oracle proper.  The spread between mode 0 and the others is the room a start-up
  * tolerance of the GPU chain can claim, and no more. */
 static double perturb_uniform(orc_demod *d)
@@ -1320,14 +1325,19 @@ static void perturb_filter_output(orc_demod *d, int n, orc_cpx *z)
     int i;
     if (d->perturb == 1 || d->perturb == 2) {
         for (i = 0; i < n; i++) { z[i].re = perturb_f32(d, z[i].re); z[i].im = perturb_f32(d, z[i].im); }
+    } else if (d->perturb == 4) {
+        const double q = d->perturb_eps * d->perturb_max;
+        for (i = 0; i < n; i++) {
+            z[i].re += q * floor(3.5 * (perturb_uniform(d) + 1.0) - 3.0);      /* -3 .. 3 */
+            z[i].im += q * floor(3.5 * (perturb_uniform(d) + 1.0) - 3.0);
+        }
     } else if (d->perturb == 3) {
-        double mx = 0.0;
-        for (i = 0; i < n; i++) { const double a = fabs(z[i].re), b = fabs(z[i].im); if (a > mx) mx = a; if (b > mx) mx = b; }
+        const double mx = d->perturb_max;
         for (i = 0; i < n; i++) { z[i].re += d->perturb_eps * mx * perturb_uniform(d); z[i].im += d->perturb_eps * mx * perturb_uniform(d); }
     }
 }
 void orc_demod_perturb_filter_output(orc_demod *d, int mode, double eps, unsigned long long seed)
-{ d->perturb = mode; d->perturb_eps = eps; d->perturb_state = seed; }
+{ d->perturb = mode; d->perturb_eps = eps; d->perturb_state = seed; d->perturb_max = 0.0; }
 static void tap_push(tapvec *t, const double *src, int ndoubles)
 {
     if (t->n + ndoubles > t->cap) {
@@ -1418,6 +1428,14 @@ static int demod_chain(orc_demod *d, int stereo, double *out_real, orc_cpx *out_
 {
     int n = orc_downconv_process(d->dc, d->pos, d->inbuf, d->inbuf);
     if (d->taps_on) tap_push(&d->tap[0], (double *)d->inbuf, 2 * n);
+    if (d->perturb >= 3) {
+        int i;
+        for (i = 0; i < n; i++) {
+            const double a = fabs(d->inbuf[i].re), b = fabs(d->inbuf[i].im);
+            if (a > d->perturb_max) d->perturb_max = a;
+            if (b > d->perturb_max) d->perturb_max = b;
+        }
+    }
     n = orc_fastfir_process(d->ff, n, d->inbuf, d->tmpbuf);
     if (d->perturb) perturb_filter_output(d, n, d->tmpbuf);
     if (d->taps_on) tap_push(&d->tap[1], (double *)d->tmpbuf, 2 * n);

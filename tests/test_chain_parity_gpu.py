@@ -68,10 +68,10 @@ def test_chain_every_mode_from_sample_zero(oracle, mode, stereo):
     errs = np.array(errs)
     assert len(errs) >= 6
     if mode == "FM":
-        late = fm_start_late(errs[0])                          # see test_postchain_gpu.py's module docstring
-        assert errs[3 + late:].max() <= 1e-3 * FULL_SCALE, errs[:8]   # locked and forgotten
-        assert errs[6 + late:].max() <= 3e-5 * FULL_SCALE, errs[:10]
+        check_chain_bursts(errs, "FM", 0, (mode, stereo))      # the derived start-up rule (tests/startup_bounds.py)
         assert (errs[1:5] <= errs[0:4] / 3.0).all(), errs[:6]  # and the start-up difference does decay, burst by burst
+    elif mode == "SAM":
+        check_chain_bursts(errs, "SAM", 0, (mode, stereo), stereo=stereo)     # stereo: bistable first two bursts (startup_bounds.py)
     else:
         assert errs.max() <= FROM_ZERO, errs[:6]
         assert errs[2:].max() <= STEADY, errs[:6]

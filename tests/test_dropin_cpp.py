@@ -181,3 +181,54 @@ def test_dropin_host_bandwidth_switch_matches_oracle(oracle, tmp_path):
     assert float(smeter) == pytest.approx(d.GetSMeterAve(), abs=0.02)
     _, wpix = f.GetScreenIntegerFFTData(255, 700, 0.0, -160.0, -900000, 900000)
     assert np.abs(pix - wpix).max() <= 1
+
+
+TB_EXE = os.path.join(ROOT, "tests", "cpp", "testbench_taps")
+
+
+def build_testbench_exe():
+    from cutesdr_amd import _build
+    _build.build()
+    src = os.path.join(ROOT, "tests", "cpp", "testbench_taps.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "cutesdr_amd", "dropin"),
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp", "stub"), src, "-o", TB_EXE,
+                           "-L", os.path.join(ROOT, "cutesdr_amd"), "-lcutesdr_mi", "-Wl,-rpath," + os.path.join(ROOT, "cutesdr_amd")])
+    return TB_EXE
+
+
+def test_dropin_with_the_test_bench_compiles():
+    """-DCSDR_DROPIN_TESTBENCH with a gui/testbench.h of the host's shape on the include path (tests/cpp/stub)"""
+    assert os.path.exists(build_testbench_exe())
+
+
+@pytest.mark.gpu
+def test_dropin_hands_every_pass_to_the_test_bench(oracle):
+    """VERDICT r5 task 8: the drop-in CDemodulator of a host that keeps the test bench calls
+    g_pTestBench->DisplayData(n, buf, m_OutputRate, PROFILE_1..4) in every pass, in the reference's order and with the
+    reference's counts (dsp/demodulator.cpp:175,180,187,208): six windows of a USB receiver in 256-sample host calls."""
+    exe = build_testbench_exe()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    calls = [l.split() for l in lines if l and not l.startswith("total")]
+    total = int([l for l in lines if l.startswith("total")][0].split()[1])
+    assert len(calls) == 4 * 6
+    ref = oracle.CDemodulator(2048)
+    m = oracle.DEMOD_USB
+    from test_postchain_gpu import MODES, info
+    ref.SetInputSampleRate(2e6); ref.SetDemod(m, info(oracle, **MODES["USB"][1])); ref.SetDemodFreq(-100e3)
+    ref.enable_taps(True)
+    t = np.arange(19968 * 6) / 2e6
+    x = 3000.0 * np.exp(2j * np.pi * 101200.0 * t)
+    want_total = 0
+    for p in range(6):
+        ref.clear_taps()
+        k, _ = ref.ProcessData(x[p * 19968:(p + 1) * 19968])
+        want_total += k
+        mine = calls[4 * p:4 * p + 4]
+        assert [int(c[0]) for c in mine] == [1, 2, 3, 4]
+        assert [int(c[1]) for c in mine] == [len(ref.tap(1)), k, k, k]
+        assert [int(c[2]) for c in mine] == [1, 1, 1, 0]
+        assert all(float(c[3]) == ref.GetOutputRate() for c in mine)
+        assert abs(float(mine[0][4]) - ref.tap(1)[0].real) <= 1e-5 * 32767.0      # the first sample of tap 1 is the down-converter's
+    assert total == want_total

@@ -4,12 +4,11 @@ Tolerances, the same rule in every test of this file, appl
 FastFIR hop of audio):
   * a stage on the oracle's own input (the leaf objects): 2e-5 of full scale from the first sample, PLLs from the
     burst after they have locked (measured 1e-6 .. 6e-6);
-  * the whole chain, AM / SAM / SSB / CW: 5e-4 of full scale from sample 0, 2e-5 from the third burst;
-  * the whole chain, FM: 1e-3 from the fourth burst, 3e-5 from the seventh (its first bursts demodulate the phase of
-    the filter's start-up, where fp32 rounding is the signal: test_chain_parity_gpu.py).  What the first burst leaves
-    is arbitrary -- 7 % of full scale in one build, all of it in the next: one ulp anywhere upstream reshuffles it, in
-    the reference's own fp64 too -- and decays by ~5 per burst, so a stream whose FIRST burst differs by more than a
-    fifth of full scale gets one burst more (fm_start_late); the decay and both bounds are still enforced;
+  * the whole chain, AM / SSB / CW: 5e-4 of full scale from sample 0, 2e-5 from the third burst; SAM mono 2.8e-3 / 5.4e-4
+    in its first two bursts, SAM stereo within the audio range there (bistable: startup_bounds.py), then the same;
+  * the whole chain, FM: the burst of the pull-in is arbitrary, then 5.6e-2, 9.8e-3, 2e-3, 3.8e-4, 7.4e-5 one to
+    five bursts behind it and 3e-5 from the sixth -- each the ORACLE's own spread under an fp32 filter's error floor x 2
+    (startup_bounds.py, reproduced on the CPU by test_oracle_independent.py::test_startup_spread_*);
 identical squelch decisions, exact sample counts; the leaf filters are compared much tighter (they are linear)."""
 import numpy as np
 import pytest
@@ -17,14 +16,20 @@ from util_signals import tones_plus_noise, fm_carrier, am_carrier, FULL_SCALE
 
 pytestmark = pytest.mark.gpu
 
+import startup_bounds as SB
+
 STEADY = 2e-5 * FULL_SCALE
 FROM_ZERO = 5e-4 * FULL_SCALE
-SAM_FIRST = 4e-3 * FULL_SCALE          # SAM chain, the stream's first burst
-SAM_SECOND = 1e-3 * FULL_SCALE         # SAM chain, the second
-FM_SECOND = 8e-2 * FULL_SCALE          # FM chain, burst 1 (the second)
-FM_THIRD = 1.5e-2 * FULL_SCALE         # FM chain, burst 2
-FM_LOCKED = 1e-3 * FULL_SCALE          # FM chain, bursts 4..6
-FM_STEADY = 3e-5 * FULL_SCALE          # FM chain, from burst 7
+# The start-up bounds are DERIVED: tests/startup_bounds.py holds the per-burst spread of the oracle chain against itself under
+# an fp32 filter's error floor (tests/test_oracle_independent.py::test_startup_spread_* reproduces every number on the CPU)
+# and the factor on top of it; the stages behind the filter are pinned without any allowance by
+# tests/test_chain_taps_gpu.py::test_post_chain_on_the_gpus_own_filter_output_from_the_first_sample.
+SAM_FIRST = SB.SAM_FIRST * FULL_SCALE          # SAM mono chain, the stream's first burst (2 x 1.4e-3)
+SAM_SECOND = SB.SAM_SECOND * FULL_SCALE        # SAM mono chain, the second (2 x 2.7e-4)
+FM_STARTUP = [None if b is None else b * FULL_SCALE for b in SB.FM_STARTUP]   # FM chain, k bursts behind the pull-in
+FM_SECOND, FM_THIRD = FM_STARTUP[1], FM_STARTUP[2]
+FM_LOCKED = 1e-3 * FULL_SCALE          # FM chain after a control call in mid-stream (tests/test_rate_change_gpu.py)
+FM_STEADY = 3e-5 * FULL_SCALE          # FM chain, steady state
 
 
 def burst_errors(got, want, hop=1024):
@@ -39,7 +44,7 @@ def fm_start_late(first_burst_err):
     return 1 if first_burst_err > 0.2 * FULL_SCALE else 0
 
 
-def check_chain_bursts(errs, mode, first_burst=0, what="", fm_late=0, from_zero=FROM_ZERO):
+def check_chain_bursts(errs, mode, first_burst=0, what="", fm_late=0, from_zero=FROM_ZERO, stereo=False):
     """the chain rule of the module docstring; errs[i] belongs to burst first_burst + i of the stream.  fm_late: bursts
     by which the FM bounds start later (given by the caller, or found from the stream's first burst when errs starts
     there: fm_start_late)"""
@@ -52,24 +57,25 @@ def check_chain_bursts(errs, mode, first_burst=0, what="", fm_late=0, from_zero=
         big = np.nonzero(errs[:3] > 0.2 * FULL_SCALE)[0]
         start = int(big[0]) if len(big) else 0
     if mode == "FM":
-        # the start-up bursts too (round 4; they used to be unbounded).  The FM chain's first burst is the PLL pulling in
-        # from zero state: an ulp on the input moves the ORACLE's own first burst by 0.03 ... 1.7 of full scale
-        # (tools/explore_fm_early.py), and whatever that burst left decays by ~5 per burst -- on both sides.  So: every
-        # word finite and within the audio range, and the decay bounded from the burst after the pull-in on (measured
-        # 0.9-1.7e-2 and 1.3-3.2e-3 of full scale one and two bursts behind it; a 10 MSPS chain's first burst is silent
-        # on both sides and its pull-in is burst 1).
+        # The FM chain's first burst with audio is the PLL pulling in from zero state on the filter's start-up: the fp32
+        # filter's error floor there moves the ORACLE's own burst by 0.8 ... 1.6 of full scale, and whatever that burst
+        # left decays by ~5 per burst -- on both sides (startup_bounds.py; a 10 MSPS chain's first burst is silent on both
+        # sides and its pull-in is burst 1).  So: every word finite and within the audio range, then burst by burst.
         assert np.isfinite(errs).all() and (errs <= 2.5 * FULL_SCALE).all(), (what, mode, errs[:4] / FULL_SCALE)
-        assert (errs[idx >= start + 1 + given_late] <= FM_SECOND).all(), (what, mode, errs[:10] / FULL_SCALE)
-        assert (errs[idx >= start + 2 + given_late] <= FM_THIRD).all(), (what, mode, errs[:10] / FULL_SCALE)
-        assert (errs[idx >= 3 + fm_late] <= FM_LOCKED).all(), (what, mode, errs[:10] / FULL_SCALE)
-        assert (errs[idx >= 6 + fm_late] <= FM_STEADY).all(), (what, mode, errs[:12] / FULL_SCALE)
+        # k bursts behind the pull-in: the oracle's own spread there x 2 (startup_bounds.py), then the steady bound
+        for k in range(1, len(FM_STARTUP)):
+            assert (errs[idx >= start + k + given_late] <= FM_STARTUP[k]).all(), (what, mode, k, errs[:10] / FULL_SCALE)
+        assert (errs[idx >= start + len(FM_STARTUP) + given_late] <= FM_STEADY).all(), (what, mode, errs[:12] / FULL_SCALE)
     else:
         # (SAM: in the stream's first burst the AGC is at full gain on the filter's start-up -- samples of rounding size --
         # and the 100 Hz loop pulls in on a carrier of arbitrary phase over the first two bursts: how far the phase error
         # swings on the way is set by the rounding noise of the filter kernel in front of it, 0.4 ... 1.5e-3 of full scale
         # with the 2048-point kernels the library has had.  4e-3 in the first burst -- the bound the longer filters' AM
         # start-up already has -- 1e-3 in the second, the common bound from the third.)
-        if mode == "SAM":
+        if mode == "SAM" and stereo:
+            # bistable start (startup_bounds.py): the oracle itself lands 0.48 / 1.70 of full scale apart in bursts 0 and 1
+            assert np.isfinite(errs).all() and (errs[idx <= 1] <= SB.SAM_STEREO_BISTABLE * FULL_SCALE).all(), (what, mode, errs[:4] / FULL_SCALE)
+        elif mode == "SAM":
             assert (errs[idx == 0] <= max(from_zero, SAM_FIRST)).all() and (errs[idx == 1] <= max(from_zero, SAM_SECOND)).all(), \
                 (what, mode, errs[:6] / FULL_SCALE)
         else:
