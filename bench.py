@@ -1245,6 +1245,73 @@ class C4Workload:
                 "collective": "torch.distributed.gather (RCCL send/recv over xGMI) in messages of 64 receivers, "
                               "S-meter + %d audio samples per receiver" % n_aud}
 
+    def control_plane(self, ctx, steps=12):
+        """What the control plane costs (VERDICT r5 task 6): between two calls of the PIPELINED 256-receiver batch, every
+        receiver is retuned (csdr_demod_batch_set_freq) and given new filter edges (a same-mode SetDemod: new frequency
+        response, AGC constants checked, squelch / AM low-pass re-set) -- 256 + 256 calls, nothing waited for.
+        retune_us = the host time of those 512 calls; step_increase_ms = how much longer a step takes with them in front
+        of every step (the patch kernels read 256 x 2 x 16 KB of responses from pinned memory) than without.
+        parity_ok: the same calls setting what is ALREADY set (FM / USB receivers; an AM SetDemod clears its low-pass as the
+        reference's does) leave every audio word of the next steps as it was."""
+        torch, ca = self.torch, self.ca
+        self.set_mode(True)
+        b, C = self.b, self.C
+        lo, _ = shard_channels(ctx, C * ctx.world)
+        base = dict(HiCut=5000, HiCutmin=5000, HiCutmax=15000, LowCut=-5000, LowCutmin=-15000, LowCutmax=-5000,
+                    FilterClickResolution=100, Offset=0, SquelchValue=0, AgcSlope=0, AgcThresh=-100,
+                    AgcManualGain=30, AgcDecay=200, AgcOn=1, AgcHangOn=0, Symetric=1)
+        modes = [(ca.DEMOD_AM, dict(HiCutmin=500, HiCutmax=10000, LowCutmax=-500, LowCutmin=-10000)),
+                 (ca.DEMOD_FM, dict()),
+                 (ca.DEMOD_USB, dict(HiCut=2800, LowCut=100, HiCutmin=500, HiCutmax=20000, LowCutmax=200, LowCutmin=0, Symetric=0))]
+
+        def touch(step, same):
+            t0 = time.perf_counter()
+            for c in range(C):
+                m, kw = modes[(lo + c) % 3]
+                kw = dict(base, **kw)
+                if not same:
+                    kw["HiCut"] = kw["HiCut"] - 100 * (1 + step % 2)          # new edges every step
+                    b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)) - 10.0 * (step % 2))
+                    b.set_demod(c, m, ca.DemodInfo(**kw))
+                elif m != ca.DEMOD_AM:
+                    b.set_freq(c, -(100e3 + 500.0 * ((lo + c) % 1024)))
+                    b.set_demod(c, m, ca.DemodInfo(**kw))
+            return time.perf_counter() - t0
+
+        def run(retune, same=False):
+            for _ in range(4):
+                self.step()
+            b.flush(self.stream); torch.cuda.synchronize()
+            host, t0 = 0.0, time.perf_counter()
+            for k in range(steps):
+                if retune:
+                    host += touch(k, same)
+                self.step()
+            b.flush(self.stream); torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3, host / steps * 1e6
+        # parity first (the object is still at its original settings): three steps untouched, three with no-op setters
+        def audio_of_three(touching):
+            self.set_mode(False); self.set_mode(True)                       # a fresh object: identical start on both sides
+            nonlocal b
+            b = self.b
+            rows = []
+            for k in range(3):
+                if touching and k > 0:
+                    touch(k, True)
+                self.step()
+                b.flush(self.stream); torch.cuda.synchronize()
+                rows.append(self.aud[1:C:3, :self.T // 32].clone())       # the FM receivers
+                rows.append(self.aud[2:C:3, :self.T // 32].clone())       # the USB receivers
+            return rows
+        plain, touched = audio_of_three(False), audio_of_three(True)
+        parity_ok = all(bool(torch.equal(p, t)) for p, t in zip(plain, touched))
+        ms_plain, _ = run(False)
+        ms_retune, host_us = run(True)
+        return {"config": "pipelined batch, %d receivers: set_freq + same-mode set_demod (new filter edges) for EVERY receiver in front of every step" % C,
+                "retune_us": round(host_us, 1), "calls_per_step": 2 * C, "ms_per_step_plain": round(ms_plain, 4),
+                "ms_per_step_with_retunes": round(ms_retune, 4), "step_increase_ms": round(ms_retune - ms_plain, 4),
+                "parity_ok": parity_ok, "parity_what": "no-op set_freq / set_demod on the FM and USB receivers: every audio word of three steps equal to an untouched batch's"}
+
     def set_mode(self, pipelined):
         """a fresh batch object in the wanted mode (a strict-mode object never creates the pipelined mode's streams
         and second buffers: that is the path a host that never asks for pipelining runs)"""
@@ -1427,6 +1494,8 @@ def run_rank(args):
             s = c4.summary(ctx, 30, 15, with_cpu, check=not args.no_check)
             if ctx.rank == 0:
                 extra["chain_c4"] = s
+            if ctx.world == 1:
+                extra["control_plane"] = c4.control_plane(ctx)
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
                 extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check)
                 extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check))

@@ -358,18 +358,10 @@ int apply_set_demod(ChainCore &k, int r, ChanCfg &c, double in_rate, int mode, c
                       info.AgcDecay, c.out_rate);
     if (rc) return rc;
     if ((rc = k.pc.smeter_rate_set(r, c.out_rate))) return rc;
-    if (mode == PC_MODE_FM || mode == PC_MODE_AM) {
-        if ((rc = k.pc.pull(r))) return rc;
-        PcChannel &h = k.pc.h[r];
-        if (mode == PC_MODE_FM) {
-            fm_set_squelch(h.fm, info.SquelchValue);
-            fm_set_bw(h.fm, k.pc.fir_fm[r], c.demod_rate, (double)info.HiCut);   // fmdemod.cpp:160-164 (the object's own rate)
-        } else {
-            am_bandwidth(h.am, k.pc.fir_am[r], c.demod_rate, (info.HiCut - info.LowCut) / 2.0);   // amdemod.cpp:56-60
-        }
-        if ((rc = k.pc.push(r))) return rc;
-    }
-    return CSDR_OK;
+    // (parameter patches: nothing is read back from the device, nothing waits -- pc_unit.hpp)
+    if (mode == PC_MODE_FM) rc = k.pc.fm_params_set(r, info.SquelchValue, c.demod_rate, (double)info.HiCut);   // fmdemod.cpp:95-98, :160-164 (the object's own rate)
+    else if (mode == PC_MODE_AM) rc = k.pc.am_bandwidth_set(r, c.demod_rate, (info.HiCut - info.LowCut) / 2.0);   // amdemod.cpp:56-60
+    return rc;
 }
 
 }  // namespace

@@ -2,6 +2,7 @@
 #include "capi_common.hpp"
 #include "downconv_kernels.h"
 #include "dc_host.hpp"
+#include "patch_queue.hpp"
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -28,6 +29,12 @@ struct csdr_downconvert_batch {
     // lists change only with the plans: a process call copies nothing.  The host mirror runs the same
     // arithmetic; after a retune or a rate change (state_dirty / lists_dirty) the next call uploads it.
     int chan_cur; bool state_dirty, lists_dirty;
+    // A RETUNE (SetFrequency: a new increment, nothing else) does not stop anything: the channel is marked and the next
+    // process call patches its DcChan -- phase and age from the host mirror, which runs the kernel's own arithmetic -- in
+    // that call's stream order (patch_queue.hpp).  state_dirty / lists_dirty (rate changes, rows that move) keep the
+    // synchronising upload.
+    std::vector<char> retuned;
+    PatchQueue patches;
     std::vector<int> list_off, list_len;   // per plan: offset and length of its channel list in d_list
     long wgs_hint = 0;                     // > 0: workgroups of the next launches (csdr__downconvert_batch_set_wgs), else one round
 };
@@ -156,8 +163,8 @@ int csdr_downconvert_batch_set_cw_offset(csdr_downconvert_batch *b, int channel,
 int csdr_downconvert_batch_set_frequency(csdr_downconvert_batch *b, int channel, double freq)
 {
     DCB_CHECK(b, channel);
-    DCB_FOR(b, channel, i) b->ch[i].set_frequency(freq);
-    b->state_dirty = true;               // the new increment reaches the device with the next process call
+    if (b->retuned.size() != (size_t)b->channels) b->retuned.assign(b->channels, 0);
+    DCB_FOR(b, channel, i) { b->ch[i].set_frequency(freq); b->retuned[i] = 1; }   // reaches the device with the next process call
     return CSDR_OK;
 }
 
@@ -251,12 +258,14 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
     // (setters synchronise: nothing of this handle may still be running on the old values)
     if (b->state_dirty || b->lists_dirty) {
         CSDR_HIP(hipDeviceSynchronize());
+        for (char r : b->retuned) if (r) b->state_dirty = true;      // (a retune waiting beside a rate change rides along)
         if (b->state_dirty) {
             std::vector<DcChan> hc(b->channels);
             for (int i = 0; i < b->channels; i++) { hc[i].phase = b->ch[i].phase; hc[i].inc = b->ch[i].inc; hc[i].age = b->ch[i].age; }
             CSDR_HIP(hipMemcpy(b->d_chan + (size_t)b->chan_cur * b->channels, hc.data(), sizeof(DcChan) * b->channels,
                                hipMemcpyHostToDevice));
             b->state_dirty = false;
+            b->retuned.assign(b->channels, 0);          // (the full upload carried every increment)
         }
         if (b->lists_dirty) {
             std::vector<int> all(b->channels);
@@ -270,6 +279,19 @@ int csdr__downconvert_batch_process_rows(csdr_downconvert_batch *b, const float 
             CSDR_HIP(hipMemcpy(b->d_list, all.data(), sizeof(int) * b->channels, hipMemcpyHostToDevice));
             b->lists_dirty = false;
         }
+    }
+    else if (!b->retuned.empty()) {
+        // retunes since the last call: one patch per retuned channel, applied on this call's stream in front of its kernels
+        bool any = false;
+        for (int i = 0; i < b->channels; i++)
+            if (b->retuned[i]) {
+                DcChan hc;
+                hc.phase = b->ch[i].phase; hc.inc = b->ch[i].inc; hc.age = b->ch[i].age;
+                const int rc = b->patches.add(b->d_chan + (size_t)b->chan_cur * b->channels + i, &hc, sizeof(hc));
+                if (rc) return rc;
+                b->retuned[i] = 0; any = true;
+            }
+        if (any) { const int rc = b->patches.flush(s); if (rc) return rc; }
     }
     const size_t half = (size_t)b->channels * b->hist_stride * 2;
     std::vector<DcArgs> launches;

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include "fastfir_kernels.h"
 #include "host_math.hpp"
+#include "patch_queue.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,10 @@ struct csdr_fastfir_batch {
     double flo, fhi, off, fs;         // last shared-filter parameters (early-out like the reference)
     std::vector<std::vector<cd>> resp;   // natural-order fp64 response per filter
     std::vector<int> perm, perm2;     // device slot -> natural bin, generic / pipelined kernel
+    // A new frequency response does not stop anything: SetupParameters designs it on the host and queues the fp32 words
+    // of both kernel orders as patches; the NEXT process call applies them on its own stream in front of its launch
+    // (patch_queue.hpp) -- in stream order behind every earlier call's reads of H, so one buffer per filter suffices.
+    PatchQueue patches;
 };
 
 static void build_perm(csdr_fastfir_batch *b)
@@ -65,7 +70,8 @@ static int upload_response(csdr_fastfir_batch *b, int slot, const std::vector<cd
             dev[2 * i] = (float)v.real();
             dev[2 * i + 1] = (float)v.imag();
         }
-        CSDR_HIP(hipMemcpy(dst + (size_t)slot * 2 * b->n, dev.data(), dev.size() * sizeof(float), hipMemcpyHostToDevice));
+        const int rc = b->patches.add(dst + (size_t)slot * 2 * b->n, dev.data(), dev.size() * sizeof(float));
+        if (rc) return rc;
     }
     return CSDR_OK;
 }
@@ -152,11 +158,11 @@ int csdr_fastfir_batch_setup(csdr_fastfir_batch *b, int channel, double flo, dou
     std::vector<cd> H;
     if (!fastfir_design(b->n, flo, fhi, offset, fs, H))
         return fail(CSDR_EINVAL, "filter parameter error (reference keeps the previous taps)");
-    // H is single-buffered: a kernel of an earlier process call (possibly on a non-blocking stream that the
-    // null-stream copy below does not order against) may still be reading it
-    CSDR_HIP(hipDeviceSynchronize());
     if (channel >= 0 && !b->per_channel) {
-        // switch to one filter per channel, seeded with the shared one
+        // switch to one filter per channel, seeded with the shared one: a reallocation, once in an object's life -- the
+        // only part of a set-up that waits (for this handle's queued patches and whatever still reads the old buffer)
+        { const int rcp = b->patches.flush(b->last_stream); if (rcp) return rcp; }
+        CSDR_HIP(hipDeviceSynchronize());
         float *nh = nullptr;
         const size_t one = (size_t)b->n * 8;
         CSDR_HIP(hipMalloc((void **)&nh, one * b->channels));
@@ -224,6 +230,7 @@ int csdr_fastfir_batch_process(csdr_fastfir_batch *b, const float *d_in, long lo
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t s = (hipStream_t)stream;
     b->last_stream = s;
+    { const int rcp = b->patches.flush(s); if (rcp) return rcp; }      // responses set up since the last call
     FastFirArgs a;
     const size_t hist_half = (size_t)b->channels * L * 2;      // floats
     a.in = (const v2f_h *)d_in; a.out = (v2f_h *)d_out;

@@ -28,7 +28,19 @@ struct csdr_fft_batch {
     int *d_scr = nullptr; size_t scr_cap = 0;           // levels of a waterfall line (csdr_fft_batch_get_waterfall_all)
     std::vector<float> h_ave;
     std::vector<int> h_over;
+    // the readers (GetScreenIntegerFFTData from the GUI thread, fft.cpp:308-410) wait for THIS object's last
+    // PutInDisplayFFT only -- the copy rides on that call's stream -- not for whatever else the device is running
+    hipStream_t last_stream = nullptr; bool have_stream = false;
 };
+
+// device -> host behind the object's own work: on the stream of its last put_display (until round 5: hipDeviceSynchronize)
+static int fft_read(csdr_fft_batch *f, void *dst, const void *src, size_t bytes)
+{
+    if (!f->have_stream) { CSDR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return CSDR_OK; }
+    CSDR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, f->last_stream));
+    CSDR_HIP(hipStreamSynchronize(f->last_stream));
+    return CSDR_OK;
+}
 
 static void fft_free_dev(csdr_fft_batch *f)
 {
@@ -146,6 +158,7 @@ int csdr_fft_batch_put_display(csdr_fft_batch *f, const float *d_in, long long i
     if (!f || !d_in || nframes < 0) return fail(CSDR_EINVAL, "bad argument");
     if (nframes == 0) return CSDR_OK;
     if (!device_ok(f->device)) return CSDR_EHIP;
+    f->last_stream = (hipStream_t)stream; f->have_stream = true;
     CSDR_HIP(hipMemsetAsync(f->d_over, 0, sizeof(int) * f->channels, (hipStream_t)stream));   // m_Overload = FALSE
     SpectrumArgs a;
     a.in = d_in; a.in_stride = in_stride; a.win = f->d_win; a.tw1 = f->d_tw1; a.tw2 = f->d_tw2;
@@ -187,8 +200,7 @@ int csdr_fft_batch_get_ave(csdr_fft_batch *f, int channel, float *out)
 {
     if (!f || !out || channel < 0 || channel >= f->channels) return fail(CSDR_EINVAL, "bad argument");
     if (!device_ok(f->device)) return CSDR_EHIP;
-    CSDR_HIP(hipDeviceSynchronize());
-    CSDR_HIP(hipMemcpy(out, f->d_ave + (size_t)channel * f->size, (size_t)f->size * 4, hipMemcpyDeviceToHost));
+    { const int rc = fft_read(f, out, f->d_ave + (size_t)channel * f->size, (size_t)f->size * 4); if (rc) return rc; }
     return f->size;
 }
 int csdr_fft_batch_get_total_count(csdr_fft_batch *f, int channel)
@@ -196,8 +208,7 @@ int csdr_fft_batch_get_total_count(csdr_fft_batch *f, int channel)
     if (!f || channel < 0 || channel >= f->channels) return fail(CSDR_EINVAL, "bad argument");
     if (!device_ok(f->device)) return CSDR_EHIP;
     int c[2];
-    CSDR_HIP(hipDeviceSynchronize());
-    CSDR_HIP(hipMemcpy(c, f->d_cnt + 2 * channel, sizeof(c), hipMemcpyDeviceToHost));
+    { const int rc = fft_read(f, c, f->d_cnt + 2 * channel, sizeof(c)); if (rc) return rc; }
     return c[1];
 }
 
@@ -212,7 +223,7 @@ int csdr_fft_batch_get_screen(csdr_fft_batch *f, int channel, int max_h, int max
     int rc = csdr_fft_batch_get_ave(f, channel, f->h_ave.data());
     if (rc < 0) return rc;
     int over = 0;
-    CSDR_HIP(hipMemcpy(&over, f->d_over + channel, sizeof(int), hipMemcpyDeviceToHost));
+    { const int rc2 = fft_read(f, &over, f->d_over + channel, sizeof(int)); if (rc2) return rc2; }
     const float *ave = f->h_ave.data();
     int i, x, y, ymax = 10000, xprev = -1;
     const double off = max_db / 10.0, gain = -10.0 / (max_db - min_db);

@@ -69,6 +69,14 @@ struct PatchQueue {
     {
         if (bytes == 0) return CSDR_OK;
         if ((bytes & 3) || ((uintptr_t)dst & 3)) return fail(CSDR_EINVAL, "patches are 4-byte granular");
+        // the patches of one flush are applied by concurrent workgroups: a second patch of the same words (a receiver
+        // retuned twice between two calls) replaces the first one's data instead of racing with it.  (Callers patch a
+        // field group always as the same range, so ranges are equal or disjoint.)
+        for (PatchDesc &d : list)
+            if (!d.fill && d.dst == (unsigned long long)(uintptr_t)dst && d.bytes == (unsigned)bytes) {
+                memcpy(arena[cur].p + d.src, src, bytes);
+                return CSDR_OK;
+            }
         const int rc = reserve((bytes + 15) & ~(size_t)15);
         if (rc) return rc;
         memcpy(arena[cur].p + used, src, bytes);

@@ -7,6 +7,8 @@
 #include "capi_common.hpp"
 #include "postchain.h"
 #include "pc_host.hpp"
+#include "patch_queue.hpp"
+#include <cstddef>
 
 namespace csdr {
 
@@ -53,6 +55,12 @@ struct PcUnit {
     hipStream_t sm_borrow = nullptr;                     // set per call by the batch chain, not owned: an EXISTING stream
                                                          // that has nothing left to do in this call -- the whole-call
                                                          // S-meter of the group whose walk ends the call runs there
+    // Parameter changes between two calls (AGC constants, S-meter rate, squelch, the demodulators' FIRs) do not stop anything:
+    // the host mirror below is authoritative for PARAMETERS, a setter computes the new words there and queues them as patches
+    // of exactly those fields; run() applies the queue on its own stream in front of its first launch (patch_queue.hpp).
+    // The STATE words of a channel (averagers, PLL, filter memories, ring positions) live on the device only and are
+    // never sent from the mirror -- except where the reference resets them (AGC at a new sample rate, a redesigned FIR).
+    PatchQueue patches;
     std::vector<PcChannel> h;            // host mirror (authoritative for parameters)
     std::vector<HostAgc> hagc;
     std::vector<HostFir> fir_am, fir_sam, fir_fm;
@@ -91,9 +99,10 @@ struct PcUnit {
         CSDR_HIP(hipMemcpy(d_chan, h.data(), sizeof(PcChannel) * nch, hipMemcpyHostToDevice));
         return CSDR_OK;
     }
-    int pull(int c)      // device -> host mirror (state advances on the device)
+    int pull(int c)      // device -> host mirror (state advances on the device); rows that MOVE and new demodulator objects only
     {
         CSDR_HIP(hipSetDevice(device));
+        { const int rcp = patches.flush(nullptr); if (rcp) return rcp; }     // nothing queued may be lost to the copy below
         CSDR_HIP(hipDeviceSynchronize());
         CSDR_HIP(hipMemcpy(&h[c], d_chan + c, sizeof(PcChannel), hipMemcpyDeviceToHost));
         return CSDR_OK;
@@ -101,6 +110,7 @@ struct PcUnit {
     int push(int c)
     {
         CSDR_HIP(hipSetDevice(device));
+        { const int rcp = patches.flush(nullptr); if (rcp) return rcp; }     // older queued words must not land on top of these
         CSDR_HIP(hipMemcpy(d_chan + c, &h[c], sizeof(PcChannel), hipMemcpyHostToDevice));
         return CSDR_OK;
     }
@@ -125,23 +135,58 @@ struct PcUnit {
                            sizeof(float) * PC_AGC_RING, hipMemcpyDeviceToDevice));
         return push(c);
     }
-    // CAgc::SetParameters
+    // a run of fields [first, last] of row c's PcChannel, from the host mirror, as one patch
+    template <class A, class B> int patch_fields(int c, const A &first, const B &last)
+    {
+        const unsigned char *b0 = reinterpret_cast<const unsigned char *>(&h[c]);
+        const unsigned char *f0 = reinterpret_cast<const unsigned char *>(&first), *f1 = reinterpret_cast<const unsigned char *>(&last) + sizeof(B);
+        return patches.add(reinterpret_cast<unsigned char *>(d_chan + c) + (f0 - b0), f0, (size_t)(f1 - f0));
+    }
+    // CAgc::SetParameters (agc.cpp:104-167): constants always; delay line, window and averagers only when the sample rate
+    // changed (:121-136) -- nothing is read back, nobody waits
     int agc_set(int c, int on, int hang, int thresh, int manual, int slope, int decay, double fs)
     {
-        int rc = pull(c);
-        if (rc) return rc;
         const int ch = hagc[c].set(h[c].agc, on != 0, hang != 0, thresh, manual, slope, decay, fs);
         if (ch == 0) return CSDR_OK;
-        if (ch == 2 && (rc = agc_rings_clear(c))) return rc;
-        return push(c);
+        PcAgc &a = h[c].agc;
+        int rc = patch_fields(c, a.on, a.hang_time);
+        if (!rc) rc = patch_fields(c, a.manual_gain, a.dec_fall);
+        if (!rc && ch == 2) {
+            rc = patch_fields(c, a.dly_pos, a.hang_timer);
+            if (!rc) rc = patch_fields(c, a.peak, a.decay_ave);
+            const float m16 = -16.0f;
+            unsigned w16; memcpy(&w16, &m16, 4);
+            if (!rc) rc = patches.add_fill(d_dly + (size_t)c * 2 * PC_AGC_RING, 0u, sizeof(float) * 2 * PC_AGC_RING);
+            if (!rc) rc = patches.add_fill(d_mag + (size_t)c * PC_AGC_RING, w16, sizeof(float) * PC_AGC_RING);
+        }
+        return rc;
     }
     int smeter_rate_set(int c, double fs)
     {
         if (h[c].sm.fs == fs) return CSDR_OK;
-        int rc = pull(c);
-        if (rc) return rc;
         smeter_rate(h[c].sm, fs);
-        return push(c);
+        return patch_fields(c, h[c].sm.att_a, h[c].sm.fs);
+    }
+    // CFmDemod::SetSquelch (fmdemod.cpp:95-98) and the HiCut-dependent high-pass of ProcessData (:160-164: redesigned, its
+    // delay line cleared, when the bandwidth changes)
+    int fm_params_set(int c, int squelch_value, double demod_rate, double fm_bw)
+    {
+        PcFm &f = h[c].fm;
+        fm_set_squelch(f, squelch_value);
+        int rc = patch_fields(c, f.sq_thresh, f.sq_thresh);
+        const double before = f.hp_freq;
+        fm_set_bw(f, fir_fm[c], demod_rate, fm_bw);
+        if (!rc && f.hp_freq != before) {
+            rc = patch_fields(c, f.hp_freq, f.hp_freq);
+            if (!rc) rc = patch_fields(c, f.hp, f.hp);
+        }
+        return rc;
+    }
+    // CAmDemod::SetBandwidth (amdemod.cpp:56-60): a new low-pass, its delay line cleared (fir.cpp:229-235), on every SetDemod
+    int am_bandwidth_set(int c, double demod_rate, double bw)
+    {
+        am_bandwidth(h[c].am, fir_am[c], demod_rate, bw);
+        return patch_fields(c, h[c].am.fir, h[c].am.fir);
     }
     // CSMeter::GetPeak resets the peak (smeter.cpp:98-103).  Read and reset on the device, one field: the rest of
     // the channel state (AGC, PLL, filter memories) is never written back from a stale host copy.
@@ -171,6 +216,7 @@ struct PcUnit {
             int burst, hipStream_t stream, const int *d_out_rows = nullptr)
     {
         CSDR_HIP(hipSetDevice(device));
+        { const int rcp = patches.flush(stream); if (rcp) return rcp; }       // parameters set since the last call
         if (burst > scratch_cap) {
             if (d_scratch) (void)hipFree(d_scratch);
             d_scratch = nullptr; scratch_cap = 0;

@@ -162,3 +162,38 @@ def test_decimator_plan_enumeration_is_every_sequence_the_selection_rule_can_pro
     spec = importlib.util.spec_from_file_location("list_dc_plans", os.path.join(root, "tools", "list_dc_plans.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     assert set(m.table(m.RATES)) | set(m.table(m.MORE_RATES)) <= set(plans)
+
+
+def test_the_retune_and_parameter_setters_hold_no_device_wide_synchronisation():
+    """VERDICT r5 task 6, checked in the source: the functions behind set_freq, a same-mode SetDemod and the spectrum's
+    readers contain no hipDeviceSynchronize (they queue patches -- csrc/patch_queue.hpp -- or wait on the object's own
+    stream); the one exception is spelled out: CFastFIR's once-in-a-lifetime switch from a shared response to one per
+    row reallocates.  (The GPU side: tests/test_control_plane_gpu.py.)"""
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cutesdr_amd", "csrc")
+
+    def body(path, signature):
+        txt = open(os.path.join(root, path)).read()
+        i = txt.index(signature)
+        j = txt.index("{", i)
+        depth, k = 0, j
+        while True:
+            depth += txt[k] == "{"
+            depth -= txt[k] == "}"
+            k += 1
+            if depth == 0:
+                return txt[j:k]
+    clean = [("capi_downconv.hip", "int csdr_downconvert_batch_set_frequency("), ("capi_downconv.hip", "int csdr_downconvert_batch_set_cw_offset("),
+             ("capi_demod.hip", "int csdr_demod_batch_set_freq("), ("capi_demod.hip", "int csdr_demod_set_freq("),
+             ("pc_unit.hpp", "int agc_set("), ("pc_unit.hpp", "int smeter_rate_set("), ("pc_unit.hpp", "int fm_params_set("),
+             ("pc_unit.hpp", "int am_bandwidth_set("), ("capi_fft.hip", "int csdr_fft_batch_get_ave("),
+             ("capi_fft.hip", "int csdr_fft_batch_get_screen("), ("capi_fft.hip", "int csdr_fft_batch_get_total_count("),
+             ("capi_fft.hip", "static int fft_read(")]
+    for path, sig in clean:
+        assert "hipDeviceSynchronize" not in body(path, sig), (path, sig)
+    setup = body("capi_fastfir.hip", "int csdr_fastfir_batch_setup(")
+    assert setup.count("hipDeviceSynchronize") == 1 and "switch to one filter per channel" in setup
+    # the same-mode half of SetDemod: everything behind the `if (c.mode != mode)` block of apply_set_demod
+    asd = body("capi_demod.hip", "int apply_set_demod(")
+    tail = asd[asd.index("c.cw_off = info.Offset;"):]
+    assert "pull(" not in tail and "push(" not in tail and "hipDeviceSynchronize" not in tail
