@@ -111,6 +111,9 @@ struct ChainCore {
     int post(const float *filt, float *d_out, long out_stride, const int *d_out_rows, bool stereo, int nb, hipStream_t s)
     {
         const int st = stereo ? PC_STEREO : 0;
+        // parameters set since the last call: applied HERE, on the stream every launch below is ordered behind (the optional
+        // stage pipeline forks to side streams; a patch kernel on one of them would not be ordered before the others)
+        { const int rcp = pc.patches.flush(s); if (rcp) return rcp; }
         // off by default: with four waves per channel one fused launch already fills the chip and the
         // extra launches cost more than the overlap returns (CSDR_CHAIN_PIPELINE=1 turns it on)
         static const bool pipelined = getenv("CSDR_CHAIN_PIPELINE") && atoi(getenv("CSDR_CHAIN_PIPELINE")) != 0;

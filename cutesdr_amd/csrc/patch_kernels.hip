@@ -4,7 +4,7 @@
 
 namespace csdr {
 
-__global__ __launch_bounds__(256) void patch_apply_kernel(const PatchDesc *list, const unsigned char *arena)
+__global__ __launch_bounds__(256) void patch_apply_kernel(const PatchDesc *list)
 {
     const PatchDesc d = list[blockIdx.x];
     unsigned *dst = reinterpret_cast<unsigned *>(d.dst);
@@ -13,15 +13,15 @@ __global__ __launch_bounds__(256) void patch_apply_kernel(const PatchDesc *list,
         const unsigned w = (unsigned)d.src;
         for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = w;
     } else {
-        const unsigned *src = reinterpret_cast<const unsigned *>(arena + d.src);
+        const unsigned *src = reinterpret_cast<const unsigned *>(d.src);
         for (unsigned i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
     }
 }
 
-hipError_t patch_apply_launch(const PatchDesc *d_list, const unsigned char *d_arena, int n, hipStream_t s)
+hipError_t patch_apply_launch(const PatchDesc *d_list, int n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(patch_apply_kernel, dim3(n), dim3(256), 0, s, d_list, d_arena);
+    hipLaunchKernelGGL(patch_apply_kernel, dim3(n), dim3(256), 0, s, d_list);
     return hipGetLastError();
 }
 
