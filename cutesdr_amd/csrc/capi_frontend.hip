@@ -14,6 +14,8 @@ struct NbHost {                          // the SetupBlanker comparands (noisepr
     bool configured = false, on = false;
     double thresh = 0, width = 0, fs = 0;
     int mag_n = 0;                       // as on the device (a rate-only change does not reconfigure: not derivable from fs)
+    bool integral = true;                // every sample since the last set-up (which clears sum and buffers) came from datagrams:
+                                         // the moving sum and the history are whole multiples of 2^-8 (frontend_kernels.hip)
 };
 
 struct csdr_noiseproc_batch {
@@ -28,6 +30,11 @@ struct csdr_noiseproc_batch {
         if (d_hist) (void)hipFree(d_hist);
     }
 };
+
+// tests (A/B of the two mask kernels in one process): 0 = always the general kernel
+static int &nb_int_switch() { static int on = !(getenv("CSDR_NB_INT") && atoi(getenv("CSDR_NB_INT")) == 0); return on; }
+static bool nb_int_enabled() { return nb_int_switch() != 0; }
+extern "C" int csdr__noiseproc_set_int(int on) { if (on >= 0) nb_int_switch() = on; return nb_int_switch(); }
 
 static int nb_setup_one(csdr_noiseproc_batch *b, int c, int on, double thresh, double width, double fs)
 {
@@ -48,6 +55,7 @@ static int nb_setup_one(csdr_noiseproc_batch *b, int c, int on, double thresh, d
     n.sum = 0.0;
     n.since_trig = 1LL << 40;
     h.configured = true; h.on = on != 0; h.thresh = thresh; h.width = width; h.fs = fs; h.mag_n = n.mag_n;
+    h.integral = true;                   // (the buffers are cleared below)
     CSDR_HIP(hipDeviceSynchronize());
     for (int k = 0; k < 2; k++) CSDR_HIP(hipMemcpy(b->d_chan + (size_t)k * b->channels + c, &n, sizeof(n), hipMemcpyHostToDevice));
     const size_t row = (size_t)NB_HIST * 8, half = (size_t)b->channels * row;
@@ -158,6 +166,10 @@ static int nb_run(csdr_noiseproc_batch *b, const float *d_in, long long in_strid
     a.channels = b->channels; a.n = n_per_channel;
     static const bool ring_env = !(getenv("CSDR_NB_RING") && atoi(getenv("CSDR_NB_RING")) == 0);
     a.ring = ring_env;
+    // float rows: from here on the sums may carry roundings -- the integer form is off until the next set-up clears them
+    if (!wire.pk) for (auto &h : b->h) h.integral = false;
+    a.int_ok = nb_int_enabled() && wire.pk != nullptr;
+    for (int c = 0; c < b->channels && a.int_ok; c++) if (b->h[c].on && !b->h[c].integral) a.int_ok = 0;
     for (int c = 0; c < b->channels && a.ring; c++)
         if (b->h[c].on && (b->h[c].mag_n + 1 < noiseblank_ring_min(d_mask != nullptr) ||
                            b->h[c].mag_n + 1 > noiseblank_ring_max(d_mask != nullptr))) a.ring = 0;

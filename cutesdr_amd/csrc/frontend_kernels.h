@@ -32,6 +32,9 @@ struct NbArgs {
     int ring;                           // the window's magnitudes stay in an LDS ring (frontend_kernels.hip) -- only when
                                         // EVERY channel with the blanker on has noiseblank_ring_min(mask form?) <=
                                         // mag_n + 1 <= noiseblank_ring_max(mask form?)
+    int int_ok;                         // mask form on datagrams: every sample the blanker has seen since its set-up came from
+                                        // datagrams -- sum and history are integral in units of 2^-8 and the integer kernel
+                                        // (noiseblank_mask_int_kernel) decides exactly what the general one does
     int nseg, seg_len;                  // each channel's call is cut into nseg segments of seg_len samples (a
                                         // multiple of 1024, >= 4 blank widths), one workgroup each
 };

@@ -409,8 +409,245 @@ void noiseblank_kernel(NbArgs a)
         for (long j = t; j < NB_HIST; j += NB_T) hist_next[j] = X((long)n - NB_HIST + j);
 }
 
+
+// =====================================================================================================================
+// The mask form on DATAGRAM input in integers (round 6).  A 16- or 24-bit datagram sample is an integer multiple of 2^-8
+// of the float the general kernel decodes (wire_format.hpp), so the magnitudes max(|I|, |Q|) are integers below 2^23 in
+// that unit and the moving sum -- at most 32768 of them -- is an integer below 2^38: every fp64 sum of the general
+// kernel (and of the reference: m_MagAveSum, noiseproc.cpp:143-147) is EXACT on such input, in any order, and equals the
+// 64-bit integer sum here bit for bit.  What the integers buy: no decode to float, no float -> double conversions, a
+// 32-bit subtract and add per sample instead of three half-rate fp64 operations, and -- the larger part -- the trigger
+// test `mag * ratio > S` (noiseproc.cpp:155-158: one conversion, one fp64 multiply, one add, one compare per sample)
+// is first asked once per THREAD in fp32 with a safety margin (largest of its eight magnitudes against the smallest of
+// its eight sums): a thread without a candidate -- all but a few per launch -- skips the eight fp64 tests and the per-sample
+// trigger positions.  A thread with a candidate runs the general kernel's exact fp64 test on the same numbers scaled by
+// 2^8 (a power of two: the products and compares round identically), so the decisions are the general kernel's, sample
+// for sample.  The host takes this kernel only while EVERY sample the blanker has seen since its last set-up came from
+// datagrams (csdr_noiseproc_batch: datagram_only) -- the state it inherits (sum, history) is then integral in that unit.
+// Ring form only (the window's magnitudes in LDS, as integers); eight samples per thread.
+__device__ __forceinline__ long long wave_incl_scan_add_i64(long long v)
+{
+#define NB_STEP(C_, R_) v += (long long)nb_dpp64<C_, R_>((unsigned long long)v, 0ull);
+    NB_SCAN_STEPS(NB_STEP)
+#undef NB_STEP
+    return v;
+}
+template <int FMT>                                           // 1444: 24-bit datagrams, 1028: 16-bit
+__global__ __launch_bounds__(NB_T)
+void noiseblank_mask_int_kernel(NbArgs a)
+{
+    constexpr int NB_PER = NbTile<true, true>::PER, NB_TILE = NbTile<true, true>::TILE;
+    static_assert(NB_PER == 8, "the packing below is written for eight samples per thread");
+    __shared__ long long wsum[NB_T / 64];
+    __shared__ int wmax[NB_T / 64];
+    extern __shared__ __attribute__((aligned(16))) float nb_ring[];
+    int *ring = reinterpret_cast<int *>(nb_ring);           // [NB_RING] integer magnitudes, units of 2^-8
+    const int ch = blockIdx.x / a.nseg, seg = blockIdx.x % a.nseg, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const NbChan C = a.chan[ch];
+    unsigned *mrow = a.mask + (long)ch * a.mask_stride;
+    const f2 *hist = reinterpret_cast<const f2 *>(a.hist) + (long)ch * NB_HIST;
+    f2 *hist_next = reinterpret_cast<f2 *>(a.hist_next) + (long)ch * NB_HIST;
+    const int n = a.n;
+    const unsigned char *pk = a.wire.pk + (long)ch * a.wire.chan_stride;
+    auto X = [&](long i) -> f2 { return i >= 0 ? wire_sample(pk, FMT, i) : hist[NB_HIST + i]; };
+    // integer magnitude of sample i of [history | call] (the history holds the floats of earlier datagrams: integral)
+    auto imag_at = [&](long i) -> int { const f2 v = X(i); return (int)(fmaxf(fabsf(v.x), fabsf(v.y)) * 256.0f); };
+    const long seg_a = (long)seg * a.seg_len;
+    const long seg_b = seg_a + a.seg_len < n ? seg_a + a.seg_len : n;
+    const bool last_seg = seg == a.nseg - 1;
+    if (C.on) {
+        const int M1 = C.mag_n + 1, W = C.width_n;
+        const double ratio = C.ratio;
+        const float ratio_hi = (float)ratio * 1.000004f;    // fp32 screen: errs on the side of calling the exact test
+        long long S0 = (long long)llrint(C.sum * 256.0);
+        long long last = -C.since_trig;
+        long first = 0;
+        auto rslot = [](long i) -> int { const int r = (int)(i % NB_RING); return r < 0 ? r + NB_RING : r; };
+        if (seg == 0) {
+            for (long k = -(long)M1 + t; k < 0; k += NB_T) ring[rslot(k)] = imag_at(k);
+            __syncthreads();
+        } else {
+            first = seg_a - (long)((W + NB_TILE - 1) / NB_TILE) * NB_TILE;
+            long long part = 0;
+            for (long k = first - M1 + t; k < first; k += NB_T) { const int m = imag_at(k); part += m; ring[rslot(k)] = m; }
+            part = wave_incl_scan_add_i64(part);
+            if (lane == 63) wsum[w] = part;
+            __syncthreads();
+            S0 = 0;
+            for (int q = 0; q < NB_T / 64; q++) S0 += wsum[q];
+            last = -(1LL << 40);
+            __syncthreads();
+        }
+        // a thread's eight samples of a tile as raw words, fetched one tile ahead: 12 words (24 bit) or 8 (16 bit); a
+        // thread's samples start at a multiple of eight, which divides 240 and 256: they lie in ONE datagram
+        constexpr int NW = FMT == 1444 ? 12 : 8;
+        unsigned pw[NW];
+        auto fetch = [&](long b0) {
+            const unsigned i0 = (unsigned)(b0 + (long)t * NB_PER);
+            if ((long)i0 + NB_PER <= seg_b) {
+                const unsigned *wp;
+                if constexpr (FMT == 1444) { const unsigned q = i0 / 240u, j = i0 - q * 240u; wp = reinterpret_cast<const unsigned *>(pk + (q * 1444u + 4u + 6u * j)); }
+                else wp = reinterpret_cast<const unsigned *>(pk + ((i0 >> 8) * 1028u + 4u + 4u * (i0 & 255u)));
+#pragma unroll
+                for (int k = 0; k < NW; k++) pw[k] = wp[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NW; k++) pw[k] = 0u;                       // past the segment: zeros (never counted: r >= nvalid)
+                // (a thread that straddles the end cannot exist: seg_b is a multiple of eight -- whole datagrams)
+            }
+        };
+        auto iabs = [](int v) -> int { return v < 0 ? -v : v; };
+        fetch(first);
+        int rb = rslot(first);
+        for (long base = first; base < seg_b; base += NB_TILE) {
+            int mag[NB_PER];
+            if constexpr (FMT == 1444) {
+#pragma unroll
+                for (int p = 0; p < NB_PER / 2; p++) {
+                    const unsigned d0 = pw[3 * p], d1 = pw[3 * p + 1], d2 = pw[3 * p + 2];
+                    const int i0 = (int)(d0 << 8), q0 = (int)(((d0 >> 24) << 8) | (d1 << 16));
+                    const int i1 = (int)(((d1 >> 16) << 8) | (d2 << 24)), q1 = (int)(d2 & 0xffffff00u);
+                    // |x| of a multiple of 256 as unsigned, then >> 8 (0x80000000 -> 2^23)
+                    auto m24 = [](int x, int y) -> int {
+                        const unsigned ax = x < 0 ? 0u - (unsigned)x : (unsigned)x, ay = y < 0 ? 0u - (unsigned)y : (unsigned)y;
+                        return (int)((ax > ay ? ax : ay) >> 8);
+                    };
+                    mag[2 * p] = m24(i0, q0); mag[2 * p + 1] = m24(i1, q1);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) {
+                    const int i = (int)(short)(pw[k] & 0xffffu), q = (int)(short)(pw[k] >> 16);
+                    const int ai = iabs(i), aq = iabs(q);
+                    mag[k] = (ai > aq ? ai : aq) << 8;
+                }
+            }
+            // the magnitudes leaving the window: NB_PER / 4 + 1 aligned 16-byte reads of the ring, picked apart by the offset
+            int far[NB_PER];
+            {
+                int f0 = rb - M1 + t * NB_PER;
+                f0 = f0 < 0 ? f0 + NB_RING : f0;
+                const int4 *src = reinterpret_cast<const int4 *>(ring);
+                int q[NB_PER + 4];
+#pragma unroll
+                for (int v = 0; v <= NB_PER / 4; v++) {
+                    int fv = (f0 >> 2) + v;
+                    fv = fv >= NB_RING / 4 ? fv - NB_RING / 4 : fv;
+                    const int4 w4 = src[fv];
+                    q[4 * v] = w4.x; q[4 * v + 1] = w4.y; q[4 * v + 2] = w4.z; q[4 * v + 3] = w4.w;
+                }
+                switch ((unsigned)(-M1) & 3u) {
+#define NB_PICK(O_) case O_: _Pragma("unroll") for (int k = 0; k < NB_PER; k++) far[k] = q[O_ + k]; break;
+                    NB_PICK(0) NB_PICK(1) NB_PICK(2) default: NB_PICK(3)
+#undef NB_PICK
+                }
+            }
+            const long left = seg_b - base, lead = seg_a - base;
+            const int nvalid = left < NB_TILE ? (int)left : NB_TILE, nskip = lead > 0 ? (int)lead : 0;
+            const bool live = t * NB_PER < nvalid;          // (nvalid is a multiple of eight: a thread is in or out whole)
+            int d[NB_PER], run = 0, mmax = 0, dmin = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < NB_PER; k++) {
+                if (!live) mag[k] = 0;
+                run += live ? mag[k] - far[k] : 0;
+                d[k] = run;                                 // thread-local inclusive prefix (|.| < 2^26)
+                mmax = mag[k] > mmax ? mag[k] : mmax;
+                dmin = run < dmin ? run : dmin;
+            }
+            {
+                int4 *dst = reinterpret_cast<int4 *>(ring) + ((rb + t * NB_PER) >> 2);
+                dst[0] = make_int4(mag[0], mag[1], mag[2], mag[3]);
+                dst[1] = make_int4(mag[4], mag[5], mag[6], mag[7]);
+            }
+            if (base + NB_TILE < seg_b) fetch(base + NB_TILE);
+            const long long incl = wave_incl_scan_add_i64((long long)run);
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            long long off = S0 + (incl - run);
+            for (int q = 0; q < w; q++) off += wsum[q];
+            long long total = 0;
+            for (int q = 0; q < NB_T / 64; q++) total += wsum[q];
+            // triggers: once per thread in fp32 (largest magnitude against the smallest sum, 4e-6 of margin against the 6e-8 of
+            // the three roundings); only a thread with a candidate runs the exact tests
+            const long long ago = last - (long long)base;
+            const int last_rel = ago < (long long)NB_NEVER ? NB_NEVER : (int)ago;
+            int lt[NB_PER], runmax = NB_NEVER;
+            const bool candidate = live && (float)mmax * ratio_hi >= (float)(off + (long long)dmin);
+            if (candidate) {
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) {
+                    const int r = t * NB_PER + k;
+                    const bool trig = (double)mag[k] * ratio > (double)(off + (long long)d[k]);
+                    if (trig) runmax = r;
+                    lt[k] = runmax;
+                }
+            }
+            const int inclm = wave_incl_scan_max(runmax, lane);
+            if (lane == 63) wmax[w] = inclm;
+            __syncthreads();
+            int before = last_rel;
+            for (int q = 0; q < w; q++) before = wmax[q] > before ? wmax[q] : before;
+            const int upto = wave_prev_lane(inclm);
+            if (upto > before) before = upto;
+            int tile_last = NB_NEVER;
+            for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
+            {
+                constexpr int LPW = 32 / NB_PER;
+                unsigned nib = 0;
+                if (live) {
+                    if (candidate) {
+#pragma unroll
+                        for (int k = 0; k < NB_PER; k++) {
+                            const int r = t * NB_PER + k;
+                            const int l = lt[k] > before ? lt[k] : before;
+                            if (r - l < W) nib |= 1u << k;
+                        }
+                    } else {
+                        // no trigger among this thread's samples: sample r is blanked while r - before < W
+                        const int nb = W + before - t * NB_PER;                 // how many of the eight, from the first
+                        nib = nb <= 0 ? 0u : (nb >= NB_PER ? 0xffu : (1u << nb) - 1u);
+                    }
+                }
+                unsigned wv = nib << (NB_PER * (lane & (LPW - 1)));
+#pragma unroll
+                for (int sh = 1; sh < LPW; sh <<= 1) wv |= (unsigned)__shfl_xor((int)wv, sh);
+                if ((lane & (LPW - 1)) == 0 && nskip == 0 && live) mrow[(base + (long)t * NB_PER) >> 5] = wv;
+            }
+            S0 += total;
+            rb += NB_TILE; rb = rb >= NB_RING ? rb - NB_RING : rb;
+            if (tile_last > NB_NEVER) last = (long long)base + tile_last;
+            __syncthreads();
+        }
+        if (t == 0 && last_seg) {
+            NbChan N = C;
+            N.sum = (double)S0 * (1.0 / 256.0);
+            long long age = (long long)n - last;
+            if (age > (1LL << 40)) age = 1LL << 40;
+            N.since_trig = age;
+            a.chan_next[ch] = N;
+        }
+    } else {
+        if (t == 0 && last_seg) a.chan_next[ch] = C;
+        for (long wv = (seg_a >> 5) + t; wv < ((seg_b + 31) >> 5); wv += NB_T) mrow[wv] = 0u;
+    }
+    if (last_seg)
+        for (long j = t; j < NB_HIST; j += NB_T) hist_next[j] = X((long)n - NB_HIST + j);
+}
+
 hipError_t noiseblank_launch(const NbArgs &a, hipStream_t stream)
 {
+    if (a.out == nullptr && a.ring && a.int_ok && a.wire.pk) {      // datagrams in, mask out, integral state: the integer form
+        if (a.wire.pkt_len == 1444) {
+            hipError_t e = CSDR_MAX_LDS_ONCE((&noiseblank_mask_int_kernel<1444>), NB_RING * 4);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((noiseblank_mask_int_kernel<1444>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
+        } else {
+            hipError_t e = CSDR_MAX_LDS_ONCE((&noiseblank_mask_int_kernel<1028>), NB_RING * 4);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((noiseblank_mask_int_kernel<1028>), dim3(a.channels * a.nseg), dim3(NB_T), NB_RING * 4, stream, a);
+        }
+        return hipGetLastError();
+    }
     if (a.out == nullptr && a.ring) {
         hipError_t e = CSDR_MAX_LDS_ONCE((&noiseblank_kernel<true, true>), NB_RING * 4);
         if (e != hipSuccess) return e;

@@ -531,3 +531,80 @@ def test_pipelined_blanked_rows_give_the_strict_mode_words():
         for c in range(Cn):
             assert len(outs[0][k][c]) > 0
             assert np.array_equal(outs[0][k][c].view(np.uint32), outs[1][k][c].view(np.uint32)), (k, c)
+
+
+@pytest.mark.parametrize("src", [1028, 1444])
+def test_integer_mask_kernel_decides_what_the_general_one_does(oracle, src):
+    """Round 6: on datagram input the mask pass runs in integers (noiseblank_mask_int_kernel: magnitudes and moving sums
+    as integers in units of 2^-8, the trigger test screened once per thread in fp32, the exact fp64 test only for threads
+    with a candidate).  Same datagrams through the general kernel (csdr__noiseproc_set_int(0)) and through the integer
+    one: every mask word equal, call after call (the state each leaves feeds the next call), thresholds low enough for
+    hundreds of triggers and blank windows that cross tiles, segments and calls; and after a call on FLOAT rows the
+    object falls back to the general kernel by itself (its sums are no longer integral) and still matches."""
+    import ctypes as C_
+    import cutesdr_amd as ca
+    L = ca.lib()
+    L.csdr__noiseproc_set_int.restype = C_.c_int
+    L.csdr__noiseproc_set_int.argtypes = [C_.c_int]
+    L.csdr__noiseproc_batch_mask.restype = C_.c_int
+    L.csdr__noiseproc_batch_mask.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_longlong, C_.c_void_p, C_.c_int, C_.c_int, C_.c_int,
+                                             C_.c_void_p, C_.c_longlong, C_.POINTER(C_.c_void_p), C_.POINTER(C_.c_void_p),
+                                             C_.c_void_p]
+    Cn, fs = 5, 2e6
+    per = 240 if src == 1444 else 256
+    counts = [2000, 7, 900, 1, 3000]
+    tot = sum(counts) * per
+    rng = np.random.default_rng(29)
+    x = [900.0 * (1 + c) * (rng.standard_normal(tot) + 1j * rng.standard_normal(tot)) for c in range(Cn)]
+    for xc in x:
+        xc[rng.random(tot) < 4e-4] += 20000.0
+        xc[tot // 3:tot // 3 + 3000] *= 0.01                   # a quiet stretch: the sum falls, the next impulse triggers harder
+    raw = np.stack([(_pack24 if src == 1444 else _pack16)(xc) for xc in x])
+    rows_call = 2                                              # after this call one float-rows call is put in between
+    xs = [oracle.unpack_packets(raw[c], src).astype(np.complex64) for c in range(Cn)]
+
+    def run(int_on):
+        assert L.csdr__noiseproc_set_int(int_on) == int_on
+        nb = ca.NoiseProcBatch(Cn)
+        for c in range(Cn):
+            nb.setup(True, 12.0 + 3.0 * c, 15.0 + 40.0 * c, fs, channel=c)
+        masks, k0 = [], 0
+        for call, npk in enumerate(counts):
+            n = npk * per
+            words = (n + 31) // 32 + 64
+            dm = ca.DeviceBuffer(Cn * words * 4)
+            st, hi = C_.c_void_p(), C_.c_void_p()
+            if call == rows_call + 1:                          # the same samples as float rows: the object leaves the integer form
+                part = np.ascontiguousarray(np.stack([xc[k0 * per:k0 * per + n] for xc in xs]))
+                dp = ca.DeviceBuffer(part.nbytes); dp.upload(part)
+                rc = L.csdr__noiseproc_batch_mask(nb.h, C_.c_void_p(dp.ptr), n, None, 0, 0, n, C_.c_void_p(dm.ptr), words,
+                                                  C_.byref(st), C_.byref(hi), None)
+            else:
+                part = np.ascontiguousarray(raw[:, k0:k0 + npk])
+                dp = ca.DeviceBuffer(part.nbytes); dp.upload(part)
+                rc = L.csdr__noiseproc_batch_mask(nb.h, None, 0, C_.c_void_p(dp.ptr), npk, src, n, C_.c_void_p(dm.ptr), words,
+                                                  C_.byref(st), C_.byref(hi), None)
+            assert rc == 0
+            ca.sync()
+            masks.append(dm.download(np.uint32, Cn * words).reshape(Cn, words)[:, :(n + 31) // 32].copy())
+            k0 += npk
+        return masks
+    try:
+        general = run(0)
+        integer = run(1)
+    finally:
+        L.csdr__noiseproc_set_int(1)
+    blanked = 0
+    for call, (g, i) in enumerate(zip(general, integer)):
+        assert np.array_equal(g, i), (call, np.nonzero(g != i))
+        blanked += int(np.unpackbits(i.view(np.uint8)).sum())
+    assert blanked > 2000                                      # hundreds of triggers, each a window of 30 ... 350 samples
+    # and the integer run against the oracle's blanker, channel 0, first call (what test_blank_mask_is_bit_exact does for all)
+    q = oracle.CNoiseProc(); q.SetupBlanker(True, 12.0, 15.0, fs)
+    n0 = counts[0] * per
+    delay1 = int(15.0 * 1e-6 * fs) // 2 + 1
+    bits = ((integer[0][0, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:n0].astype(bool)
+    idx = np.arange(n0) - delay1
+    delayed = np.where(idx >= 0, xs[0][np.maximum(idx, 0)], 0).astype(np.complex64)
+    want = q.ProcessBlanker(xs[0][:n0].astype(np.complex128)).astype(np.complex64)
+    assert np.array_equal(np.where(bits, np.complex64(0), delayed), want)
