@@ -563,10 +563,19 @@ void noiseblank_mask_int_kernel(NbArgs a)
             const long long incl = wave_incl_scan_add_i64((long long)run);
             if (lane == 63) wsum[w] = incl;
             __syncthreads();
-            long long off = S0 + (incl - run);
-            for (int q = 0; q < w; q++) off += wsum[q];
-            long long total = 0;
-            for (int q = 0; q < NB_T / 64; q++) total += wsum[q];
+            // the waves' sums: lane q < 8 reads wave q's, a three-step prefix inside the first row, two broadcasts (instead
+            // of sixteen LDS reads per thread)
+            long long ws = lane < NB_T / 64 ? wsum[lane] : 0;
+            ws += (long long)nb_dpp64<0x111, 0xf>((unsigned long long)ws, 0ull);
+            ws += (long long)nb_dpp64<0x112, 0xf>((unsigned long long)ws, 0ull);
+            ws += (long long)nb_dpp64<0x114, 0xf>((unsigned long long)ws, 0ull);
+            const int wu = __builtin_amdgcn_readfirstlane(w);
+            auto lane_of = [](long long v, int l) -> long long {
+                return (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), l) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)v, l));
+            };
+            const long long total = lane_of(ws, NB_T / 64 - 1);
+            const long long off = S0 + (incl - run) + (wu > 0 ? lane_of(ws, wu - 1) : 0);
             // triggers: once per thread in fp32 (largest magnitude against the smallest sum, 4e-6 of margin against the 6e-8 of
             // the three roundings); only a thread with a candidate runs the exact tests
             const long long ago = last - (long long)base;
@@ -585,12 +594,15 @@ void noiseblank_mask_int_kernel(NbArgs a)
             const int inclm = wave_incl_scan_max(runmax, lane);
             if (lane == 63) wmax[w] = inclm;
             __syncthreads();
+            int wm = lane < NB_T / 64 ? wmax[lane] : NB_NEVER;
+            { const int o = __builtin_amdgcn_update_dpp(NB_NEVER, wm, 0x111, 0xf, 0xf, false); wm = o > wm ? o : wm; }
+            { const int o = __builtin_amdgcn_update_dpp(NB_NEVER, wm, 0x112, 0xf, 0xf, false); wm = o > wm ? o : wm; }
+            { const int o = __builtin_amdgcn_update_dpp(NB_NEVER, wm, 0x114, 0xf, 0xf, false); wm = o > wm ? o : wm; }
             int before = last_rel;
-            for (int q = 0; q < w; q++) before = wmax[q] > before ? wmax[q] : before;
+            if (wu > 0) { const int o = __builtin_amdgcn_readlane(wm, wu - 1); before = o > before ? o : before; }
             const int upto = wave_prev_lane(inclm);
             if (upto > before) before = upto;
-            int tile_last = NB_NEVER;
-            for (int q = 0; q < NB_T / 64; q++) tile_last = wmax[q] > tile_last ? wmax[q] : tile_last;
+            const int tile_last = __builtin_amdgcn_readlane(wm, NB_T / 64 - 1);
             {
                 constexpr int LPW = 32 / NB_PER;
                 unsigned nib = 0;
@@ -608,15 +620,17 @@ void noiseblank_mask_int_kernel(NbArgs a)
                         nib = nb <= 0 ? 0u : (nb >= NB_PER ? 0xffu : (1u << nb) - 1u);
                     }
                 }
+                static_assert(LPW == 4, "four lanes make a mask word: one quad");
                 unsigned wv = nib << (NB_PER * (lane & (LPW - 1)));
-#pragma unroll
-                for (int sh = 1; sh < LPW; sh <<= 1) wv |= (unsigned)__shfl_xor((int)wv, sh);
+                wv |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)wv, 0xb1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+                wv |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)wv, 0x4e, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
                 if ((lane & (LPW - 1)) == 0 && nskip == 0 && live) mrow[(base + (long)t * NB_PER) >> 5] = wv;
             }
             S0 += total;
             rb += NB_TILE; rb = rb >= NB_RING ? rb - NB_RING : rb;
             if (tile_last > NB_NEVER) last = (long long)base + tile_last;
-            __syncthreads();
+            // (no barrier here: wsum is next written behind this tile's second barrier, which every wave reaches only after
+            // its reads of wsum; wmax is next written behind the NEXT tile's first barrier, reached only after the reads of wmax)
         }
         if (t == 0 && last_seg) {
             NbChan N = C;
