@@ -1192,8 +1192,8 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         k.pk = d_packets; k.pk_len = pkt_len;            // this call's input as datagrams, or nullptr
         k.blank = blank;                                  // this call's blanker mask, or nullptr
         hipStream_t st = forked ? b->streams[ki] : caller;
-        if (strict_multi) csdr__downconvert_batch_set_wgs(k.dc, oi > 0 ? corun_wgs[oi > 1 ? 1 : 0] : (blank ? corun_wgs[1] : 0));
-        else csdr__downconvert_batch_set_wgs(k.dc, blank ? corun_wgs[1] : 0);     // (the blanked kernel: three waves per SIMD)
+        if (strict_multi) csdr__downconvert_batch_set_wgs(k.dc, oi > 0 ? corun_wgs[oi > 1 ? 1 : 0] : 0);
+        else csdr__downconvert_batch_set_wgs(k.dc, 0);
         if (forked) CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
         // pipelined: the caller's stream catches up with the PREVIOUS call only now, behind this call's fork
         // event, so that this call's down-converter is not held back by it: previous input consumed, output

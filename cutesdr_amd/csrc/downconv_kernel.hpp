@@ -305,14 +305,8 @@ __device__ __forceinline__ float dc_rotl1(float v)
 #ifndef CSDR_DC_WAVES_PER_EU
 #define CSDR_DC_WAVES_PER_EU 4
 #endif
-// (BLK: the blanked form carries the mask words and the delayed samples -- at four waves per SIMD, 128 registers, it spilled
-// 132-144 bytes per lane; it is compiled for three (168 registers, no scratch) and launched as at most 12 waves per CU, which
-// costs the plain kernel 6 % alone and is what the groups behind the first run at anyway: capi_demod.hip)
-#ifndef CSDR_DC_BLK_WAVES_PER_EU
-#define CSDR_DC_BLK_WAVES_PER_EU 3
-#endif
 template <class P, bool BLK = false>
-__global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(BLK ? CSDR_DC_BLK_WAVES_PER_EU : CSDR_DC_WAVES_PER_EU, BLK ? CSDR_DC_BLK_WAVES_PER_EU : CSDR_DC_WAVES_PER_EU)))
+__global__ __launch_bounds__(DC_T) __attribute__((amdgpu_waves_per_eu(CSDR_DC_WAVES_PER_EU, CSDR_DC_WAVES_PER_EU)))
 void downconv_kernel(DcArgs a)
 {
     constexpr bool FIX = P::NS >= 0;                      // compile-time plan
