@@ -591,7 +591,8 @@ void noiseblank_mask_int_kernel(NbArgs a)
                     lt[k] = runmax;
                 }
             }
-            const int inclm = wave_incl_scan_max(runmax, lane);
+            // (a wave without a candidate -- nearly every wave of nearly every tile -- has no trigger: no scan)
+            const int inclm = __any(candidate) ? wave_incl_scan_max(runmax, lane) : NB_NEVER;
             if (lane == 63) wmax[w] = inclm;
             __syncthreads();
             int wm = lane < NB_T / 64 ? wmax[lane] : NB_NEVER;
