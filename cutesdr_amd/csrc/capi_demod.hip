@@ -7,6 +7,7 @@
 #include "dc_host.hpp"
 #include "stream_pool.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -426,6 +427,7 @@ struct csdr_demod_batch {
     hipEvent_t fork = nullptr;
     bool pipelined = false;                           // csdr_demod_batch_set_pipelined
     int taps = 0;                                     // csdr_demod_batch_set_taps (new groups inherit it)
+    bool rate_change_failed = false;                  // csdr_demod_batch_set_input_rate stopped half way: no processing until one succeeds
     std::vector<int> prev_post;                       // pipelined: per core, the post-chain event of the previous call
     std::vector<char> prev_join;                      // pipelined: per core, joins[] of the previous call not yet waited for
     float *d_blank = nullptr;                         // blanked input of process_packets (two-pass form)
@@ -660,10 +662,11 @@ int csdr_demod_set_input_rate(csdr_demod *d, double rate)
 {
     if (!d) return fail(CSDR_EINVAL, "bad handle");
     if (d->s) CSDR_HIP(hipStreamSynchronize(d->s));   // control plane: a pass that returned no samples may still be in flight
+    if (!(rate > 0.0) || !std::isfinite(rate)) return fail(CSDR_EINVAL, "input rate %g", rate);
     if (d->in_rate != rate) {
-        d->in_rate = rate;
         const double r = csdr_downconvert_batch_set_data_rate(d->k.dc, 0, rate, d->c.want_bw);
-        if (r < 0) return CSDR_EHIP;
+        if (r < 0) return CSDR_EHIP;                      // (in_rate keeps its old value: the same call again is not a no-op)
+        d->in_rate = rate;
         d->c.out_rate = r;
         // Everything else stays as it is until the next SetDemod: filter taps, AGC constants and rings, m_InBufLimit and
         // the demodulator object (built for the OLD output rate; a same-mode SetDemod does not rebuild it,
@@ -880,8 +883,8 @@ void csdr_demod_batch_destroy(csdr_demod_batch *b) { delete b; }
 int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate)
 {
     if (!b) return fail(CSDR_EINVAL, "bad handle");
-    if (b->cores.empty() || rate == b->in_rate) { b->in_rate = rate; return CSDR_OK; }
-    if (!(rate > 0.0)) return fail(CSDR_EINVAL, "input rate %g", rate);
+    if (!(rate > 0.0) || !std::isfinite(rate)) return fail(CSDR_EINVAL, "input rate %g", rate);     // before anything records it
+    if (b->cores.empty() || (rate == b->in_rate && !b->rate_change_failed)) { b->in_rate = rate; return CSDR_OK; }
     if (!device_ok(b->device)) return CSDR_EHIP;
     CSDR_HIP(hipDeviceSynchronize());                  // control plane: nothing of this batch in flight from here on
     // ---- plan (nothing changes yet): every receiver's new stage count, every group's (its first live row's)
@@ -910,11 +913,15 @@ int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate)
         for (size_t q = 0; q < b->members[ki].size(); q++) {
             const int c = b->members[ki][q];
             if (c >= 0 && stages[c] != group_stages[ki]) { movers.push_back(c); continue; }
-            if (c >= 0) { const int rc = apply_input_rate(k, (int)q, b->cfg[c], rate); if (rc) return rc; }
-            else if (group_stages[ki] >= 0 && csdr_downconvert_batch_set_data_rate(k.dc, (int)q, rate, group_bw[ki]) < 0) return CSDR_EHIP;
+            // (from the first row that has taken the new rate a failure leaves the groups' rows on DIFFERENT decimations while
+            // the staging is sized from row 0: the batch refuses to process until a set_input_rate has gone through -- the
+            // same call again finishes the job, every step above is idempotent)
+            if (c >= 0) { const int rc = apply_input_rate(k, (int)q, b->cfg[c], rate); if (rc) { b->rate_change_failed = true; return rc; } }
+            else if (group_stages[ki] >= 0 && csdr_downconvert_batch_set_data_rate(k.dc, (int)q, rate, group_bw[ki]) < 0) { b->rate_change_failed = true; return CSDR_EHIP; }
         }
     }
     b->in_rate = rate;
+    b->rate_change_failed = false;
     // ---- the others move, with all their state, like a receiver whose new mode decimates differently; the row each
     // leaves behind is muted and takes its old group's new chain
     int err = CSDR_OK;
@@ -933,6 +940,7 @@ int csdr_demod_batch_set_input_rate(csdr_demod_batch *b, double rate)
         if (!alone && still && csdr_downconvert_batch_set_data_rate(A->dc, r, rate, bw) < 0 && !err) err = CSDR_EHIP;
     }
     batch_order(b);
+    if (err) b->rate_change_failed = true;               // a receiver that should have moved did not: see above
     return err;
 }
 /* Configure every channel, then call csdr_demod_batch_commit() once: channels that decimate by
@@ -1127,6 +1135,8 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
 {
     if (!b || (!d_in && !d_packets) || !d_out) return fail(CSDR_EINVAL, "bad argument");
     if (b->cores.empty()) return fail(CSDR_ESTATE, "commit first");
+    if (b->rate_change_failed)
+        return fail(CSDR_ESTATE, "a csdr_demod_batch_set_input_rate failed half way (rows of one group decimate differently): call it again");
     if (!device_ok(b->device)) return CSDR_EHIP;
     hipStream_t caller = (hipStream_t)stream;
     const bool forked = b->cores.size() > 1 || b->pipelined;

@@ -138,6 +138,13 @@ void fastfir_os2_kernel(FastFirArgs a)
     const int b0 = run * a.blocks_per_run;
     int b1 = b0 + a.blocks_per_run;
     if (b1 > a.nblocks) b1 = a.nblocks;
+    // VW == 2 (N = 4096): the two virtual workgroups of a real one share its s_barrier, and one of them may END here -- or
+    // walk one block fewer in the last run -- while the other keeps arriving at barriers.  That is defined on this target:
+    // the gfx9 barrier counts the waves of the workgroup that have not terminated (an s_endpgm wave leaves the count), so
+    // the survivor's barriers complete with its own waves.  The HIP model does not promise it, the build pins the target:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fastfir_os2_kernel<12> relies on gfx950's s_barrier ignoring terminated waves (two virtual workgroups per workgroup)"
+#endif
     if (ch >= a.channels || b0 >= b1) return;          // uniform per (virtual) workgroup
 
     if constexpr (VW == 1)

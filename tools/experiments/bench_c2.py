@@ -4,7 +4,7 @@
 measurement: a single receiver cannot fill the chip, this is its latency-bound rate."""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import cutesdr_amd as ca
 T = 1 << 24

@@ -3,7 +3,7 @@
 without the rest of the line (for A/B runs of chain experiments: CSDR_LIB_PATH=<alt build> python tools/bench_c4_modes.py)."""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import cutesdr_amd as ca
 import bench

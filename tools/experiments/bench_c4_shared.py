@@ -4,7 +4,7 @@ shared input instead of one stream per receiver -- the down-converters read 16 M
    usage: tools/bench_c4_shared.py [streams, default 1]"""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import numpy as np
 import torch
 import cutesdr_amd as ca

@@ -3,7 +3,7 @@
 drop-in classes): complex doubles in host memory in, results in host memory out, one channel.
 Secondary measurement for DESIGN.md section 6 -- never the bench.py value."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import numpy as np
 import cutesdr_amd as ca
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The noise blanker alone on 256 receivers x 2^21 samples (for counter passes: rocprofv3 --pmc ... -- python3 tools/bench_k6_only.py)"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import cutesdr_amd as ca
 C, T = 256, 1 << 21

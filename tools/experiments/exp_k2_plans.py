@@ -3,7 +3,7 @@
 maximum bandwidth): ms per launch by stage sequence.  (GPU box)"""
 import sys, json
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch, cutesdr_amd as ca
 C,T=256,1<<21
 dev=torch.device("cuda",0); st=torch.cuda.current_stream().cuda_stream

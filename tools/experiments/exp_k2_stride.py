@@ -2,7 +2,7 @@
 """K2 alone on 256 ch x 2^21 with the channel rows at a power-of-two pitch and at padded pitches: do all
 workgroups marching through rows 16 MiB apart camp on the same HBM channels?  (experiment, GPU box)"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import cutesdr_amd as ca
 C, T = 256, 1 << 21

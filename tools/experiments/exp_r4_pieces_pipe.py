@@ -3,7 +3,7 @@
 pieces inside the library would cost): P = 1, 2, 4."""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import cutesdr_amd as ca
 import bench

@@ -3,7 +3,7 @@
 GPU needs to run it: if the first is not well below the second the chain is launch-bound."""
 import os, sys, time, json
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import bench, cutesdr_amd as ca
 ctx = bench.dist_init()

@@ -2,7 +2,7 @@
 """Host time of each pipelined csdr_demod_batch call on the C4 share (is the host ahead of the GPU?)."""
 import json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # the repo root
 import torch
 import cutesdr_amd as ca
 import bench

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/k6t
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 tools/bench_blank_widths.py > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 tools/experiments/bench_blank_widths.py > $OUT/log.txt 2>&1
 tail -1 $OUT/log.txt
 python3 - <<'PY'
 import csv, glob

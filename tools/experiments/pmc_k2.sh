@@ -3,8 +3,8 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/k2pmc2
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH --output-format csv -d $OUT/a -- python3 tools/exp_k2_stride.py 0 > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/b -- python3 tools/exp_k2_stride.py 0 > $OUT/b.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH --output-format csv -d $OUT/a -- python3 tools/experiments/exp_k2_stride.py 0 > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/b -- python3 tools/experiments/exp_k2_stride.py 0 > $OUT/b.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 for tag in "ab":
