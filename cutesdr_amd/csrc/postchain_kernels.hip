@@ -130,6 +130,36 @@ struct SqLds {
 
 __device__ __forceinline__ double wrap_turn(double a) { return a - rint(a); }    // [-0.5, 0.5]
 
+// An EXACTLY ZERO sample in front of a PLL (round 6).  The kernels run the loops in the phase domain -- theta = arg(x), error
+// = -wrap(theta + phi) -- and a zero has no argument.  The reference (fmdemod.cpp:166-172, samdemod.cpp:83-89 / 120-126) rotates
+// first, t = x (cos phi + j s sin phi), and takes atan2(t.im, t.re): for x = (+-0, +-0) the products are signed zeros, their
+// sum / difference is a signed zero by IEEE 754 (a - b = -0 only for (-0) - (+0); a + b = -0 only for (-0) + (-0)), and
+// atan2(+-0, +0) = +-0 but atan2(+-0, -0) = +-pi: depending on the QUADRANT of phi the loop is left alone or kicked by half a
+// turn.  Zeros are not exotic: the AGC's delay line is zeros for the first 15 ms of every stream, a muted input is zeros, and
+// an fp32 filter's start-up is full of them (its samples are small multiples of one quantum) -- until round 5 the kernels
+// took theta = 0 there, the error -wrap(phi), and the first burst of an FM receiver fed the SAME filter output differed from
+// the reference's arithmetic by up to 0.6 of full scale (tests/test_randomized_gpu.py's loop-only check).
+// The tile's theta array carries a zero sample as the code 4 + signbit(re) + 2 signbit(im) (no angle is beyond 0.5 turns).
+__device__ __forceinline__ float pll_theta_of(float re, float im)
+{
+    if (re == 0.f && im == 0.f) return 4.0f + (float)(__float_as_uint(re) >> 31) + 2.0f * (float)(__float_as_uint(im) >> 31);
+    return atan2f(im, re) * 0.15915494309189535f;                  // 1 / 2 pi
+}
+__device__ __forceinline__ bool pll_theta_is_zero_code(float v) { return v >= 3.5f; }
+// the reference's phase error (turns) on such a sample; p = phi in turns, sgn = the sign s above (FM: +1; the error is -sgn atan2)
+__device__ __forceinline__ double pll_zero_err(float code, double p, double sgn)
+{
+    const int bits = (int)code - 4;
+    const bool sxr = bits & 1, sxi = bits & 2;
+    const double fr = p - floor(p);                                    // [0, 1)
+    const bool sc = fr > 0.25 && fr < 0.75;                            // cos(2 pi p) < 0
+    const bool ss = (fr > 0.5) != (sgn < 0.0);                         // s sin(2 pi p) negative (-0 included: -1 x (+0))
+    const bool neg_re = (sc != sxr) && !(ss != sxi);                   // c xr - s xi = -0
+    const bool neg_im = (sc != sxi) && (ss != sxr);                    // c xi + s xr = -0
+    const double a = neg_re ? (neg_im ? -0.5 : 0.5) : 0.0;             // atan2(t.im, t.re) in turns
+    return -sgn * a;
+}
+
 // A wave's scan steps on the DPP network instead of __shfl_up (two ds_bpermute per double and step: an LDS-pipe
 // round trip each, and a tile runs some ninety such steps one after the other on a single wave per SIMD).
 // pc_dpp<CTRL, ROW_MASK>(v, ident): v of the source lane, `ident` where the step has none.  The six steps
@@ -790,8 +820,10 @@ __device__ __forceinline__ bool pll_scan(const Wg<NW> &g, const float *th, int n
     const int base = LC * g.t;
     int cnt = n - base; cnt = cnt < 0 ? 0 : (cnt > LC ? LC : cnt);
     float tv[LC];
+    bool zero = false;
 #pragma unroll
-    for (int j = 0; j < LC; j++) tv[j] = j < cnt ? th[base + j] : 0.f;
+    for (int j = 0; j < LC; j++) { tv[j] = j < cnt ? th[base + j] : 0.f; zero = zero || pll_theta_is_zero_code(tv[j]); }
+    if (g.any(zero)) return false;                                   // an exactly zero sample has no phase: the exact walks take the tile
     // unwrapped input phase relative to the first sample of the tile
     float last = tv[0];
 #pragma unroll
@@ -876,7 +908,7 @@ __device__ __forceinline__ bool pll_overlap(const Wg<NW> &g, const float *th, in
     const bool exact = i <= 0;
     if (exact) { i = 0; p = ph; f = fr; }
     auto step = [&](float v) {                                  // fmdemod.cpp:166-177, in turns
-        const double err = -wrap_turn((double)v + p);
+        const double err = pll_theta_is_zero_code(v) ? pll_zero_err(v, p, 1.0) : -wrap_turn((double)v + p);
         f = fmin(fmax(f + beta * err, lo), hi);
         p = wrap_turn(p + f + alpha * err);
     };
@@ -1234,7 +1266,7 @@ void postchain_kernel(PcArgs a)
             } else {
                 // PLL modes: theta = arg(x) for the whole tile, in turns
                 float *th = S.w1 + (nt - 1), *au = S.w0 + (nt - 1);
-                for (int i = t; i < n; i += NT) th[i] = atan2f(x[i].y, x[i].x) * (float)kInvTwoPiD;
+                for (int i = t; i < n; i += NT) th[i] = pll_theta_of(x[i].x, x[i].y);
                 g.sync();
                 PC_TICK(7);
                 if (mode == PC_MODE_FM) {
@@ -1262,7 +1294,7 @@ void postchain_kernel(PcArgs a)
                             const double beta = F.beta, alpha = F.alpha, hi = F.hi * kInvTwoPiD, lo = F.lo * kInvTwoPiD;
                             double ph = fm_ph * kInvTwoPiD, fr = fm_fr * kInvTwoPiD;
                             seq_walk(th, n, [&](float v, int i) {              // fmdemod.cpp:166-177
-                                const double err = -wrap_turn((double)v + ph);
+                                const double err = pll_theta_is_zero_code(v) ? pll_zero_err(v, ph, 1.0) : -wrap_turn((double)v + ph);
                                 fr = fmin(fmax(fr + beta * err, lo), hi);
                                 ph = wrap_turn(ph + fr + alpha * err);
                                 au[i] = (float)fr;                             // NCO frequency, turns per sample
@@ -1324,7 +1356,7 @@ void postchain_kernel(PcArgs a)
                             double ph = sam_ph * kInvTwoPiD, fr = sam_fr * kInvTwoPiD;
                             seq_walk(th, n, [&](float v, int i) {
                                 S.w2[i] = (float)ph;                          // phase used for this sample (turns)
-                                const double err = -sgn * wrap_turn((double)v + sgn * ph);
+                                const double err = pll_theta_is_zero_code(v) ? pll_zero_err(v, ph, sgn) : -sgn * wrap_turn((double)v + sgn * ph);
                                 fr = fmin(fmax(fr + beta * err, lo), hi);
                                 ph = wrap_turn(ph + fr + alpha * err);
                             });

@@ -138,10 +138,14 @@ def test_batch_taps_equal_the_single_receivers(oracle):
                 assert np.abs(g3 - w3).max() <= STEADY, (k, c, names[c], np.abs(g3 - w3).max() / FULL_SCALE)
 
 
-def _oracle_post_chain(oracle, mode, stereo, fs_out):
+def _oracle_post_chain(oracle, mode, stereo, fs_out, kw=None):
     """the reference's stages behind the filter as separate oracle objects, configured as CDemodulator::SetDemod does
-    (dsp/demodulator.cpp:107-157): returns f(filter output of one pass) -> (AGC output, audio)"""
-    m, kw = MODES[mode]
+    (dsp/demodulator.cpp:107-157): returns f(filter output of one pass) -> (AGC output, audio).  kw: the receiver's
+    tDemodInfo fields (default: the mode's)"""
+    if mode in ("LSB", "CWU", "CWL"):
+        kw = kw if kw is not None else MODES.get(mode, MODES["USB"])[1]
+    elif kw is None:
+        kw = MODES[mode][1]
     di = info(oracle, **kw)
     agc = oracle.CAgc()
     agc.SetParameters(di.AgcOn, di.AgcHangOn, di.AgcThresh, di.AgcManualGain, di.AgcSlope, di.AgcDecay, fs_out)

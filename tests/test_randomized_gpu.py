@@ -217,6 +217,11 @@ def test_batch_chain_random_receivers(oracle, seed):
     for c, (name, m, kw, off, dbfs) in enumerate(cfg):
         b.set_freq(c, -off)
     assert b.group_count()[0] >= 2                               # the receivers do spread over plan groups
+    # the loop-only check beside the end-to-end one: every receiver's stages behind the filter, as oracle objects,
+    # fed the GPU chain's OWN filter output (stage tap 2 of the batch) -- no start-up allowance at all, from the first sample
+    from test_chain_taps_gpu import _oracle_post_chain
+    b.set_taps(2)
+    post = [_oracle_post_chain(oracle, name, False, refs[c].GetOutputRate(), kw) for c, (name, m, kw, off, dbfs) in enumerate(cfg)]
     a0, first = 0, [0] * C
     for ncall in calls:
         got = b.process(x[:, a0:a0 + ncall])
@@ -225,6 +230,11 @@ def test_batch_chain_random_receivers(oracle, seed):
             assert len(got[c]) == len(want), (seed, c, name)        # (a narrow plan may not fill a hop in a short call)
             if not len(want):
                 continue
+            own = post[c](b.tap(c, 2))[1]
+            loop = T.burst_errors(got[c], own)
+            gain_allow = 1.0 if kw["AgcOn"] else max(1.0, np.abs(own).max() / T.FULL_SCALE)   # (manual gain: audio beyond full scale)
+            assert (loop <= (3e-5 if name == "FM" else 2e-5) * T.FULL_SCALE * gain_allow).all(), \
+                (seed, c, name, "post-chain on its own filter output", loop[:6] / T.FULL_SCALE)
             errs = T.burst_errors(got[c], want)
             # (SAM locking onto a carrier up to 200 Hz off its tuning: 3e-3 ... 2e-2 of full scale in the burst of the
             # pull-in -- by seed and by the last bit of the samples in front of the loop: the same seeds moved between
