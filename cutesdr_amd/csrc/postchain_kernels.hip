@@ -823,7 +823,8 @@ __device__ __forceinline__ bool pll_scan(const Wg<NW> &g, const float *th, int n
     bool zero = false;
 #pragma unroll
     for (int j = 0; j < LC; j++) { tv[j] = j < cnt ? th[base + j] : 0.f; zero = zero || pll_theta_is_zero_code(tv[j]); }
-    if (g.any(zero)) return false;                                   // an exactly zero sample has no phase: the exact walks take the tile
+    // (an exactly zero sample has no phase: the exact walks take the tile -- decided together with the guess's own check at the
+    // end: a vote of its own per tile cost a single receiver's walk 0.4 us per tile, 5 % of a C2 / C5 call)
     // unwrapped input phase relative to the first sample of the tile
     float last = tv[0];
 #pragma unroll
@@ -869,7 +870,7 @@ __device__ __forceinline__ bool pll_scan(const Wg<NW> &g, const float *th, int n
             x0 = x0 + f + alpha * e;
         }
     }
-    if (g.any(bad)) return false;
+    if (g.any(bad || zero)) return false;
     const double nph = mt[0] * ph + mt[1] * fr + vt[0], nfr = mt[2] * ph + mt[3] * fr + vt[1];
     ph = nph - rint(nph); fr = nfr;
     return true;
