@@ -2,7 +2,7 @@
 """Exploration (GPU box): error of the chain against the oracle from sample 0, per FastFIR burst, mono and
 stereo, every mode -- the data behind the bounds in tests/test_chain_parity_gpu.py."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import cutesdr_amd as ca
