@@ -17,6 +17,7 @@
 // CSdrInterface::NcoSpurCalibrate (interface/sdrinterface.cpp:829-848).
 #include "launch_once.hpp"
 #include <cstdlib>
+#include <type_traits>
 #include "frontend_kernels.h"
 
 namespace csdr {
@@ -36,6 +37,9 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
 // word); ring x 8: 1.07 ms (92 registers, 64 KB of ring, two workgroups per CU, one round of 512 workgroups).
 #ifndef NB_PER_THREAD
 #define NB_PER_THREAD 4
+#endif
+#ifndef NB_MASK_PREFETCH
+#define NB_MASK_PREFETCH 2       // tiles the integer mask kernel fetches ahead (1: 760 us, 2 / 3 / 4: 722 / 723 / 724 us for 256 x 2^21 24-bit samples)
 #endif
 #ifndef NB_PER_THREAD_RING
 #define NB_PER_THREAD_RING 8
@@ -425,6 +429,25 @@ void noiseblank_kernel(NbArgs a)
 // for sample.  The host takes this kernel only while EVERY sample the blanker has seen since its last set-up came from
 // datagrams (csdr_noiseproc_batch: datagram_only) -- the state it inherits (sum, history) is then integral in that unit.
 // Ring form only (the window's magnitudes in LDS, as integers); eight samples per thread.
+// |a - b| of two unsigned words, b wave-uniform: one instruction (the compiler has no builtin for it)
+__device__ __forceinline__ unsigned nb_absdiff(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+// the same for a value whose sixteen-lane row sums fit 32 bits (|v| < 2^27): the four steps inside a row are one
+// v_add_u32 with a DPP operand each, only the two steps across rows carry 64 bits
+__device__ __forceinline__ long long wave_incl_scan_add_i27(int v)
+{
+#define NB_STEP(C_, R_) v += __builtin_amdgcn_update_dpp(0, v, C_, R_, 0xf, false);
+    NB_STEP(0x111, 0xf) NB_STEP(0x112, 0xf) NB_STEP(0x114, 0xf) NB_STEP(0x118, 0xf)
+#undef NB_STEP
+    long long w = (long long)v;
+    w += (long long)nb_dpp64<0x142, 0xa>((unsigned long long)w, 0ull);
+    w += (long long)nb_dpp64<0x143, 0xc>((unsigned long long)w, 0ull);
+    return w;
+}
 __device__ __forceinline__ long long wave_incl_scan_add_i64(long long v)
 {
 #define NB_STEP(C_, R_) v += (long long)nb_dpp64<C_, R_>((unsigned long long)v, 0ull);
@@ -441,7 +464,7 @@ void noiseblank_mask_int_kernel(NbArgs a)
     __shared__ long long wsum[NB_T / 64];
     __shared__ int wmax[NB_T / 64];
     extern __shared__ __attribute__((aligned(16))) float nb_ring[];
-    int *ring = reinterpret_cast<int *>(nb_ring);           // [NB_RING] integer magnitudes, units of 2^-8
+    int *ring = reinterpret_cast<int *>(nb_ring);           // [NB_RING] integer magnitudes, units of 2^-8, in eight planes (below)
     const int ch = blockIdx.x / a.nseg, seg = blockIdx.x % a.nseg, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const NbChan C = a.chan[ch];
     unsigned *mrow = a.mask + (long)ch * a.mask_stride;
@@ -462,7 +485,21 @@ void noiseblank_mask_int_kernel(NbArgs a)
         long long S0 = (long long)llrint(C.sum * 256.0);
         long long last = -C.since_trig;
         long first = 0;
-        auto rslot = [](long i) -> int { const int r = (int)(i % NB_RING); return r < 0 ? r + NB_RING : r; };
+        // The ring in EIGHT PLANES: sample s of the stream (counted so that tiles start at multiples of the tile) sits in
+        // plane s mod 8 at word (s div 8) mod NB_RING / 8.  A thread's eight new magnitudes then go to the eight planes at
+        // ONE word index, consecutive lanes to consecutive words (eight conflict-free 4-byte stores at constant offsets);
+        // and the eight leaving the window, M1 samples back, come from the planes (k - M1) mod 8 at one of two word indices,
+        // again lane-consecutive -- where eight consecutive words per thread (32 bytes between lanes) kept the LDS unit busy
+        // 41 % of the kernel with three quarters of that in bank conflicts (tools/experiments/pmc_mask_int.sh)
+        constexpr int PLANE = NB_RING / 8;
+        static_assert((PLANE & (PLANE - 1)) == 0 && NB_TILE / 8 <= PLANE, "plane words are a power of two");
+        auto rslot = [](long i) -> int { return (int)(i & 7) * PLANE + (int)((i >> 3) & (PLANE - 1)); };
+        auto rbase = [](long i) -> int { const int r = (int)(i % NB_RING); return r < 0 ? r + NB_RING : r; };
+        // plane and word step of the k-th sample leaving the window (wave-uniform, fixed for the launch)
+        int far_plane[NB_PER], far_hi[NB_PER];
+        const int far_e0 = (int)((-(long)M1) >> 3);
+#pragma unroll
+        for (int k = 0; k < NB_PER; k++) { far_plane[k] = (int)((k - (long)M1) & 7) * PLANE; far_hi[k] = (int)((k - (long)M1) >> 3) - far_e0; }
         if (seg == 0) {
             for (long k = -(long)M1 + t; k < 0; k += NB_T) ring[rslot(k)] = imag_at(k);
             __syncthreads();
@@ -481,8 +518,11 @@ void noiseblank_mask_int_kernel(NbArgs a)
         // a thread's eight samples of a tile as raw words, fetched one tile ahead: 12 words (24 bit) or 8 (16 bit); a
         // thread's samples start at a multiple of eight, which divides 240 and 256: they lie in ONE datagram
         constexpr int NW = FMT == 1444 ? 12 : 8;
-        unsigned pw[NW];
-        auto fetch = [&](long b0) {
+        // (TWO tiles ahead: the occupancy is LDS's -- two workgroups of 64 KB, four waves per SIMD -- so the registers of a
+        // second buffer are free, and one tile ahead left 48 bytes per lane in flight against an iteration of ~3 us)
+        constexpr int PF = NB_MASK_PREFETCH;
+        unsigned pwq[PF][NW];
+        auto fetch = [&](long b0, unsigned (&pw)[NW]) {
             const unsigned i0 = (unsigned)(b0 + (long)t * NB_PER);
             if ((long)i0 + NB_PER <= seg_b) {
                 const unsigned *wp;
@@ -497,22 +537,37 @@ void noiseblank_mask_int_kernel(NbArgs a)
             }
         };
         auto iabs = [](int v) -> int { return v < 0 ? -v : v; };
-        fetch(first);
-        int rb = rslot(first);
-        for (long base = first; base < seg_b; base += NB_TILE) {
+        fetch(first, pwq[0]);
+#pragma unroll
+        for (int q = 1; q < PF; q++)
+            if (first + q * NB_TILE < seg_b) fetch(first + q * NB_TILE, pwq[q]);
+        int rb = rbase(first);                              // the tile's first sample, counted around the ring
+        auto tile = [&](const long base, unsigned (&pw)[NW]) {
+#ifdef NB_MASK_LOADONLY                                      // experiment: the kernel's loads alone (the floor of its access pattern)
+            {
+                unsigned x = 0;
+#pragma unroll
+                for (int k = 0; k < NW; k++) x ^= pw[k];
+                if (base + PF * NB_TILE < seg_b) fetch(base + PF * NB_TILE, pw);
+                if (x == 0x12345679u) mrow[(base + (long)t * NB_PER) >> 5] = x;
+                return;
+            }
+#endif
             int mag[NB_PER];
             if constexpr (FMT == 1444) {
 #pragma unroll
                 for (int p = 0; p < NB_PER / 2; p++) {
-                    const unsigned d0 = pw[3 * p], d1 = pw[3 * p + 1], d2 = pw[3 * p + 2];
-                    const int i0 = (int)(d0 << 8), q0 = (int)(((d0 >> 24) << 8) | (d1 << 16));
-                    const int i1 = (int)(((d1 >> 16) << 8) | (d2 << 24)), q1 = (int)(d2 & 0xffffff00u);
-                    // |x| of a multiple of 256 as unsigned, then >> 8 (0x80000000 -> 2^23)
-                    auto m24 = [](int x, int y) -> int {
-                        const unsigned ax = x < 0 ? 0u - (unsigned)x : (unsigned)x, ay = y < 0 ? 0u - (unsigned)y : (unsigned)y;
-                        return (int)((ax > ay ? ax : ay) >> 8);
-                    };
-                    mag[2 * p] = m24(i0, q0); mag[2 * p + 1] = m24(i1, q1);
+                    // two samples = I0 Q0 I1 Q1, three bytes each, in three words.  With the four sign bits flipped (three
+                    // XORs on the packed words) a component is offset binary, b = x + 2^23, and |x| = |b - 2^23| is one
+                    // v_sad_u32; the two components that straddle words are picked out by one v_perm_b32 each
+                    const unsigned d0 = pw[3 * p] ^ 0x00800000u, d1 = pw[3 * p + 1] ^ 0x00008000u, d2 = pw[3 * p + 2] ^ 0x80000080u;
+                    const unsigned bi0 = d0 & 0x00ffffffu;
+                    const unsigned bq0 = __builtin_amdgcn_perm(d1, d0, 0x0c050403u);      // bytes d0[3] d1[0] d1[1] 0
+                    const unsigned bi1 = __builtin_amdgcn_perm(d2, d1, 0x0c040302u);      // bytes d1[2] d1[3] d2[0] 0
+                    const unsigned bq1 = d2 >> 8;
+                    const unsigned ai0 = nb_absdiff(bi0, 0x00800000u), aq0 = nb_absdiff(bq0, 0x00800000u);
+                    const unsigned ai1 = nb_absdiff(bi1, 0x00800000u), aq1 = nb_absdiff(bq1, 0x00800000u);
+                    mag[2 * p] = (int)(ai0 > aq0 ? ai0 : aq0); mag[2 * p + 1] = (int)(ai1 > aq1 ? ai1 : aq1);
                 }
             } else {
 #pragma unroll
@@ -522,45 +577,32 @@ void noiseblank_mask_int_kernel(NbArgs a)
                     mag[k] = (ai > aq ? ai : aq) << 8;
                 }
             }
-            // the magnitudes leaving the window: NB_PER / 4 + 1 aligned 16-byte reads of the ring, picked apart by the offset
-            int far[NB_PER];
-            {
-                int f0 = rb - M1 + t * NB_PER;
-                f0 = f0 < 0 ? f0 + NB_RING : f0;
-                const int4 *src = reinterpret_cast<const int4 *>(ring);
-                int q[NB_PER + 4];
-#pragma unroll
-                for (int v = 0; v <= NB_PER / 4; v++) {
-                    int fv = (f0 >> 2) + v;
-                    fv = fv >= NB_RING / 4 ? fv - NB_RING / 4 : fv;
-                    const int4 w4 = src[fv];
-                    q[4 * v] = w4.x; q[4 * v + 1] = w4.y; q[4 * v + 2] = w4.z; q[4 * v + 3] = w4.w;
-                }
-                switch ((unsigned)(-M1) & 3u) {
-#define NB_PICK(O_) case O_: _Pragma("unroll") for (int k = 0; k < NB_PER; k++) far[k] = q[O_ + k]; break;
-                    NB_PICK(0) NB_PICK(1) NB_PICK(2) default: NB_PICK(3)
-#undef NB_PICK
-                }
-            }
             const long left = seg_b - base, lead = seg_a - base;
             const int nvalid = left < NB_TILE ? (int)left : NB_TILE, nskip = lead > 0 ? (int)lead : 0;
             const bool live = t * NB_PER < nvalid;          // (nvalid is a multiple of eight: a thread is in or out whole)
+            // the magnitudes leaving the window
+            int far[NB_PER];
+            {
+                const int p0 = ((rb >> 3) + t + far_e0) & (PLANE - 1), p1 = (p0 + 1) & (PLANE - 1);
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) far[k] = ring[far_plane[k] + (far_hi[k] ? p1 : p0)];
+            }
             int d[NB_PER], run = 0, mmax = 0, dmin = 0x7fffffff;
 #pragma unroll
             for (int k = 0; k < NB_PER; k++) {
-                if (!live) mag[k] = 0;
-                run += live ? mag[k] - far[k] : 0;
+                run += mag[k] - far[k];                     // (a thread past the end of a call's last tile: unused, see below)
                 d[k] = run;                                 // thread-local inclusive prefix (|.| < 2^26)
                 mmax = mag[k] > mmax ? mag[k] : mmax;
                 dmin = run < dmin ? run : dmin;
             }
+            if (!live) run = 0;                            // (its fetch returned zeros: magnitudes 0 into the ring; nothing into the sums)
             {
-                int4 *dst = reinterpret_cast<int4 *>(ring) + ((rb + t * NB_PER) >> 2);
-                dst[0] = make_int4(mag[0], mag[1], mag[2], mag[3]);
-                dst[1] = make_int4(mag[4], mag[5], mag[6], mag[7]);
+                int *dst = ring + (rb >> 3) + t;             // (rb / 8 + t < PLANE: tiles divide the ring)
+#pragma unroll
+                for (int k = 0; k < NB_PER; k++) dst[k * PLANE] = mag[k];
             }
-            if (base + NB_TILE < seg_b) fetch(base + NB_TILE);
-            const long long incl = wave_incl_scan_add_i64((long long)run);
+            if (base + PF * NB_TILE < seg_b) fetch(base + PF * NB_TILE, pw);
+            const long long incl = wave_incl_scan_add_i27(run);
             if (lane == 63) wsum[w] = incl;
             __syncthreads();
             // the waves' sums: lane q < 8 reads wave q's, a three-step prefix inside the first row, two broadcasts (instead
@@ -632,6 +674,12 @@ void noiseblank_mask_int_kernel(NbArgs a)
             if (tile_last > NB_NEVER) last = (long long)base + tile_last;
             // (no barrier here: wsum is next written behind this tile's second barrier, which every wave reaches only after
             // its reads of wsum; wmax is next written behind the NEXT tile's first barrier, reached only after the reads of wmax)
+        };
+        for (long base = first; base < seg_b; base += PF * NB_TILE) {
+            tile(base, pwq[0]);
+#pragma unroll
+            for (int q = 1; q < PF; q++)
+                if (base + q * NB_TILE < seg_b) tile(base + q * NB_TILE, pwq[q]);
         }
         if (t == 0 && last_seg) {
             NbChan N = C;
