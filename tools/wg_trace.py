@@ -50,6 +50,7 @@ def run(mode="strict", out=None):
     kind = (r[:, 0] >> np.uint64(56)).astype(int)
     launch = ((r[:, 0] >> np.uint64(32)) & np.uint64(0xFFFFFF)).astype(int)
     t0 = r[:, 1].astype(np.int64); t1 = r[:, 2].astype(np.int64)
+    blk = (r[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     hw = r[:, 3] & np.uint64(0xFFFFFFFF)
     xcc = (r[:, 3] >> np.uint64(32)).astype(int) & 15
     cu = (xcc * 1024 + (((hw >> np.uint64(13)) & np.uint64(7)).astype(int)) * 32 + (((hw >> np.uint64(12)) & np.uint64(1)).astype(int)) * 16
@@ -90,6 +91,24 @@ def run(mode="strict", out=None):
         x["wgs_beside_a_walk_on_its_cu"] = int(on_walk_cu.sum())
         x["wg_us_beside_walk_vs_not"] = [round(float(np.median((e - s)[on_walk_cu])), 1) if on_walk_cu.any() else None,
                                          round(float(np.median((e - s)[~on_walk_cu])), 1) if (~on_walk_cu).any() else None]
+        # where the long workgroups are: the spread of the durations, by XCD, by the CU's share of the launch, by segment
+        d = e - s
+        x["wg_us_percentiles_5_25_50_75_95_100"] = [round(float(v), 1) for v in np.percentile(d, [5, 25, 50, 75, 95, 100])]
+        xm = xcc[m]
+        x["wg_us_median_by_xcd"] = [round(float(np.median(d[xm == q])), 1) if (xm == q).any() else None for q in range(8)]
+        per_cu = {}
+        for cc in c.tolist():
+            per_cu[cc] = per_cu.get(cc, 0) + 1
+        load = np.array([per_cu[cc] for cc in c.tolist()])
+        x["wgs_per_cu_min_max"] = [int(load.min()), int(load.max())]
+        x["wg_us_median_by_wgs_on_its_cu"] = {str(int(q)): round(float(np.median(d[load == q])), 1) for q in sorted(set(load.tolist()))}
+        b = blk[m]
+        # a launch is channels x segments, segment = block % nseg; nseg is not known here: the LAST blocks of the grid in
+        # issue order against the first ones tells whether late issue matters
+        order = np.argsort(b)
+        q4 = len(order) // 4
+        x["wg_us_median_by_block_quarter"] = [round(float(np.median(d[order[i * q4:(i + 1) * q4]])), 1) for i in range(4)]
+        x["end_us_percentiles_50_90_99_100"] = [round(float(v), 1) for v in np.percentile(e, [50, 90, 99, 100])]
         # start-time histogram in 50 us bins
         h, _ = np.histogram(s - s.min(), bins=np.arange(0, max(100.0, (s - s.min()).max() + 50.0), 50.0))
         x["start_hist_50us"] = h.tolist()
