@@ -325,6 +325,7 @@ def live_traffic(timeout_s=240):
             if not counts:
                 return None
             acc = {"k1": [], "k2": [], "k3": 0.0, "k6": [], "k6m": [], "chain": 0.0}
+            by_name = {}                                  # the chain steps' share, kernel by kernel
             dcs = []                                      # every down-converter dispatch: (dispatch id, value)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -344,12 +345,15 @@ def live_traffic(timeout_s=240):
                         acc["k6"].append(v)
                     else:
                         acc["chain"] += v
+                        short = name.split("csdr::")[-1].split("<")[0].split("(")[0]
+                        by_name[short] = by_name.get(short, 0.0) + v
             # the child runs "K2 alone" BEFORE its chain steps and says how many launches that was: the first counts["k2"]
             # down-converter dispatches are those, whatever grid the library's segment rule gave them (the grid size
             # depends on the channel count, the workgroup budget and CSDR_DC_WGS); the rest belong to the chain steps
             dcs.sort()
             acc["k2"] = [v for _, v in dcs[:counts["k2"]]]
             acc["chain"] += sum(v for _, v in dcs[counts["k2"]:])
+            by_name["downconv_kernel"] = sum(v for _, v in dcs[counts["k2"]:])
             if len(acc["k1"]) != counts["k1"] or len(acc["k2"]) != counts["k2"] or not acc["k6"] or not acc["k6m"] or \
                     len(dcs) <= counts["k2"]:
                 return None                               # a phase is missing or split differently: no figure rather than a wrong one
@@ -357,12 +361,17 @@ def live_traffic(timeout_s=240):
             per[counter] = {"k1": mean(acc["k1"]), "k2": mean(acc["k2"]), "k6": sum(acc["k6"]) / counts["k6"],
                             "k6m": sum(acc["k6m"]) / counts["k6m"],
                             "k3": acc["k3"] / counts["k3"] if counts.get("k3") else None,
-                            "chain": acc["chain"] / counts["chain"] if counts.get("chain") else None}
+                            "chain": acc["chain"] / counts["chain"] if counts.get("chain") else None,
+                            "chain_by_kernel": {k: v / counts["chain"] for k, v in by_name.items()} if counts.get("chain") else None}
         res = {}
         for key in ("k1", "k2", "k3", "k6", "k6m", "chain"):
             f, w = per["FETCH_SIZE"].get(key), per["WRITE_SIZE"].get(key)
             res[key] = None if f is None or w is None else {"bytes": (2.0 * f + w) * 1024.0, "FETCH_SIZE_KiB": round(f, 1),
                                                             "WRITE_SIZE_KiB": round(w, 1)}
+        fk, wk = per["FETCH_SIZE"].get("chain_by_kernel"), per["WRITE_SIZE"].get("chain_by_kernel")
+        if fk and wk and res.get("chain"):
+            res["chain"]["GB_by_kernel"] = {k: round((2.0 * fk.get(k, 0.0) + wk.get(k, 0.0)) * 1024.0 / 1e9, 3)
+                                            for k in sorted(set(fk) | set(wk))}
         res["source"] = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this script (KiB means per launch; "
                          "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md)")
         return res
@@ -1541,7 +1550,9 @@ def run_rank(args):
                         r = extra[name]["roofline"]
                         r["traffic"] = live[key]["bytes"]
                         r["traffic_over_algorithmic"] = round(live[key]["bytes"] / r["algorithmic_bytes_per_launch"], 3)
-                        r["traffic_counters_KiB"] = {k: v for k, v in live[key].items() if k != "bytes"}
+                        r["traffic_counters_KiB"] = {k: v for k, v in live[key].items() if k not in ("bytes", "GB_by_kernel")}
+                        if live[key].get("GB_by_kernel"):
+                            r["traffic_GB_by_kernel"] = live[key]["GB_by_kernel"]
                 if live.get("k6m") and "mask_kernel" in extra.get("packets_chain", {}):
                     r = extra["packets_chain"]["mask_kernel"]["roofline"]
                     r["traffic"] = live["k6m"]["bytes"]
