@@ -345,7 +345,7 @@ def live_traffic(timeout_s=240):
                         acc["k6"].append(v)
                     else:
                         acc["chain"] += v
-                        short = name.split("csdr::")[-1].split("<")[0].split("(")[0]
+                        short = name.split("csdr::", 1)[-1].split("<")[0].split("(")[0]
                         by_name[short] = by_name.get(short, 0.0) + v
             # the child runs "K2 alone" BEFORE its chain steps and says how many launches that was: the first counts["k2"]
             # down-converter dispatches are those, whatever grid the library's segment rule gave them (the grid size
