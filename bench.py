@@ -263,6 +263,8 @@ def condensed(extra):
         if o:
             others["spectrum_" + size] = {"ms": o.get("ms"), "frac": o.get("frac"), "parity_ok": g(o, "parity_checked", "ok")}
     sec = {"host_form_MSps": g(extra, "host_form", "raw_input_MSamples_per_s"), "host_form_parity_ok": g(extra, "host_form", "parity_checked", "ok"),
+           "host_form_deferred_MSps": g(extra, "host_form", "deferred_output", "raw_input_MSamples_per_s"),
+           "host_form_deferred_same_words": g(extra, "host_form", "deferred_output", "same_words_one_window_later"),
            "chain_c2_ms": g(extra, "chain_c2", "ms_per_call"), "chain_c2_parity_ok": g(extra, "chain_c2", "parity_checked", "ok"),
            "chain_c5_ms": g(extra, "chain_c5", "ms_per_call"), "chain_c5_parity_ok": g(extra, "chain_c5", "parity_checked", "ok"),
            "packets_chain_ms": g(extra, "packets_chain", "packets_chain_ms"),
@@ -913,6 +915,21 @@ def host_form(ca, with_cpu, check=True):
         if with_cpu:
             v, m = cpu_rate(lambda: r.process_append(x), n, 2.0)
             res["cpu_baseline"] = cpu_obj(v, m, "CDemodulator::ProcessData on the same stream")
+    del d
+    # the same with deferred output (csdr_demod_set_deferred, opt-in): a pass hands over the previous pass's audio, the
+    # chain's pass runs while the host converts the next window; the audio must be the undeferred object's, word for word
+    d = ca.CDemodulator(2048)
+    d.SetInputSampleRate(fs); d.SetDemod(ca.DEMOD_FM, fm_defaults(ca)); d.SetDemodFreq(-fc)
+    d.set_deferred(True)
+    run = lambda: _capi.check(L.csdr__demod_process_calls(d.h, n, call, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "host form, deferred")
+    k1 = run()
+    late = np.concatenate([out[:k1].copy(), d.flush()])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    dt2 = (time.perf_counter() - t0) / reps
+    res["deferred_output"] = {"raw_input_MSamples_per_s": round(n / dt2 / 1e6, 1),
+                              "same_words_one_window_later": bool(len(late) == len(first) and np.array_equal(late, first))}
     del d
     return res
 

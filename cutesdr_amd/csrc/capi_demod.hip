@@ -385,7 +385,15 @@ struct csdr_demod {
     // cross-engine dependency between a copy and the kernel behind it (9 us of copy + 10 us until the kernel started, per
     // pass, and a 4 us copy kernel on the way back).  CSDR_HOST_ZEROCOPY=0 restores the copies (d_in / d_out).
     bool zero_copy = true;
-    PinnedBuf win[2], pin_out;
+    PinnedBuf win[2], pin_out, pin_out2;
+    // DEFERRED output (csdr_demod_set_deferred): a pass that is due to return samples returns the PREVIOUS such pass's
+    // instead -- already complete, so the call does not wait -- and leaves its own in the other pinned buffer: the chain's
+    // pass runs while the caller converts the next window (host-form throughput x1.4-1.6), every sample comes out one
+    // window (10 ms at 2 MSPS) later, the last window's by csdr_demod_flush_*.
+    bool deferred = false;
+    int out_cur = 0;
+    int pend_k = 0, pend_buf = 0; bool pend_stereo = false;
+    hipEvent_t ev_out[2] = {nullptr, nullptr};
     int cur = 0;
     bool win_busy[2] = {false, false};
     hipEvent_t ev_win[2] = {nullptr, nullptr};   // window w's copy to the device has left the pinned buffer
@@ -401,6 +409,7 @@ struct csdr_demod {
     {
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         for (hipEvent_t e : ev_win) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_out) if (e) (void)hipEventDestroy(e);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
     }
@@ -649,6 +658,7 @@ csdr_demod *csdr_demod_create(int device, int fastfir_n)
     if (d->k.init(device, 1, fastfir_n) != CSDR_OK) { delete d; return nullptr; }
     bool ok = hipStreamCreateWithFlags(&d->s, hipStreamNonBlocking) == hipSuccess;
     for (auto &e : d->ev_win) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : d->ev_out) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { fail(CSDR_EHIP, "stream / event creation failed"); delete d; return nullptr; }
     csdr_downconvert_batch_set_cw_offset(d->k.dc, 0, 0.0);      // ctor: SetDemodFreq(0.0)
     csdr_downconvert_batch_set_frequency(d->k.dc, 0, 0.0);
@@ -704,6 +714,7 @@ int csdr_demod_get_buf_limit(csdr_demod *d) { return d ? d->limit : fail(CSDR_EI
 /* the chain's test points (dsp/demodulator.cpp:175,180,187,208): see include/cutesdr_mi.h */
 int csdr_demod_set_taps(csdr_demod *d, int mask, csdr_tap_fn fn, void *user)
 {
+    if (d && mask && d->deferred) return fail(CSDR_ESTATE, "stage taps and deferred output exclude each other");
     if (!d || mask < 0 || mask > 15) return fail(CSDR_EINVAL, "bad argument");
     if (d->s) CSDR_HIP(hipStreamSynchronize(d->s));
     d->k.taps = mask; d->tap_fn = fn; d->tap_user = user;
@@ -755,6 +766,17 @@ static int demod_emit_taps(csdr_demod *d, int k, bool stereo)
     const float *audio = d->zero_copy ? d->pin_out.p : d->d_out;
     return emit(4, audio, !d->zero_copy, k, stereo);
 }
+// deferred mode: the pending pass's samples (if any) to `out`; returns their count and clears the slot
+static int demod_take_pending(csdr_demod *d, double *out)
+{
+    const int k = d->pend_k;
+    if (k <= 0) return 0;
+    CSDR_HIP(hipEventSynchronize(d->ev_out[d->pend_buf]));
+    const PinnedBuf &pb = d->pend_buf ? d->pin_out2 : d->pin_out;
+    cvt_to_f64(out, pb.p, d->pend_stereo ? 2 * (size_t)k : (size_t)k);
+    d->pend_k = 0;
+    return k;
+}
 static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out, bool stereo, bool append)
 {
     if (!d || n < 0 || (n && (!in_iq || !out))) return fail(CSDR_EINVAL, "bad argument");
@@ -785,15 +807,18 @@ static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out,
         const float *chain_in = nullptr;
         float *chain_out = nullptr;
         size_t out_stride = 0;
+        // (deferred: the two output buffers in turn -- the one written now last held the pass before the pending one)
+        const int ob = d->deferred ? d->out_cur : 0;
+        PinnedBuf &pout = ob ? d->pin_out2 : d->pin_out;
         if (d->zero_copy) {
-            if (2 * need_out > d->pin_out.cap) {
+            if (2 * need_out > pout.cap) {
                 CSDR_HIP(hipStreamSynchronize(d->s));
-                if ((rc = d->pin_out.reserve(2 * need_out))) return rc;
+                if ((rc = pout.reserve(2 * need_out))) return rc;
             }
             void *pi = nullptr, *po = nullptr;
             CSDR_HIP(hipHostGetDevicePointer(&pi, w.p, 0));
-            CSDR_HIP(hipHostGetDevicePointer(&po, d->pin_out.p, 0));
-            chain_in = (const float *)pi; chain_out = (float *)po; out_stride = d->pin_out.cap / 2;
+            CSDR_HIP(hipHostGetDevicePointer(&po, pout.p, 0));
+            chain_in = (const float *)pi; chain_out = (float *)po; out_stride = pout.cap / 2;
         } else {
             if ((size_t)len > d->cap_in) {
                 CSDR_HIP(hipStreamSynchronize(d->s));
@@ -821,6 +846,21 @@ static int demod_process(csdr_demod *d, int n, const double *in_iq, double *out,
         d->win_busy[wcur] = true;
         if (k < 0) return k;
         if (d->k.taps) { const int rct = demod_emit_taps(d, k, stereo); if (rct) return rct; }
+        if (k > 0 && d->deferred) {
+            // this pass's samples stay where they are; the pending pass's -- complete, or nearly -- are handed over
+            const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
+            if (!d->zero_copy) {
+                if (nf > pout.cap) { CSDR_HIP(hipStreamSynchronize(d->s)); if ((rc = pout.reserve(nf))) return rc; }
+                CSDR_HIP(hipMemcpyAsync(pout.p, d->d_out, nf * 4, hipMemcpyDeviceToHost, d->s));
+            }
+            CSDR_HIP(hipEventRecord(d->ev_out[ob], d->s));
+            const int got = demod_take_pending(d, append ? out + (d->pend_stereo ? 2 : 1) * (size_t)ret : out);
+            if (got < 0) return got;
+            d->pend_k = k; d->pend_buf = ob; d->pend_stereo = stereo;
+            d->out_cur ^= 1;
+            ret += got;
+            continue;
+        }
         if (k > 0) {                                      // a pass that returns samples: the one wait of this call
             const size_t nf = stereo ? 2 * (size_t)k : (size_t)k;
             if (!d->zero_copy) {
@@ -840,6 +880,22 @@ int csdr_demod_process_stereo(csdr_demod *d, int n, const double *in_iq, double 
 { return demod_process(d, n, in_iq, out_iq, true, false); }
 int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, double *out)
 { return demod_process(d, n, in_iq, out, false, true); }
+int csdr_demod_set_deferred(csdr_demod *d, int on)
+{
+    if (!d) return fail(CSDR_EINVAL, "bad handle");
+    if (on && d->k.taps) return fail(CSDR_ESTATE, "stage taps and deferred output exclude each other");
+    if (!on && d->pend_k > 0) return fail(CSDR_ESTATE, "a pass is pending: csdr_demod_flush first");
+    d->deferred = on != 0;
+    return CSDR_OK;
+}
+int csdr_demod_flush(csdr_demod *d, double *out, int cap)
+{
+    if (!d || cap < 0 || (cap && !out)) return fail(CSDR_EINVAL, "bad argument");
+    const int need = d->pend_stereo ? 2 * d->pend_k : d->pend_k;
+    if (need > cap) return fail(CSDR_EINVAL, "the pending pass holds %d values, room for %d", need, cap);
+    if (!device_ok(d->k.device)) return CSDR_EHIP;
+    return demod_take_pending(d, out);
+}
 
 /* internal (bench.py `host_form`, tests; not in the public header): the reference's call pattern in one C loop --
  * n_total samples handed over in calls of call_len (one datagram: 240 / 256 samples, interface/sdrinterface.cpp:903),

@@ -73,6 +73,10 @@ public:
     {
 #ifdef CSDR_DROPIN_TESTBENCH
         csdr_dropin_count(csdr_demod_set_taps(m_h, CSDR_DROPIN_TESTBENCH_MASK, &CDemodulator::TestBenchTap, this), "CDemodulator taps");
+#elif defined(CSDR_DROPIN_DEFERRED)
+        // a live receiver, whose audio goes through the sound card's queue anyway: every pass hands over the previous
+        // pass's audio and ProcessData never waits for the device (csdr_demod_set_deferred; one window = 10 ms later)
+        csdr_dropin_count(csdr_demod_set_deferred(m_h, 1), "CDemodulator deferred output");
 #endif
     }
     virtual ~CDemodulator() { csdr_demod_destroy(m_h); }

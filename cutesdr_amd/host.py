@@ -559,6 +559,17 @@ class CDemodulator(_Obj):
         k = check(lib().csdr_demod_process_mono_append(self.h, len(a), _vp(a), _vp(out)), "process_append")
         return out[:k]
 
+    def set_deferred(self, on=True):
+        """deferred output (include/cutesdr_mi.h): a pass returns the previous pass's samples, the call never waits for
+        the device; flush() hands over the last pass"""
+        check(lib().csdr_demod_set_deferred(self.h, 1 if on else 0), "csdr_demod_set_deferred")
+
+    def flush(self, stereo=False):
+        cap = 2 * (self.n + 65536)
+        out = np.zeros(cap)
+        k = check(lib().csdr_demod_flush(self.h, _vp(out), cap), "csdr_demod_flush")
+        return out[:2 * k].view(np.complex128) if stereo else out[:k]
+
     def enable_taps(self, mask=15, callback=None):
         """the chain's test points PROFILE_1..4 (dsp/demodulator.cpp:175,180,187,208): bit k-1 of mask switches tap k on;
         callback(profile, n, data, is_complex, rate) is called per pass, else the samples accumulate for tap()"""

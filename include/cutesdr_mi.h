@@ -240,6 +240,15 @@ int csdr_demod_process_mono(csdr_demod *d, int n, const double *in_iq, double *o
 int csdr_demod_process_stereo(csdr_demod *d, int n, const double *in_iq, double *out_iq);
 /* same chain, passes append instead of overwriting (batch harness form) */
 int csdr_demod_process_mono_append(csdr_demod *d, int n, const double *in_iq, double *out);
+/* Deferred output (opt-in; no counterpart in the reference, whose ProcessData computes on the caller's thread).  With it
+ * on, a pass that is due to return samples (dsp/demodulator.cpp:169-214, every m_InBufLimit samples) returns the samples
+ * of the PREVIOUS such pass -- finished while the caller was handing over this window -- and leaves its own on the way:
+ * the call never waits for the device, the chain's pass and the caller's next m_InBufLimit samples overlap.  The same
+ * samples in the same order, one window later (10 ms at 2 MSPS); the first pass returns 0.  csdr_demod_flush hands over
+ * the last pass (returns its count: mono reals, stereo complex pairs; cap in doubles) -- before a switch back, a mode
+ * change between mono and stereo calls, or the end of the stream.  Not together with the stage taps. */
+int csdr_demod_set_deferred(csdr_demod *d, int on);
+int csdr_demod_flush(csdr_demod *d, double *out, int cap);
 /* Stage taps of the chain: what the reference hands to g_pTestBench->DisplayData(n, buf, m_OutputRate, PROFILE_k) in
  * every pass (dsp/demodulator.cpp:175,180,187,208; gui/testbench.h:29-38) -- PROFILE_1 the down-converter's output,
  * PROFILE_2 the band-pass filter's, PROFILE_3 the AGC's (n complex samples each, n = 0 while the filter is filling),

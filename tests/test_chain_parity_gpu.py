@@ -80,6 +80,44 @@ def test_chain_every_mode_from_sample_zero(oracle, mode, stereo):
     assert d.GetSMeterPeak() == r.GetSMeterPeak() == 5.0       # reading the peak reset it (smeter.cpp:98-103)
 
 
+@pytest.mark.parametrize("stereo", [False, True], ids=["mono", "stereo"])
+@pytest.mark.parametrize("mode", ["AM", "FM", "USB"])
+def test_deferred_output_is_the_same_stream_one_window_later(mode, stereo):
+    """csdr_demod_set_deferred: every pass hands over the previous pass's samples (the call does not wait for the device),
+    csdr_demod_flush the last one -- word for word what the undeferred object returns, in the reference's call pattern
+    (datagram-sized calls) and in whole-window calls."""
+    import cutesdr_amd as ca
+    m, kw = MODES[mode]
+    objs = []
+    for deferred in (False, True):
+        d = ca.CDemodulator(2048)
+        d.SetInputSampleRate(2e6); d.SetDemod(m, info(ca, **kw)); d.SetDemodFreq(-100e3)
+        if deferred:
+            d.set_deferred(True)
+        objs.append(d)
+    plain, late = objs
+    lim = plain.buf_limit()
+    x = chain_input(mode, lim * 30 + 777, 2e6)
+    for call in (256, lim):
+        a, b, counts_a, counts_b = [], [], [], []
+        for i in range(0, len(x), call):
+            ka, oa = plain.ProcessData(x[i:i + call], stereo)
+            kb, ob = late.ProcessData(x[i:i + call], stereo)
+            counts_a.append(ka); counts_b.append(kb)
+            a.append(oa[:ka].copy()); b.append(ob[:kb].copy())
+        b.append(late.flush(stereo))
+        a, b = np.concatenate(a), np.concatenate(b)
+        assert len(a) == len(b) and len(a) >= 4 * 1024, (len(a), len(b))
+        assert np.array_equal(a, b)
+        # one window later: the k-th pass that returns samples returns what the (k-1)-th produced
+        pa = [k for k in counts_a if k]; pb = [k for k in counts_b if k]
+        assert pb == pa[:-1] or (len(pa) == len(pb) + 1)
+    assert late.flush(stereo).size == 0                       # nothing pending any more
+    late.set_deferred(False)
+    with pytest.raises(Exception):
+        late.set_deferred(True); late.enable_taps(15)
+
+
 def test_fm_and_agc_stages_from_sample_zero_on_the_oracle_stream(oracle):
     """The start-up of an FM receiver, stage by stage on identical inputs: the oracle's post-filter and
     post-AGC streams (its DisplayData taps 2 and 3, dsp/demodulator.cpp:180,187) rounded to fp32 feed fresh AGC

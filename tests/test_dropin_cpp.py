@@ -12,17 +12,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 EXE = os.path.join(ROOT, "tests", "cpp", "dropin_host")
 
 
-def build_exe():
+def build_exe(exe=None, flags=()):
     from cutesdr_amd import _build
     _build.build()
+    exe = exe or EXE
     src = os.path.join(ROOT, "tests", "cpp", "dropin_host.cpp")
     hdrs = [os.path.join(ROOT, "cutesdr_amd", "dropin", "dsp", f) for f in os.listdir(os.path.join(ROOT, "cutesdr_amd", "dropin", "dsp"))]
-    if not os.path.exists(EXE) or any(os.path.getmtime(p) > os.path.getmtime(EXE) for p in [src] + hdrs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "cutesdr_amd", "dropin"),
-                               "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+    if not os.path.exists(exe) or any(os.path.getmtime(p) > os.path.getmtime(exe) for p in [src] + hdrs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", *flags, "-I", os.path.join(ROOT, "cutesdr_amd", "dropin"),
+                               "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                                "-L", os.path.join(ROOT, "cutesdr_amd"), "-lcutesdr_mi",
                                "-Wl,-rpath," + os.path.join(ROOT, "cutesdr_amd")])
-    return EXE
+    return exe
 
 
 def test_dropin_headers_compile_and_link_with_gpp():
@@ -129,6 +130,29 @@ def test_dropin_host_matches_oracle(oracle, tmp_path):
     assert float(smeter) == pytest.approx(d.GetSMeterAve(), abs=0.02)
     _, wpix = f.GetScreenIntegerFFTData(255, 700, 0.0, -160.0, -900000, 900000)
     assert np.abs(pix - wpix).max() <= 1
+
+
+def test_dropin_with_deferred_output_compiles():
+    assert os.path.exists(build_exe(EXE + "_deferred", ("-DCSDR_DROPIN_DEFERRED",)))
+
+
+@pytest.mark.gpu
+def test_dropin_host_with_deferred_output_returns_the_same_audio_one_window_later(tmp_path):
+    """-DCSDR_DROPIN_DEFERRED: the same host program, its CDemodulator never waiting for the
+    device -- the audio file is the undeferred build's, word for word, less the last pass (nobody flushes at exit)."""
+    from util_signals import fm_carrier
+    fs, n = 2e6, 19968 * 20
+    x = fm_carrier(n, fs, 100e3, dbfs=-20.0).astype(np.complex64).astype(np.complex128)
+    x.tofile(tmp_path / "in.bin")
+    audio = {}
+    for tag, exe in (("plain", build_exe()), ("late", build_exe(EXE + "_deferred", ("-DCSDR_DROPIN_DEFERRED",)))):
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / tag), "2", str(fs), "-100000"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        audio[tag] = np.fromfile(tmp_path / (tag + ".audio"))
+    a, b = audio["plain"], audio["late"]
+    assert 0 < len(a) - len(b) <= 1024 and len(b) >= 8 * 1024     # one pass = one 1024-sample hop at most (19968 / 32 = 624 per window)
+    assert np.array_equal(a[:len(b)], b)
 
 
 @pytest.mark.gpu
