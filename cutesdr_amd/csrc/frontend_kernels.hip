@@ -461,6 +461,7 @@ void noiseblank_mask_int_kernel(NbArgs a)
 {
     constexpr int NB_PER = NbTile<true, true>::PER, NB_TILE = NbTile<true, true>::TILE;
     static_assert(NB_PER == 8, "the packing below is written for eight samples per thread");
+    static_assert(NB_T == 512, "eight waves: their sums and trigger positions cross in one row of eight lanes (three DPP steps)");
     __shared__ long long wsum[NB_T / 64];
     __shared__ int wmax[NB_T / 64];
     extern __shared__ __attribute__((aligned(16))) float nb_ring[];
