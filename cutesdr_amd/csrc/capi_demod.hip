@@ -85,6 +85,8 @@ struct ChainCore {
         if (d_filt2) (void)hipFree(d_filt2);
         if (d_stage2) (void)hipFree(d_stage2);
         if (d_tap1) (void)hipFree(d_tap1);
+        if (ev_ff2) (void)hipEventDestroy(ev_ff2);
+        for (hipEvent_t e : ev_pdone2) if (e) (void)hipEventDestroy(e);
         if (s_post) stream_pool().put(device, s_post);
         if (s_fir) stream_pool().put(device, s_fir);
         if (ev_dc) (void)hipEventDestroy(ev_dc);
@@ -210,6 +212,11 @@ struct ChainCore {
     }
     // the two halves of step(): the down-converter of this call into the staging rows ...
     int m_call = 0;                     // decimated samples the down-converter of this call appended
+    // chained pipeline (csdr_demod_batch_set_pipelined, round 6): filter + shift stay in the down-converter's stream, the
+    // post-chain goes to a second one
+    hipEvent_t ev_ff2 = nullptr, ev_pdone2[2] = {nullptr, nullptr};
+    bool post_busy2[2] = {false, false};
+    int filt_cur2 = 0;
     int step_dc(const float *d_in, long in_stride, const int *d_in_rows, int n, hipStream_t s, hipEvent_t dc_after,
                 hipEvent_t dc_done)
     {
@@ -227,6 +234,51 @@ struct ChainCore {
         if (dc_done) CSDR_HIP(hipEventRecord(dc_done, s));
         m_call = m;
         return CSDR_OK;
+    }
+    // The chained pipeline's pass: the down-converter, the filter and the staging shift in stream s -- so that the filter
+    // reaches the chip in queue order behind its down-converter, BEFORE the next group's down-converter, which waits for an
+    // event between two streams (HISTORY, round 6 (d): the other order starves the filter for a whole launch) -- and the
+    // post-chain in stream sp, where it may run on into the next call: s is free for the next call's down-converter as soon
+    // as the filter has left.  The filter's output alternates between d_filt and d_agc (idle without the stage taps): with one
+    // buffer the next call's filter waited for this call's walk, and a first group's post-chain -- 1.5 ms when its peaks
+    // kernel is starved beside the down-converters -- set the period.  *joined: the stream the call's last work is in.
+    int step_split(const float *d_in, long in_stride, const int *d_in_rows, int n, float *d_out, long out_stride,
+                   const int *d_out_rows, bool stereo, hipStream_t s, hipStream_t sp, hipEvent_t dc_after, hipEvent_t dc_done,
+                   hipStream_t *joined)
+    {
+        if (taps) return fail(CSDR_ESTATE, "stage taps need the strict mode");
+        if (!ev_ff2) {
+            CSDR_HIP(hipEventCreateWithFlags(&ev_ff2, hipEventDisableTiming));
+            for (auto &e : ev_pdone2) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        static const bool one_buffer = getenv("CSDR_CHAIN_PIPELINE") && atoi(getenv("CSDR_CHAIN_PIPELINE")) != 0;   // (post() then uses d_agc itself)
+        *joined = s;
+        int rc = step_dc(d_in, in_stride, d_in_rows, n, s, dc_after, dc_done);
+        if (rc < 0) return rc;
+        const int total = pending + m_call, nb = total / L;
+        m_call = 0; last_out = 0; last_post = -1;
+        if (nb == 0) { pending = total; return 0; }
+        const int fc = one_buffer ? 0 : filt_cur2;
+        filt_cur2 ^= 1;
+        float *fb = fc ? d_agc : d_filt;
+        if (post_busy2[fc]) { CSDR_HIP(hipStreamWaitEvent(s, ev_pdone2[fc], 0)); post_busy2[fc] = false; }
+        rc = csdr_fastfir_batch_process(ff, d_stage, cap, nb * L, fb, cap, s, 0);
+        if (rc) return rc;
+        CSDR_HIP(hipEventRecord(ev_ff2, s));
+        const int rest = total - nb * L;
+        if (rest > 0) {
+            hipLaunchKernelGGL(shift_rows_kernel, dim3(rows), dim3(256), 0, s, d_stage, d_stage, cap, nb * L, rest);
+            CSDR_HIP(hipGetLastError());
+        }
+        pending = rest;
+        CSDR_HIP(hipStreamWaitEvent(sp, ev_ff2, 0));
+        rc = post(fb, d_out, out_stride, d_out_rows, stereo, nb, sp);
+        if (rc) return rc;
+        CSDR_HIP(hipEventRecord(ev_pdone2[fc], sp));
+        post_busy2[fc] = true;
+        *joined = sp;
+        last_out = nb * L;
+        return last_out;
     }
     // ... and everything behind it: filter, S-meter, AGC, demodulator, the staging shift
     int step_post(float *d_out, long out_stride, const int *d_out_rows, bool stereo, hipStream_t s)
@@ -435,6 +487,9 @@ struct csdr_demod_batch {
     std::vector<hipEvent_t> dc_done;                  // core -> its down-converter has been issued and finished
     hipEvent_t fork = nullptr;
     bool pipelined = false;                           // csdr_demod_batch_set_pipelined
+    bool chained = false;                             // ... its chained form (ChainCore::step_split): the cores stay plain
+    std::vector<hipStream_t> post_streams;            // chained pipeline: core -> its post-chain's stream
+    bool have_last_dc = false;                        // chained pipeline: dc_done[order.back()] holds the previous call's record
     int taps = 0;                                     // csdr_demod_batch_set_taps (new groups inherit it)
     bool rate_change_failed = false;                  // csdr_demod_batch_set_input_rate stopped half way: no processing until one succeeds
     std::vector<int> prev_post;                       // pipelined: per core, the post-chain event of the previous call
@@ -451,6 +506,7 @@ struct csdr_demod_batch {
         if (d_blank) (void)hipFree(d_blank);
         if (d_mask) (void)hipFree(d_mask);
         for (auto st : streams) stream_pool().put(device, st);
+        for (auto st : post_streams) stream_pool().put(device, st);
         for (auto ev : joins) (void)hipEventDestroy(ev);
         for (auto ev : dc_done) (void)hipEventDestroy(ev);
         if (fork) (void)hipEventDestroy(fork);
@@ -461,6 +517,7 @@ struct csdr_demod_batch {
 // first: its down-converter should not share the chip with the other groups' while its demodulators wait.
 static void batch_order(csdr_demod_batch *b)
 {
+    b->have_last_dc = false;                            // (the chained pipeline's link to the previous call's last group)
     std::vector<double> weight(b->cores.size(), 0.0);
     for (int c = 0; c < b->channels; c++) {
         if (b->core_of[c] < 0) continue;
@@ -532,6 +589,8 @@ static void batch_drop_core(csdr_demod_batch *b, int ki)
     b->d_rows.erase(b->d_rows.begin() + ki);
     b->d_out_rows.erase(b->d_out_rows.begin() + ki);
     if ((size_t)ki < b->streams.size()) { stream_pool().put(b->device, b->streams[ki]); b->streams.erase(b->streams.begin() + ki); }
+    if ((size_t)ki < b->post_streams.size()) { stream_pool().put(b->device, b->post_streams[ki]); b->post_streams.erase(b->post_streams.begin() + ki); }
+    b->have_last_dc = false;
     if ((size_t)ki < b->joins.size()) { (void)hipEventDestroy(b->joins[ki]); b->joins.erase(b->joins.begin() + ki); }
     if ((size_t)ki < b->dc_done.size()) { (void)hipEventDestroy(b->dc_done[ki]); b->dc_done.erase(b->dc_done.begin() + ki); }
     if ((size_t)ki < b->prev_post.size()) b->prev_post.erase(b->prev_post.begin() + ki);
@@ -1113,10 +1172,24 @@ int csdr_demod_batch_set_pipelined(csdr_demod_batch *b, int on)
         int rc = batch_plumbing(b);
         if (rc) return rc;
     }
-    if (on) for (auto *k : b->cores) { int rc = k->pipelined_init(); if (rc) return rc; }
+    // Two forms.  CHAINED (round 6, the default; on == 2 asks for it by name): the strict mode's schedule -- one
+    // down-converter at a time, each group's filter in queue order behind it -- carried across calls: the first group's next
+    // down-converter follows the last group's, the post-chains run in streams of their own and the caller joins a call behind
+    // the next call's launches.  Two streams per group, no second staging buffer.  1.65-1.68 ms per call of the C4 share, the
+    // strict mode's period, against 1.75-1.80 for THREE-STAGE (rounds 3-5; on == 3 or CSDR_PIPE_KIND=3): every group's
+    // down-converter at once, filter and post-chain on two more streams per group over double buffers.  A batch that has ever
+    // run the three-stage form keeps its cores' extra streams and stays with it.
+    static const int kind_env = getenv("CSDR_PIPE_KIND") ? atoi(getenv("CSDR_PIPE_KIND")) : 0;
+    bool plain = true;
+    for (auto *k : b->cores) plain = plain && !k->s_post;
+    const bool chained = on && plain && on != 3 && (on == 2 || kind_env != 3);
+    if (on && !chained) for (auto *k : b->cores) { int rc = k->pipelined_init(); if (rc) return rc; }
     b->prev_post.assign(b->cores.size(), -1);
     b->prev_join.assign(b->cores.size(), 0);
+    for (auto *k : b->cores) { k->post_busy2[0] = k->post_busy2[1] = false; }
+    b->have_last_dc = false;
     b->pipelined = on != 0;
+    b->chained = chained;
     return CSDR_OK;
 }
 /* stream-orders the caller's stream behind everything the batch has in flight (pipelined mode: the post-chain
@@ -1250,6 +1323,41 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         corun_wgs[0] = e ? atol(e) : 13L * cus;
     }
     const bool strict_multi = forked && !b->pipelined && plain && b->cores.size() > 1;
+    if (b->pipelined && b->chained && plain) {
+        int pr_lo = 0, pr_hi = 0;
+        CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        while (b->post_streams.size() < b->cores.size()) {
+            hipStream_t st;
+            CSDR_HIP(stream_pool().get(b->device, pr_hi, &st));
+            b->post_streams.push_back(st);
+        }
+        // the first group's down-converter runs beside the previous call's last walks: the co-run grid for it too
+        static const long first_wgs = getenv("CSDR_PIPE_FIRST_WGS") ? atol(getenv("CSDR_PIPE_FIRST_WGS")) : -1;
+        const size_t ng = b->cores.size();
+        for (size_t oi = 0; oi < ng; oi++) {
+            const size_t ki = (size_t)b->order[oi];
+            ChainCore &k = *b->cores[ki];
+            k.pk = d_packets; k.pk_len = pkt_len; k.blank = blank;
+            hipStream_t st = b->streams[ki], sp = b->post_streams[ki];
+            long wgs = ng > 1 ? (oi > 0 ? corun_wgs[oi > 1 ? 1 : 0] : (b->have_last_dc ? (first_wgs >= 0 ? first_wgs : corun_wgs[1]) : 0)) : 0;
+            csdr__downconvert_batch_set_wgs(k.dc, wgs);
+            CSDR_HIP(hipStreamWaitEvent(st, b->fork, 0));
+            // the caller's stream catches up with the PREVIOUS call behind this call's fork event (the pipelined contract)
+            if (b->prev_join[ki]) { CSDR_HIP(hipStreamWaitEvent(caller, b->joins[ki], 0)); b->prev_join[ki] = 0; }
+            // one down-converter at a time, across calls: behind the previous group's, the first behind the previous call's last
+            hipEvent_t after = oi > 0 ? b->dc_done[b->order[oi - 1]] : (b->have_last_dc ? b->dc_done[b->order[ng - 1]] : nullptr);
+            k.pc.sm_borrow = nullptr; k.pc.sm_own_side = false;
+            hipStream_t joined = st;
+            const int rc = k.step_split(d_in, in_stride, b->d_rows[ki], n_per_channel, d_out, out_stride, b->d_out_rows[ki], stereo,
+                                        st, sp, after, b->dc_done[ki], &joined);
+            if (rc < 0 && !err) err = rc;
+            CSDR_HIP(hipEventRecord(b->joins[ki], joined));
+            b->prev_join[ki] = 1;
+            b->prev_post[ki] = -1;
+        }
+        b->have_last_dc = !err;
+        return err ? err : CSDR_OK;
+    }
     // strict mode: CSDR_CHAIN_DC_CHAINED=0 starts every group's down-converter at once (A/B)
     static const bool dc_chained = !(getenv("CSDR_CHAIN_DC_CHAINED") && atoi(getenv("CSDR_CHAIN_DC_CHAINED")) == 0);
     for (size_t oi = 0; oi < b->cores.size(); oi++) {

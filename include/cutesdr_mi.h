@@ -309,14 +309,17 @@ int csdr_demod_batch_get_smeter_all(csdr_demod_batch *b, float *d_ave, float *d_
  * the filter walks whole hops, the post-chain whole bursts): one call of 24 windows = 24 calls of one, bit for bit. */
 int csdr_demod_batch_process(csdr_demod_batch *b, const float *d_in, long long in_stride,
                              int n_per_channel, float *d_out, long long out_stride, void *stream);
-/* Pipelined mode for streaming hosts (off by default).  on != 0: the three stages of a call (down-converter |
- * filter | S-meter, AGC, demodulator) run on internal streams and overlap the neighbouring calls' other stages; a
- * process call only enqueues.  In the caller's stream order, after process call k+1 the INPUT buffer of call k has
- * been consumed and the OUTPUT rows of call k-1 are complete; after csdr_demod_batch_flush everything issued so
- * far is complete.  Same results as the strict mode, word for word.
- * The mode runs three streams per plan group: give the process more than HIP's default four hardware queues
- * (GPU_MAX_HW_QUEUES=8 or more in the environment, before the runtime starts) or the streams share queues and the
- * mode is slower than the strict one (2.19 against 1.85 ms per call on 256 mixed receivers; 1.79 with 8 or 16). */
+/* Pipelined mode for streaming hosts (off by default).  on != 0: a process call only enqueues, and a call's post-chains
+ * (S-meter, AGC, demodulator) run on internal streams beside the NEXT call's down-converters.  In the caller's stream
+ * order, after process call k+1 the INPUT buffer of call k has been consumed and the OUTPUT rows of call k-1 are complete
+ * (the default form completes those of call k as well); after csdr_demod_batch_flush everything issued so far is
+ * complete.  Same results as the strict mode, word for word.
+ * on = 1 / 2: the chained form (round 6) -- the strict mode's schedule (one down-converter at a time, every group's
+ * filter in queue order behind its down-converter) carried across calls, two streams per plan group.  on = 3 (or
+ * CSDR_PIPE_KIND=3 in the environment): the three-stage form of rounds 3-5 -- every group's down-converter at once,
+ * filter and post-chain on two more streams per group over double buffers; it wants more than HIP's default four
+ * hardware queues (GPU_MAX_HW_QUEUES=8 or more) and is the slower one (1.75-1.80 against 1.65-1.68 ms per call on 256
+ * mixed receivers; the strict mode: 1.60-1.65). */
 int csdr_demod_batch_set_pipelined(csdr_demod_batch *b, int on);
 int csdr_demod_batch_flush(csdr_demod_batch *b, void *stream);
 /* the stereo overload (dsp/demodulator.cpp:221-273: AM/FM duplicate the audio into both halves, SAM splits the

@@ -378,12 +378,13 @@ def test_chain_words_do_not_depend_on_how_the_stream_is_cut():
         assert np.abs(mtr - meters[0]).max() <= 1e-3
 
 
-def test_pipelined_mode_gives_the_strict_mode_results():
+@pytest.mark.parametrize("form", [1, 3], ids=["chained", "three-stage"])
+def test_pipelined_mode_gives_the_strict_mode_results(form):
     """csdr_demod_batch_set_pipelined: the post-chain of call k overlaps the down-converter of call k+1 on
-    internal streams; four calls issued back to back without any host synchronisation, one flush at the end --
-    every output word equals the strict mode's."""
+    internal streams; six calls issued back to back without any host synchronisation, one flush at the end --
+    every output word equals the strict mode's.  Both forms: the chained one (the default) and the three-stage one."""
     import cutesdr_amd as ca
-    C, fs, n, calls = 12, 2e6, 19968 * 8, 4
+    C, fs, n, calls = 12, 2e6, 19968 * 8, 6
     names = ["AM", "FM", "USB", "SAM"]
     x = np.stack([chain_input(names[c % 4], calls * n, fs) * np.exp(2j * np.pi * 700.0 * c * np.arange(calls * n) / fs)
                   for c in range(C)]).astype(np.complex64)
@@ -398,7 +399,7 @@ def test_pipelined_mode_gives_the_strict_mode_results():
         for c in range(C):
             b.set_freq(c, -100e3 - 700.0 * c)
         if pipelined:
-            b.set_pipelined(True)
+            b.set_pipelined(form)
         cap = n // 8
         din = ca.DeviceBuffer(x.nbytes)
         dout = ca.DeviceBuffer(4 * C * cap * calls)
