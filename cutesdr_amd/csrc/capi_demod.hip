@@ -101,8 +101,8 @@ struct ChainCore {
     int pipeline_init()
     {
         if (s_dem) return CSDR_OK;
-        CSDR_HIP(stream_pool().get(device, 0, &s_dem));
-        CSDR_HIP(stream_pool().get(device, 0, &s_sm));
+        CSDR_HIP(stream_pool().get(device, 0, &s_dem, STREAM_SIDE));
+        CSDR_HIP(stream_pool().get(device, 0, &s_sm, STREAM_SIDE));
         CSDR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         CSDR_HIP(hipEventCreateWithFlags(&ev_dem, hipEventDisableTiming));
         CSDR_HIP(hipEventCreateWithFlags(&ev_sm, hipEventDisableTiming));
@@ -156,8 +156,8 @@ struct ChainCore {
         CSDR_HIP(hipDeviceSynchronize());
         int pr_lo = 0, pr_hi = 0;                        // the post-chain is the long pole of a call: highest priority
         CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        CSDR_HIP(stream_pool().get(device, pr_hi, &s_post));
-        CSDR_HIP(stream_pool().get(device, pr_hi, &s_fir));
+        CSDR_HIP(stream_pool().get(device, pr_hi, &s_post, STREAM_STAGE_POST));
+        CSDR_HIP(stream_pool().get(device, pr_hi, &s_fir, STREAM_STAGE_FIR));
         CSDR_HIP(hipEventCreateWithFlags(&ev_dc, hipEventDisableTiming));
         for (auto &e : ev_stage_free) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : ev_fir) CSDR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1328,7 +1328,7 @@ static int demod_batch_run(csdr_demod_batch *b, const float *d_in, long long in_
         CSDR_HIP(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
         while (b->post_streams.size() < b->cores.size()) {
             hipStream_t st;
-            CSDR_HIP(stream_pool().get(b->device, pr_hi, &st));
+            CSDR_HIP(stream_pool().get(b->device, pr_hi, &st, STREAM_POST));
             b->post_streams.push_back(st);
         }
         // the first group's down-converter runs beside the previous call's last walks: the co-run grid for it too

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 // The batch objects' internal streams come from a process-wide pool and go back to it: what a stream costs or gains
@@ -12,26 +13,37 @@
 // for every object the process makes.  (An idle pooled stream may still have work of its former owner in flight: a
 // stream is in-order, the new owner's work queues behind it.)
 namespace csdr {
+// A stream also keeps the ROLE it was created for (a plan group's stream, a chained pipeline's post-chain stream, the
+// three-stage pipeline's filter / post streams ...): the streams of one priority are not interchangeable -- a strict object
+// whose first group ran on a stream that had been created as a post-chain stream took 2.14-2.32 ms per C4 call instead of
+// 1.56 (tools/experiments/r6_repro_mode2.py: every second strict object after a pipelined one, by the order in which the
+// pool handed the streams out).  With the role in the key an object of either mode gets, role by role, the streams the first
+// object of that mode created.
+enum StreamRole { STREAM_GROUP = 0, STREAM_POST = 1, STREAM_STAGE_POST = 2, STREAM_STAGE_FIR = 3, STREAM_SIDE = 4 };
 struct StreamPool {
     std::mutex m;
-    std::map<std::pair<int, int>, std::vector<hipStream_t>> idle;      // (device, priority) -> streams
-    hipError_t get(int device, int prio, hipStream_t *out)
+    std::map<std::tuple<int, int, int>, std::vector<hipStream_t>> idle;      // (device, priority, role) -> streams
+    std::map<hipStream_t, int> role_of;
+    hipError_t get(int device, int prio, hipStream_t *out, int role = STREAM_GROUP)
     {
         {
             std::lock_guard<std::mutex> g(m);
-            auto &v = idle[{device, prio}];
-            if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+            auto &v = idle[std::make_tuple(device, prio, role)];
+            // first in, first out: objects return their streams in the order they took them
+            if (!v.empty()) { *out = v.front(); v.erase(v.begin()); return hipSuccess; }
         }
-        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+        const hipError_t e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+        if (e == hipSuccess) { std::lock_guard<std::mutex> g(m); role_of[*out] = role; }
+        return e;
     }
     void put(int device, hipStream_t s)
     {
         int prio = 0;
         if (hipStreamGetPriority(s, &prio) != hipSuccess) { (void)hipStreamDestroy(s); return; }
         std::lock_guard<std::mutex> g(m);
-        idle[{device, prio}].push_back(s);
+        const auto it = role_of.find(s);
+        idle[std::make_tuple(device, prio, it == role_of.end() ? (int)STREAM_GROUP : it->second)].push_back(s);
     }
 };
 inline StreamPool &stream_pool() { static StreamPool *p = new StreamPool(); return *p; }   // never destroyed: outlives every object
 }  // namespace csdr
-

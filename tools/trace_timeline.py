@@ -2,11 +2,11 @@
 """One step of a rocprofv3 --kernel-trace CSV as a timeline: kernels of the last complete step (steps are told apart
 by the first downconv launch of each), start / end in us from the step's first launch, with the queue each ran on.
    usage: tools/trace_timeline.py <dir> [steps back from the end, default 2] [anchor kernel substring]"""
-import csv, glob, sys
+import csv, glob, os, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "csdr" in r["Kernel_Name"]:
+        if "csdr" in r["Kernel_Name"] or os.environ.get("TIMELINE_ALL"):    # TIMELINE_ALL=1: the runtime's and torch's kernels too
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"],
                          int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
 rows.sort()
