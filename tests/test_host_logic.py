@@ -197,3 +197,32 @@ def test_the_retune_and_parameter_setters_hold_no_device_wide_synchronisation():
     asd = body("capi_demod.hip", "int apply_set_demod(")
     tail = asd[asd.index("c.cw_off = info.Offset;"):]
     assert "pull(" not in tail and "push(" not in tail and "hipDeviceSynchronize" not in tail
+
+
+def test_bench_fm_start_up_rule_is_the_derived_one():
+    """bench.py's spot check of a timed FM buffer applies the per-burst bounds of tests/startup_bounds.py (the oracle's own
+    spread x 2, counted from the burst in which the loop pulls in), not a fixed 1e-3 for the fourth burst."""
+    import importlib, os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    import startup_bounds as SB
+    hop, fs = 1024, bench.FULL_SCALE
+    want = np.zeros(12 * hop)
+    def errs(per_burst):
+        got = want.copy()
+        for b, e in enumerate(per_burst):
+            got[b * hop + 5] = e * fs
+        return got
+    bounds = [SB.FACTOR * s for s in SB.FM_SPREAD[1:]]
+    # pull-in in burst 0 (arbitrary there), then just inside every bound
+    ok = bench.chain_burst_check(errs([1.5] + [0.99 * b for b in bounds] + [2.9e-5] * 6), want, "FM")
+    assert ok["ok"] and ok["tolerance_steady"] == 3e-5
+    # the same stream with the pull-in one burst later (a 10 MSPS chain: its first burst is silent on both sides)
+    assert bench.chain_burst_check(errs([0.0, 1.5] + [0.99 * b for b in bounds] + [2.9e-5] * 5), want, "FM")["ok"]
+    # one burst over its bound fails, whichever it is
+    for k in range(len(bounds)):
+        e = [1.5] + [0.99 * b for b in bounds] + [2.9e-5] * 6
+        e[1 + k] = 1.01 * bounds[k]
+        assert not bench.chain_burst_check(errs(e), want, "FM")["ok"], k
+    assert not bench.chain_burst_check(errs([1.5] + [0.99 * b for b in bounds] + [3.1e-5] * 6), want, "FM")["ok"]
