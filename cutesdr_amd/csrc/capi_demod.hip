@@ -1517,6 +1517,34 @@ int csdr_demod_batch_process_blanked(csdr_demod_batch *b, const float *d_in, lon
     if (rc < 0) return rc;
     return demod_batch_run(b, d_in, in_stride, (int)n, d_out, out_stride, stream, false, nullptr, 0, &b->blank);
 }
+/* internal (diagnostics: tools/experiments/r6_repro_mode3.py): how fast each plan group's own buffers stream -- a
+ * device-to-device copy of the filter-output rows into the spare rows, timed with events, per group in the batch's launch
+ * order; us_out[k] = microseconds of the k-th group's copy, bytes_out[k] its size.  Synchronises. */
+extern "C" int csdr__demod_batch_probe(csdr_demod_batch *b, double *us_out, double *bytes_out, int cap)
+{
+    if (!b || !us_out || !bytes_out) return fail(CSDR_EINVAL, "bad argument");
+    if (!device_ok(b->device)) return CSDR_EHIP;
+    CSDR_HIP(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CSDR_HIP(hipEventCreate(&e0)); CSDR_HIP(hipEventCreate(&e1));
+    int n = 0;
+    for (size_t oi = 0; oi < b->cores.size() && n < cap; oi++, n++) {
+        ChainCore &k = *b->cores[(size_t)b->order[oi]];
+        const size_t bytes = (size_t)k.rows * (size_t)k.cap * 8;
+        us_out[n] = 0.0; bytes_out[n] = (double)bytes;
+        if (!k.d_filt || !k.d_agc || !bytes) continue;
+        for (int rep = 0; rep < 3; rep++) CSDR_HIP(hipMemcpyAsync(k.d_agc, k.d_filt, bytes, hipMemcpyDeviceToDevice, nullptr));
+        CSDR_HIP(hipEventRecord(e0, nullptr));
+        for (int rep = 0; rep < 10; rep++) CSDR_HIP(hipMemcpyAsync(k.d_agc, k.d_filt, bytes, hipMemcpyDeviceToDevice, nullptr));
+        CSDR_HIP(hipEventRecord(e1, nullptr));
+        CSDR_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CSDR_HIP(hipEventElapsedTime(&ms, e0, e1));
+        us_out[n] = ms * 100.0;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return n;
+}
 /* stage taps of a batch's receivers: see include/cutesdr_mi.h */
 int csdr_demod_batch_set_taps(csdr_demod_batch *b, int mask)
 {

@@ -37,4 +37,12 @@ remake(w, False)
 if os.environ.get("SLOW", "1") == "0":
     remake(w, False)
 torch.cuda.synchronize()
-print(json.dumps({"ms": round(bench.gpu_ms(torch, w.step, 8, 30), 3)}))
+ms = round(bench.gpu_ms(torch, w.step, 8, 30), 3)
+import ctypes as C
+L = ca.lib()
+L.csdr__demod_batch_probe.restype = C.c_int
+L.csdr__demod_batch_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+us, by = (C.c_double * 8)(), (C.c_double * 8)()
+n = L.csdr__demod_batch_probe(w.b.h, us, by, 8)
+print(json.dumps({"ms": ms, "group_buffers_copy_GBps": [round(2 * by[i] / us[i] / 1e3, 1) if us[i] else None for i in range(max(n, 0))],
+                  "group_buffer_MB": [round(by[i] / 1e6, 1) for i in range(max(n, 0))]}))
