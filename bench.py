@@ -1365,10 +1365,10 @@ class C4Workload:
         """the batch object of the wanted mode: ONE per mode for the workload's life, made on first use (a strict-mode
         object never creates the pipelined mode's streams: that is the path a host that never asks for pipelining runs)
         and kept while the other mode is timed; fresh=True replaces it by a new one (identical start for a comparison).
-        (Until round 6 every switch dropped the object and made a new one.  A batch object's step time turned out to be
-        bistable -- 1.6 or 2.0-2.2 ms for its whole life, by where its buffers land after other objects and torch
-        allocations have come and gone: tools/experiments/r6_repro_mode*.py, HISTORY -- so what is timed here are the
-        objects a process makes first, as in every earlier round.)"""
+        (Until round 6 every switch dropped the object and made a new one; what such a new object ran on depended on the
+        order in which the library's stream pool got its streams back -- 1.6 or 2.0-2.2 ms per step for the object's whole
+        life: tools/experiments/r6_repro_mode*.py, HISTORY.  The pool hands out the process's oldest streams now; the
+        workload keeps its objects anyway.)"""
         want = "pipelined" if pipelined else "strict"
         if want == self.mode and not fresh:
             return
@@ -1555,10 +1555,8 @@ def run_rank(args):
             if ctx.rank == 0:
                 extra["chain_c4"] = s
             if ctx.world == 1:                                   # single-GPU configurations: not part of a scaling run
-                # (the datagram chain on the strict object chain_c4 has just timed, the control plane -- which makes and
-                # drops several objects -- last: a batch object's step time is bistable, 1.6 or 2.0-2.2 ms for its whole
-                # life by what it collides with in its tail, and the object made right after control_plane's is the slow
-                # kind, run after run: tools/experiments/r6_repro_mode*.py, HISTORY round 6)
+                # (the datagram chain on the strict object chain_c4 has just timed; the control plane, which makes and drops
+                # objects, last)
                 extra["packets_chain"] = packets_chain(torch, ca, ctx, c4, check=not args.no_check)
                 extra["spectrum_c1"] = spectrum_c1(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check)
                 extra.update(input_rate_kernels(torch, ca, ctx, c4.x, with_cpu, check=not args.no_check))

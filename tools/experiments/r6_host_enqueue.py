@@ -9,6 +9,8 @@ import cutesdr_amd as ca
 import bench
 ctx = bench.dist_init()
 torch.cuda.set_device(0)
+if os.environ.get("OWN"):                # the caller on a stream of its own instead of the null stream
+    torch.cuda.set_stream(torch.cuda.Stream())
 out = {}
 for pipelined in (False, True):
     w = bench.C4Workload(torch, ca, ctx, 256)

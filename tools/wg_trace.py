@@ -24,6 +24,8 @@ def run(mode="strict", out=None):
     import bench
     ctx = bench.dist_init()
     torch.cuda.set_device(0)
+    if os.environ.get("WGTRACE_OWN_STREAM"):           # the caller on a stream of its own instead of the null stream
+        torch.cuda.set_stream(torch.cuda.Stream())
     w = bench.C4Workload(torch, ca, ctx, 256)
     w.set_mode(mode == "pipelined")
     if os.environ.get("WGTRACE_PRE") == "control_plane":
