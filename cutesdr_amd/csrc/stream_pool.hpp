@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <map>
 #include <mutex>
+#include <cstdlib>
 #include <tuple>
 #include <vector>
 
@@ -26,6 +27,27 @@ struct StreamPool {
     std::map<hipStream_t, int> role_of;
     std::map<hipStream_t, long> born;                     // creation order: the pool hands out the OLDEST idle stream of a class
     long next_born = 0;
+    // The chain runs at its speed only when the DEFAULT stream's hardware queue was made before the streams created here:
+    // 1.57-1.66 ms per C4 call then, whatever stream the caller uses, against 1.83-2.0 when the first streams of the process
+    // were the host's own or the library's (tools/experiments/r6_own_stream.py: OWN / NULLFIRST; HISTORY round 6).  The runtime
+    // makes a stream's queue at its first use, so: four bytes through the default stream, once per device, before the first
+    // stream is created.  (The one place the library touches the default stream; at that moment it has no work in flight.)
+    std::map<int, bool> touched;
+    void touch_default_stream(int device)
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (touched[device]) return;
+            touched[device] = true;
+        }
+        static const bool off = getenv("CSDR_NO_DEFAULT_STREAM_TOUCH") && atoi(getenv("CSDR_NO_DEFAULT_STREAM_TOUCH")) != 0;
+        if (off) return;
+        void *p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return;
+        (void)hipMemsetAsync(p, 0, 4, nullptr);
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(p);
+    }
     hipError_t get(int device, int prio, hipStream_t *out, int role = STREAM_GROUP)
     {
         {
@@ -41,6 +63,7 @@ struct StreamPool {
                 *out = v[best]; v.erase(v.begin() + best); return hipSuccess;
             }
         }
+        touch_default_stream(device);
         const hipError_t e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
         if (e == hipSuccess) { std::lock_guard<std::mutex> g(m); role_of[*out] = role; born[*out] = next_born++; }
         return e;

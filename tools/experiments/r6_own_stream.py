@@ -10,6 +10,8 @@ import bench
 ctx = bench.dist_init()
 torch.cuda.set_device(0)
 own = os.environ.get("OWN", "1") == "1"
+if os.environ.get("NULLFIRST"):          # some work on the default (null) stream before the host's own stream exists
+    torch.zeros(1 << 20, device="cuda").add_(1); torch.cuda.synchronize()
 if own:
     s = torch.cuda.Stream(priority=int(os.environ.get("PRIO", "0")))
     torch.cuda.set_stream(s)
